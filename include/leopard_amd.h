@@ -1,0 +1,109 @@
+/* leopard_amd.h — C ABI of libleopard_amd.so: the MI355X (gfx950) kernels behind Leopard's multi-image
+ * prefill path.
+ *
+ * The reference has NO native/FFI layer on this path: it is Python over `transformers` + PyTorch
+ * (SURVEY.md 0.1).  Each entry point below therefore replaces a *Python call site* of the reference; the
+ * citation gives the file:line of that call site (EVAL = evaluations/models/llava_multiimg_siglip_anyres.py)
+ * and, where the arithmetic lives in third-party code, the in-tree Megatron analogue that states the same math.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - raw device pointers + explicit sizes / leading dimensions (in ELEMENTS) + dtype enum + hipStream_t
+ *     (passed as void*); no torch types.  All pointers must be 16-byte aligned, leading dimensions multiples of 8.
+ *   - stream-ordered, no implicit synchronisation, no allocation: the caller owns every buffer.
+ *   - returns 0 on success, a negative LMI_E* code otherwise; lmi_last_error() gives a thread-local message.
+ *   - "T" below is the 16-bit compute type selected by `dtype` (LMI_F16 or LMI_BF16); accumulation, softmax
+ *     statistics, normalisation statistics and the residual stream are fp32.
+ */
+#ifndef LEOPARD_AMD_H
+#define LEOPARD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMI_OK 0
+#define LMI_EINVAL (-1)   /* bad argument (shape / alignment / enum) */
+#define LMI_ELAUNCH (-2)  /* HIP launch error */
+
+enum { LMI_F16 = 0, LMI_BF16 = 1, LMI_F32 = 2 };
+
+/* epilogues of lmi_gemm */
+enum {
+    LMI_EPI_STORE = 0,    /* out[T]   = act(acc + bias)                                   */
+    LMI_EPI_RESIDUAL = 1, /* out[f32] += acc + bias            (residual stream update)   */
+    LMI_EPI_STORE_F32 = 2,/* out[f32] = acc + bias + addmat[row % add_period]             */
+    LMI_EPI_SWIGLU = 3    /* out[T][:, N/2] = silu(gate) * up, W rows interleaved [32 gate | 32 up] */
+};
+enum { LMI_ACT_NONE = 0, LMI_ACT_GELU_TANH = 1, LMI_ACT_GELU_ERF = 2 };
+enum { LMI_A_PLAIN = 0, LMI_A_PIXEL_SHUFFLE = 1 };
+
+const char* lmi_last_error(void);
+int lmi_abi_version(void);
+
+/* Deterministic synthetic parameters (no checkpoints exist offline): element i = f(seed, i, kind); bit-identical
+ * to leopard_amd/synth.py.  out_dtype in {LMI_F16, LMI_BF16, LMI_F32}. */
+int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dtype, void* stream);
+
+/* a5 — replaces SiglipImageProcessor.preprocess + the patch gather of the SigLIP patch conv
+ * (EVAL:403-405; third-party modeling_siglip patch_embedding; analogue
+ * megatron_patch/model/idefics2/idefics_vision_tower.py:57-64).
+ * in: u8 tiles [n_tiles, S, S, 3] (from_u8=1; applies x/255 then (x-0.5)/0.5) or normalised fp32 pixel_values
+ * [n_tiles, 3, S, S] (from_u8=0).  out: T [n_tiles*(S/P)^2, ldo], column c*P*P+ky*P+kx, zero padded to ldo. */
+int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, int image_size, int patch,
+                         int ldo, int dtype, void* stream);
+
+/* LayerNorm (SigLIP layer_norm1/2, post_layernorm; analogue idefics_vision_tower.py:77-81,176) and
+ * RMSNorm (Llama input/post_attention/final norm; megatron/legacy/model/rms_norm.py:26-31):
+ * x fp32 [M, ldx] -> out T [M, ldo]; w, b fp32 [D]. */
+int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo,
+                  float eps, int dtype, void* stream);
+int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx, int ldo, float eps, int dtype,
+                void* stream);
+
+/* out = epilogue(A[M,K] . W[N,K]^T): every nn.Linear / conv-as-GEMM on the path —
+ * SigLIP patch-embed, q/k/v/out_proj, fc1 (+gelu_tanh), fc2; projector linear_1 (+gelu_erf, A gathered through
+ * the 2x2 pixel shuffle of EVAL:165-176) and linear_2 (EVAL:187-192); Llama qkv / o_proj / gate+up (+SwiGLU,
+ * megatron_patch/model/llava/transformer.py:136-139) / down_proj; all-position lm_head (EVAL:333).
+ * Requires N % 128 == 0, K % 64 == 0.  A, W are T; bias/addmat fp32 (nullable); row_map (nullable) scatters
+ * output row m to row row_map[m].  For LMI_A_PIXEL_SHUFFLE, A is the ViT output [tiles*G*G, K/4] and M counts
+ * shuffled rows (tiles*(G/2)^2). */
+int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* row_map,
+             int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
+             int ps_grid, int dtype, void* stream);
+
+/* Variable-length FlashAttention-2 forward over packed sequences (SigLIP: non-causal, head_dim 72, one
+ * sequence per tile; Llama: causal GQA, head_dim 128) — replaces the attention inside self.vision_tower(...)
+ * and self.language_model(...) (EVAL:268,322; analogue transformer.py:456-512 flash_attn_varlen_func).
+ * q/k/v/out: T, head h of row r at base + r*ld + h*head_dim.  cu_seqlens: int32 [n_seq+1] on device.
+ * Causal alignment is bottom-right (key j visible to query i iff j <= i + len_k - len_q).
+ * use_tr=1 uses ds_read_b64_tr_b16 for the V operand (production); 0 uses plain LDS gathers (cross-check). */
+int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,
+                        const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads,
+                        int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, int causal, int use_tr,
+                        int dtype, void* stream);
+
+/* RoPE (rotate-half; cos/sin fp32 [S, head_dim/2] built from position_ids and the llama3-scaled inverse
+ * frequencies, rotary_pos_embedding.py:48-83,197-239) applied in place to the q and k heads of packed qkv rows
+ * [S, ld]; when k_cache/v_cache are non-null also appends rotated K and V to the cache rows cache_pos0.. */
+int lmi_rope_qk(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_table,
+                const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int dtype,
+                void* stream);
+
+/* a10 — get_input_embeddings()(input_ids) + _merge_input_ids_with_image_features (EVAL:263,284-287; analogue
+ * megatron_patch/model/llava/vlm_model.py:526-533): out fp32 [S, D]; src[s] >= 0 -> embed_table[ids[src[s]]],
+ * src[s] < 0 -> visual_tokens[-src[s]-1] (fp32 [., ld_feats]).  ids, src: int64 on device. */
+int lmi_embed_merge(const int64_t* ids, const int64_t* src, const void* embed_table, const float* visual_tokens,
+                    float* out, int S, int D, int ld_feats, int dtype, void* stream);
+
+/* M = 1 weight-streaming GEMV: last-token lm_head (EVAL:333 restricted to the position generate() consumes)
+ * and the decode step (EVAL:291-320).  epilogue: 0 store fp32, 1 store T, 2 fp32 +=, 3 SwiGLU (N/2 outputs). */
+int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, int epilogue,
+             int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEOPARD_AMD_H */

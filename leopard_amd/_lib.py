@@ -1,0 +1,61 @@
+"""ctypes loader of libleopard_amd.so (the C ABI declared in include/leopard_amd.h).
+
+The product path has exactly one backend: the HIP library built for gfx950.  If it is missing this module
+raises — there is no CPU or PyTorch fallback (build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libleopard_amd.so")
+
+LMI_F16, LMI_BF16, LMI_F32 = 0, 1, 2
+EPI_STORE, EPI_RESIDUAL, EPI_STORE_F32, EPI_SWIGLU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
+A_PLAIN, A_PIXEL_SHUFFLE = 0, 1
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+
+# name -> argtypes  (restype is int unless noted); mirrors include/leopard_amd.h one to one
+SIGNATURES = {
+    "lmi_abi_version": [],
+    "lmi_fill_synthetic": [_P, C.c_int64, C.c_uint32, _I, _I, _P],
+    "lmi_preprocess_tiles": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "lmi_layernorm": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "lmi_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "lmi_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_attn_varlen_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
+    "lmi_rope_qk": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P],
+    "lmi_embed_merge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "lmi_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+}
+
+
+def bind(path: str) -> C.CDLL:
+    """dlopen ``path`` and attach the prototypes of every symbol the header declares."""
+    lib = C.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = the library does not export the ABI
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.lmi_last_error.argtypes = []
+    lib.lmi_last_error.restype = C.c_char_p
+    return lib
+
+
+_LIB = None
+
+
+def load() -> C.CDLL:
+    """The product library.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built (run `make` or "
+                "`__graft_entry__.build()`); leopard_amd has no CPU fallback")
+        _LIB = bind(LIB_PATH)
+    return _LIB

@@ -1,0 +1,254 @@
+// attention.h — variable-length FlashAttention-2 forward for gfx950 (wave64, v_mfma_f32_32x32x16).
+//
+// Serves both attention shapes on the Leopard prefill path:
+//   * SigLIP: non-causal, 16 heads x 72, one 676-token sequence per tile (cu_seqlens = 0,676,1352,..)
+//     third-party SiglipAttention; in-tree analogue megatron_patch/model/llava/transformer.py:456-512
+//     (flash_attn_varlen_func with cu_seqlens)
+//   * Llama-3.1: causal GQA 32 q / 8 kv heads x 128 over the merged [img0..imgN | text] sequence
+//     (megatron_patch/model/llava/transformer.py:678-885; GQA repeat :829-836)
+//
+// Work split: one workgroup = 128 query rows of one (sequence, head) = 4 waves x 32 rows; K/V walk in
+// 64-key tiles staged through registers into padded LDS images (the next tile's global loads are in
+// flight while the current tile is computed).
+//
+// Register-level design (everything stays in the lane that owns query row q = lane&31):
+//   S^T = K . Q^T   mfma32(A = K rows, B = Q rows)  -> lane (q, hi) holds 16 keys of its own row per 32-key block;
+//                   row max / row sum are in-lane + ONE exchange with lane^32.
+//   O^T = V^T . P^T mfma32(A = V^T, B = P^T)        -> the B operand is exactly the lane's own P registers (the
+//                   contraction index is a free permutation of keys, so no cross-lane shuffle of P is needed);
+//                   the A operand (8 keys for one d) comes from ds_read_b64_tr_b16 transpose reads of the
+//                   row-major V image; O^T's column is q, so the online-softmax rescale is a per-lane scalar.
+// Softmax statistics and accumulators are fp32; P is rounded to the 16-bit compute type for the PV MFMA.
+#pragma once
+#include "lmi_device.h"
+
+namespace lmi {
+
+struct AttnArgs {
+    const void* q;            // [total_q, ...] head h at q + row*ldq + h*D      (elements of T)
+    const void* k;            // head kvh at k + row*ldk + kvh*D
+    const void* v;
+    void* out;                // [total_q, ...] head h at out + row*ldo + h*D
+    const int* cu_q;          // [nseq+1]
+    const int* cu_k;          // [nseq+1]
+    int ldq, ldk, ldv, ldo;
+    int n_heads, n_kv_heads;
+    float scale;              // softmax scale (head_dim^-0.5)
+};
+
+constexpr int ATT_BQ = 128, ATT_BKV = 64, ATT_THREADS = 256;
+
+template <int D> struct AttnGeom {
+    static constexpr int DK = (D + 15) / 16 * 16;            // QK^T contraction length (zero padded)
+    static constexpr int NKS = DK / 16;
+    static constexpr int NDB = (D + 31) / 32;                // 32-row blocks of O^T
+    static constexpr int CH = D / 8;                         // 16-byte chunks per row in HBM
+    // K image row stride: an odd number of 16-byte chunks -> the 16 rows of a ds_read_b128 lane group land on
+    // 16 distinct slots of the 256-byte bank row.
+    static constexpr int KSTRIDE = ((DK / 8) | 1) * 16;
+    // V image row stride: odd multiple of 64 bytes -> the 4 key rows of one transpose read use disjoint banks.
+    static constexpr int VROW = NDB * 64;
+    static constexpr int VSTRIDE = ((VROW / 64) & 1) ? VROW : VROW + 64;
+    static constexpr int K_BYTES = ATT_BKV * KSTRIDE;
+    static constexpr int V_BYTES = ATT_BKV * VSTRIDE;
+    static constexpr int SMEM = K_BYTES + V_BYTES;
+    static constexpr int LD_ITERS = (ATT_BKV * CH + ATT_THREADS - 1) / ATT_THREADS;
+};
+
+// USE_TR = false replaces the hardware transpose reads of V by plain 16-bit LDS gathers (slow; kept as an
+// on-device cross-check of the ds_read_b64_tr_b16 addressing — tests run both).
+template <typename T, int D, bool CAUSAL, bool USE_TR>
+__global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
+    typedef AttnGeom<D> G;
+    typedef typename vec_of<T>::x8 T8;
+    typedef typename vec_of<T>::x4 T4;
+    LMI_DYN_SMEM(smem);
+    char* k_lds = smem;
+    char* v_lds = smem + G::K_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int seq = blockIdx.z, head = blockIdx.y;
+    const int kvh = head / (p.n_heads / p.n_kv_heads);
+    const int q_beg = p.cu_q[seq], len_q = p.cu_q[seq + 1] - q_beg;
+    const int k_beg = p.cu_k[seq], len_k = p.cu_k[seq + 1] - k_beg;
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;          // heavy (late) causal blocks first
+    const int q0 = qb * ATT_BQ;
+    if (q0 >= len_q) return;                                      // whole block exits together
+    const int shift = len_k - len_q;                              // causal: key j visible to query i iff j <= i + shift
+    int kv_end = len_k;
+    if (CAUSAL) kv_end = imin(len_k, q0 + ATT_BQ + shift);
+    const int n_tiles = (kv_end + ATT_BKV - 1) / ATT_BKV;
+
+    // zero the K pad columns once (QK^T contracts over DK >= D; stale LDS bits could be NaN)
+    if (G::DK > D) {
+        for (int i = tid; i < ATT_BKV * (G::DK - D) / 8; i += ATT_THREADS) {
+            const int r = i / ((G::DK - D) / 8), c = i % ((G::DK - D) / 8);
+            *(u32x4*)(k_lds + r * G::KSTRIDE + (G::CH + c) * 16) = u32x4{0, 0, 0, 0};
+        }
+    }
+
+    // ---- Q fragments straight from HBM: lane (q = fr, hi = fh) holds Q[q][16ks + 8hi .. +7] -------------------
+    const int my_q = q0 + wave * 32 + fr;
+    const int my_q_ld = imin(my_q, len_q - 1);
+    const T* q_row = (const T*)p.q + (long)(q_beg + my_q_ld) * p.ldq + head * D;
+    T8 qf[G::NKS];
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) {
+        const int c = 2 * ks + fh;
+        if (c < G::CH) qf[ks] = *(const T8*)(q_row + c * 8);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (T)0.0f;
+        }
+    }
+
+    // ---- K/V staging through registers ------------------------------------------------------------------
+    const T* k_base = (const T*)p.k + (long)k_beg * p.ldk + kvh * D;
+    const T* v_base = (const T*)p.v + (long)k_beg * p.ldv + kvh * D;
+    u32x4 kreg[G::LD_ITERS], vreg[G::LD_ITERS];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < G::LD_ITERS; ++it) {
+            const int i = tid + it * ATT_THREADS;
+            if (i < ATT_BKV * G::CH) {
+                const int r = i / G::CH, c = i - r * G::CH;
+                const int key = imin(t * ATT_BKV + r, len_k - 1);
+                kreg[it] = *(const u32x4*)(k_base + (long)key * p.ldk + c * 8);
+                vreg[it] = *(const u32x4*)(v_base + (long)key * p.ldv + c * 8);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < G::LD_ITERS; ++it) {
+            const int i = tid + it * ATT_THREADS;
+            if (i < ATT_BKV * G::CH) {
+                const int r = i / G::CH, c = i - r * G::CH;
+                *(u32x4*)(k_lds + r * G::KSTRIDE + c * 16) = kreg[it];
+                *(u32x4*)(v_lds + r * G::VSTRIDE + c * 16) = vreg[it];
+            }
+        }
+    };
+
+    f32x16 o_acc[G::NDB];
+#pragma unroll
+    for (int i = 0; i < G::NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = p.scale * 1.4426950408889634f;              // scale * log2(e)
+    const int wave_q_lo = q0 + wave * 32, wave_q_hi = wave_q_lo + 31;
+
+    // transpose-read lane geometry (see lmi_device.h ds_read_tr16_b64)
+    const int tr_j = (lane & 15) >> 2, tr_g = lane & 3, tr_half = (lane >> 4) & 1;
+
+    if (n_tiles > 0) load_tile(0);
+    for (int t = 0; t < n_tiles; ++t) {
+        __syncthreads();                                          // everyone is done with tile t-1
+        store_tile();
+        __syncthreads();
+        if (t + 1 < n_tiles) load_tile(t + 1);                    // flies under the MFMAs below
+        const int kv0 = t * ATT_BKV;
+        if (CAUSAL && kv0 > wave_q_hi + shift) continue;          // tile fully masked for this wave (uniform)
+
+        // ---- S^T = K . Q^T ----------------------------------------------------------------------------
+        f32x16 s[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < G::NKS; ++ks) {
+                const T8 kf = *(const T8*)(k_lds + (b * 32 + fr) * G::KSTRIDE + (2 * ks + fh) * 16);
+                s[b] = mfma32(kf, qf[ks], s[b]);
+            }
+        }
+        // ---- mask -----------------------------------------------------------------------------------
+        const bool need_mask = (kv0 + ATT_BKV > len_k) || (CAUSAL && (kv0 + ATT_BKV - 1 > wave_q_lo + shift));
+        if (need_mask) {
+            const int lim = CAUSAL ? imin(len_k - 1, my_q + shift) : len_k - 1;   // last visible key
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (key > lim) s[b][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax ---------------------------------------------------------------------------
+        float mx = s[0][0];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][r]);
+        mx = fmaxf(mx, shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        // rows that see no key at all so far (only query rows past len_q+shift<0 corner cases) keep m = -inf
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2((m_run - m_use) * c2);
+        m_run = m_new;
+        const float mc = m_use * c2;
+        float psum = 0.f;
+        T8 pf[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(s[b][r] * c2 - mc);
+                psum += pv;
+                pf[b][r >> 3][r & 7] = (T)pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < G::NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+
+        // ---- O^T += V^T . P^T -------------------------------------------------------------------------
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kbase = b * 32 + 16 * u + 4 * fh;
+                const char* a0 = v_lds + (kbase + tr_j) * G::VSTRIDE + (16 * tr_half + 4 * tr_g) * 2;
+                if (USE_TR) {
+                    u32x4 vraw[G::NDB];
+                    ds_read_tr16_batch<G::NDB, 8 * G::VSTRIDE>(a0, vraw);
+#pragma unroll
+                    for (int db = 0; db < G::NDB; ++db)
+                        o_acc[db] = mfma32(__builtin_bit_cast(T8, vraw[db]), pf[b][u], o_acc[db]);
+                } else {
+#pragma unroll
+                    for (int db = 0; db < G::NDB; ++db) {
+                        T8 vf;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            vf[j] = *(const T*)(v_lds + (kbase + (j & 3) + 8 * (j >> 2)) * G::VSTRIDE + (db * 32 + fr) * 2);
+                        o_acc[db] = mfma32(vf, pf[b][u], o_acc[db]);
+                    }
+                }
+            }
+    }
+
+    // ---- finish: O / l, store rows of this lane's query ---------------------------------------------------
+    const float l_tot = l_run + shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (my_q < len_q) {
+        T* o_row = (T*)p.out + (long)(q_beg + my_q) * p.ldo + head * D;
+#pragma unroll
+        for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int d = db * 32 + 8 * qd + 4 * fh;
+                if (d < D) {
+                    T4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (T)(o_acc[db][qd * 4 + e] * inv);
+                    *(T4*)(o_row + d) = o;
+                }
+            }
+    }
+}
+
+}  // namespace lmi

@@ -1,0 +1,275 @@
+// capi.hip — extern "C" launchers of libleopard_amd.so (see include/leopard_amd.h for the contract).
+// Built by hipcc for gfx950; the same file builds against tools/hipemu with -DLMI_EMU for CPU logic tests.
+#include "../../include/leopard_amd.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "attention.h"
+#include "elementwise.h"
+#include "gemm.h"
+
+using namespace lmi;
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LMI_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return LMI_OK;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <typename K>
+void allow_big_lds(K kernel, int bytes) {
+#ifndef LMI_EMU
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#else
+    (void)kernel; (void)bytes;
+#endif
+}
+
+int grid_for(long n, int block, int cap = 256 * 8) {
+    long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---- GEMM dispatch ---------------------------------------------------------------------------------------
+template <typename T, int EPI, int ACT, int AMODE>
+int launch_gemm(const GemmArgs& a, void* stream) {
+    const int tiles = ((a.M + GEMM_BM - 1) / GEMM_BM) * (a.N / GEMM_BN);
+    allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE>, GEMM_SMEM_BYTES);
+    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE>), dim3(tiles), dim3(GEMM_THREADS), GEMM_SMEM_BYTES, stream, a);
+    return check_launch("lmi_gemm");
+}
+
+template <typename T>
+int dispatch_gemm(const GemmArgs& a, int epi, int act, int amode, void* stream) {
+    if (amode == LMI_A_PIXEL_SHUFFLE) {
+        if (epi == LMI_EPI_STORE && act == LMI_ACT_GELU_ERF) return launch_gemm<T, EPI_STORE_T, ACT_GELU_ERF, AMODE_PIXSHUF>(a, stream);
+        if (epi == LMI_EPI_STORE && act == LMI_ACT_NONE) return launch_gemm<T, EPI_STORE_T, ACT_NONE, AMODE_PIXSHUF>(a, stream);
+        return fail(LMI_EINVAL, "lmi_gemm: pixel-shuffle A mode supports epilogue STORE with act none|gelu_erf");
+    }
+    switch (epi) {
+        case LMI_EPI_STORE:
+            if (act == LMI_ACT_NONE) return launch_gemm<T, EPI_STORE_T, ACT_NONE, AMODE_PLAIN>(a, stream);
+            if (act == LMI_ACT_GELU_TANH) return launch_gemm<T, EPI_STORE_T, ACT_GELU_TANH, AMODE_PLAIN>(a, stream);
+            if (act == LMI_ACT_GELU_ERF) return launch_gemm<T, EPI_STORE_T, ACT_GELU_ERF, AMODE_PLAIN>(a, stream);
+            break;
+        case LMI_EPI_RESIDUAL:
+            if (act == LMI_ACT_NONE) return launch_gemm<T, EPI_RESID_F32, ACT_NONE, AMODE_PLAIN>(a, stream);
+            break;
+        case LMI_EPI_STORE_F32:
+            if (act == LMI_ACT_NONE) return launch_gemm<T, EPI_STORE_F32, ACT_NONE, AMODE_PLAIN>(a, stream);
+            break;
+        case LMI_EPI_SWIGLU:
+            if (act == LMI_ACT_NONE) return launch_gemm<T, EPI_SWIGLU_T, ACT_NONE, AMODE_PLAIN>(a, stream);
+            break;
+    }
+    return fail(LMI_EINVAL, "lmi_gemm: unsupported epilogue/act combination (%d, %d)", epi, act);
+}
+
+// ---- attention dispatch ------------------------------------------------------------------------------------
+template <typename T, int D, bool CAUSAL, bool USE_TR>
+int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
+    const int qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
+    allow_big_lds(attn_fwd_kernel<T, D, CAUSAL, USE_TR>, AttnGeom<D>::SMEM);
+    LMI_LAUNCH((attn_fwd_kernel<T, D, CAUSAL, USE_TR>), dim3(qblocks, a.n_heads, n_seq), dim3(ATT_THREADS),
+               AttnGeom<D>::SMEM, stream, a);
+    return check_launch("lmi_attn_varlen_fwd");
+}
+template <typename T, int D>
+int dispatch_attn(const AttnArgs& a, int n_seq, int max_q, int causal, int use_tr, void* stream) {
+    if (causal) return use_tr ? launch_attn<T, D, true, true>(a, n_seq, max_q, stream)
+                              : launch_attn<T, D, true, false>(a, n_seq, max_q, stream);
+    return use_tr ? launch_attn<T, D, false, true>(a, n_seq, max_q, stream)
+                  : launch_attn<T, D, false, false>(a, n_seq, max_q, stream);
+}
+
+template <typename T, int EPI>
+int launch_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, void* stream) {
+    const int rows = (EPI == GEMV_SWIGLU_T) ? N / 2 : N;
+    const int grid = grid_for(rows, 4);
+    if (K <= 4096) {
+        LMI_LAUNCH((gemv_kernel<T, EPI, 8>), dim3(grid), dim3(256), 0, stream, (const T*)W, (const T*)x, bias, out, N, K, ldw);
+    } else {
+        LMI_LAUNCH((gemv_kernel<T, EPI, 28>), dim3(grid), dim3(256), 0, stream, (const T*)W, (const T*)x, bias, out, N, K, ldw);
+    }
+    return check_launch("lmi_gemv");
+}
+template <typename T>
+int dispatch_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, int epi, void* stream) {
+    switch (epi) {
+        case 0: return launch_gemv<T, GEMV_STORE_F32>(W, x, bias, out, N, K, ldw, stream);
+        case 1: return launch_gemv<T, GEMV_STORE_T>(W, x, bias, out, N, K, ldw, stream);
+        case 2: return launch_gemv<T, GEMV_RESID_F32>(W, x, bias, out, N, K, ldw, stream);
+        case 3: return launch_gemv<T, GEMV_SWIGLU_T>(W, x, bias, out, N, K, ldw, stream);
+    }
+    return fail(LMI_EINVAL, "lmi_gemv: bad epilogue %d", epi);
+}
+template <typename T, bool RMS>
+int norm_impl(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo,
+                     float eps, void* stream, const char* what) {
+    if (!x || !w || !out || (!RMS && !b) || M < 0 || D <= 0 || (D & 3) || D > 4096 || (ldx & 3) || (ldo & 3) ||
+        !aligned16(x) || !aligned16(w) || !aligned16(out))
+        return fail(LMI_EINVAL, "%s: bad argument (M=%d D=%d ldx=%d ldo=%d; D%%4==0, D<=4096)", what, M, D, ldx, ldo);
+    if (M == 0) return LMI_OK;
+    const int grid = (M + 3) / 4;
+    if (D <= 1280) LMI_LAUNCH((norm_kernel<T, RMS, 5>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
+    else LMI_LAUNCH((norm_kernel<T, RMS, 16>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
+    return check_launch(what);
+}
+
+template <typename T>
+int im2col_impl(const void* in, int from_u8, void* out, int n_tiles, int S, int P, int ldo, int grid, void* stream) {
+    if (from_u8) LMI_LAUNCH((im2col_kernel<T, true>), dim3(grid), dim3(256), 0, stream, in, (T*)out, n_tiles, S, P, ldo);
+    else LMI_LAUNCH((im2col_kernel<T, false>), dim3(grid), dim3(256), 0, stream, in, (T*)out, n_tiles, S, P, ldo);
+    return check_launch("lmi_preprocess_tiles");
+}
+template <typename T>
+int rope_impl(void* qkv, int S, int ld, int nq, int nkv, int D, const float* c, const float* s, void* kc, void* vc,
+              int ldc, int pos0, int grid, void* stream) {
+    LMI_LAUNCH((rope_kernel<T>), dim3(grid), dim3(256), 0, stream, (T*)qkv, S, ld, nq, nkv, D, c, s, (T*)kc, (T*)vc, ldc, pos0);
+    return check_launch("lmi_rope_qk");
+}
+template <typename T>
+int merge_impl(const int64_t* ids, const int64_t* src, const void* table, const float* feats, float* out, int S, int D,
+               int ld_feats, void* stream) {
+    LMI_LAUNCH((embed_merge_kernel<T>), dim3(S), dim3(256), 0, stream, (const long*)ids, (const long*)src, (const T*)table,
+               feats, out, D, ld_feats);
+    return check_launch("lmi_embed_merge");
+}
+
+}  // namespace
+
+#define LMI_DISPATCH_T(dtype, CALL_F16, CALL_BF16)                                   \
+    do {                                                                              \
+        if ((dtype) == LMI_F16) return CALL_F16;                                      \
+        if ((dtype) == LMI_BF16) return CALL_BF16;                                    \
+        return fail(LMI_EINVAL, "%s: dtype must be LMI_F16 or LMI_BF16", __func__);   \
+    } while (0)
+
+extern "C" {
+
+const char* lmi_last_error(void) { return g_err; }
+int lmi_abi_version(void) { return 1; }
+
+int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dtype, void* stream) {
+    if (!out || n < 0 || kind < 0 || kind > 2) return fail(LMI_EINVAL, "lmi_fill_synthetic: bad argument");
+    if (n == 0) return LMI_OK;
+    const int grid = grid_for(n, 256);
+    if (out_dtype == LMI_F16) LMI_LAUNCH((fill_synth_kernel<f16_t>), dim3(grid), dim3(256), 0, stream, (f16_t*)out, (long)n, seed, kind);
+    else if (out_dtype == LMI_BF16) LMI_LAUNCH((fill_synth_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, (bf16_t*)out, (long)n, seed, kind);
+    else if (out_dtype == LMI_F32) LMI_LAUNCH((fill_synth_kernel<float>), dim3(grid), dim3(256), 0, stream, (float*)out, (long)n, seed, kind);
+    else return fail(LMI_EINVAL, "lmi_fill_synthetic: bad out_dtype %d", out_dtype);
+    return check_launch("lmi_fill_synthetic");
+}
+
+int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, int image_size, int patch, int ldo,
+                         int dtype, void* stream) {
+    if (!in || !out || n_tiles < 0 || patch <= 0 || image_size % patch || ldo < 3 * patch * patch || (ldo & 7))
+        return fail(LMI_EINVAL, "lmi_preprocess_tiles: bad shape (S=%d P=%d ldo=%d)", image_size, patch, ldo);
+    if (n_tiles == 0) return LMI_OK;
+    const int g = image_size / patch;
+    const int grid = grid_for((long)n_tiles * g * g * ldo, 256);
+    LMI_DISPATCH_T(dtype, (im2col_impl<f16_t>(in, from_u8, out, n_tiles, image_size, patch, ldo, grid, stream)),
+                   (im2col_impl<bf16_t>(in, from_u8, out, n_tiles, image_size, patch, ldo, grid, stream)));
+}
+
+int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps,
+                  int dtype, void* stream) {
+    LMI_DISPATCH_T(dtype, (norm_impl<f16_t, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm")),
+                   (norm_impl<bf16_t, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm")));
+}
+
+int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx, int ldo, float eps, int dtype,
+                void* stream) {
+    LMI_DISPATCH_T(dtype, (norm_impl<f16_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm")),
+                   (norm_impl<bf16_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm")));
+}
+
+int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* row_map,
+             int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
+             int ps_grid, int dtype, void* stream) {
+    if (!A || !W || !out) return fail(LMI_EINVAL, "lmi_gemm: null pointer");
+    if (M < 0 || N <= 0 || K <= 0 || (N % GEMM_BN) || (K % GEMM_BK))
+        return fail(LMI_EINVAL, "lmi_gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+    if ((lda & 7) || (ldw & 7) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out) ||
+        (bias && !aligned16(bias)) || (addmat && !aligned16(addmat)))
+        return fail(LMI_EINVAL, "lmi_gemm: pointers must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
+    if (addmat && add_period <= 0) return fail(LMI_EINVAL, "lmi_gemm: addmat needs add_period > 0");
+    if (a_mode == LMI_A_PIXEL_SHUFFLE) {
+        if (ps_grid <= 0 || (ps_grid & 1) || (K & 3) || ((K / 4) % GEMM_BK) || (M % ((ps_grid / 2) * (ps_grid / 2))))
+            return fail(LMI_EINVAL, "lmi_gemm: pixel-shuffle needs even grid, (K/4) %% 64 == 0, M %% (G/2)^2 == 0");
+    } else if (a_mode != LMI_A_PLAIN) {
+        return fail(LMI_EINVAL, "lmi_gemm: bad a_mode %d", a_mode);
+    }
+    if (M == 0) return LMI_OK;
+    GemmArgs a;
+    a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.row_map = row_map;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid;
+    LMI_DISPATCH_T(dtype, dispatch_gemm<f16_t>(a, epilogue, act, a_mode, stream),
+                   dispatch_gemm<bf16_t>(a, epilogue, act, a_mode, stream));
+}
+
+int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,
+                        const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                        int ldq, int ldk, int ldv, int ldo, float scale, int causal, int use_tr, int dtype, void* stream) {
+    if (!q || !k || !v || !out || !cu_seqlens_q || !cu_seqlens_k) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: null pointer");
+    if (n_seq < 0 || max_seqlen_q < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads))
+        return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: bad head counts (%d, %d)", n_heads, n_kv_heads);
+    if (head_dim != 128 && head_dim != 72) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: head_dim %d not in {72, 128}", head_dim);
+    if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out))
+        return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: alignment");
+    if (n_seq == 0 || max_seqlen_q == 0) return LMI_OK;
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale;
+    if (head_dim == 128)
+        LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
+                       (dispatch_attn<bf16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
+    LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 72>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
+                   (dispatch_attn<bf16_t, 72>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
+}
+
+int lmi_rope_qk(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_table,
+                const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int dtype, void* stream) {
+    if (!qkv || !cos_table || !sin_table || S < 0 || (head_dim & 15) || (ld & 7) || ((k_cache || v_cache) && (ld_cache & 7)) ||
+        ((k_cache != nullptr) != (v_cache != nullptr)))
+        return fail(LMI_EINVAL, "lmi_rope_qk: bad argument");
+    if (S == 0) return LMI_OK;
+    const long work = (long)S * ((n_q_heads + n_kv_heads) * (head_dim / 16) + (v_cache ? n_kv_heads * head_dim / 8 : 0));
+    const int grid = grid_for(work, 256);
+    LMI_DISPATCH_T(dtype, (rope_impl<f16_t>(qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, k_cache, v_cache, ld_cache, cache_pos0, grid, stream)),
+                   (rope_impl<bf16_t>(qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, k_cache, v_cache, ld_cache, cache_pos0, grid, stream)));
+}
+
+int lmi_embed_merge(const int64_t* ids, const int64_t* src, const void* embed_table, const float* visual_tokens, float* out,
+                    int S, int D, int ld_feats, int dtype, void* stream) {
+    if (!ids || !src || !embed_table || !out || S < 0 || (D & 7) || (ld_feats & 3)) return fail(LMI_EINVAL, "lmi_embed_merge: bad argument");
+    if (S == 0) return LMI_OK;
+    LMI_DISPATCH_T(dtype, (merge_impl<f16_t>(ids, src, embed_table, visual_tokens, out, S, D, ld_feats, stream)),
+                   (merge_impl<bf16_t>(ids, src, embed_table, visual_tokens, out, S, D, ld_feats, stream)));
+}
+
+int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, int epilogue, int dtype,
+             void* stream) {
+    if (!W || !x || !out || N <= 0 || K <= 0 || (K & 7) || (ldw & 7) || K > 28 * 512 || (epilogue == 3 && (N & 63)))
+        return fail(LMI_EINVAL, "lmi_gemv: bad argument (N=%d K=%d)", N, K);
+    LMI_DISPATCH_T(dtype, dispatch_gemv<f16_t>(W, x, bias, out, N, K, ldw, epilogue, stream),
+                   dispatch_gemv<bf16_t>(W, x, bias, out, N, K, ldw, epilogue, stream));
+}
+
+}  // extern "C"

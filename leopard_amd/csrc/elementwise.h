@@ -1,0 +1,252 @@
+// elementwise.h — the HBM-bound kernels of the prefill path (SURVEY.md 2.5 "Bound by: HBM" rows):
+// tile normalisation + im2col, LayerNorm / RMSNorm over the fp32 residual stream, RoPE (+ KV-cache write),
+// embedding gather + image/text merge, last-token lm_head GEMV, synthetic parameter fill.
+// All of them move 16 bytes per lane where the layout allows and reduce with wave64 shuffles.
+#pragma once
+#include "lmi_device.h"
+
+namespace lmi {
+
+// ------------------------------------------------------------------------------------------------
+// synthetic fill: element i of tensor `seed` (see leopard_amd/synth.py — same integer hash, bit-exact)
+// ------------------------------------------------------------------------------------------------
+LMI_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+LMI_DEV float synth_value(uint32_t seed, uint64_t i, int kind) {
+    uint32_t h = mix32((uint32_t)i ^ seed);
+    h = mix32(h + (uint32_t)(i >> 32) * 0x9E3779B9u + 0x85EBCA6Bu);
+    const float b = (float)(h >> 24);
+    if (kind == 0) return (2.0f * b - 255.0f) * 0x1p-13f;
+    if (kind == 1) return (2.0f * b - 255.0f) * 0x1p-15f;
+    return (112.0f + floorf(b * 0.125f)) * 0x1p-7f;
+}
+template <typename OUT>
+__global__ void fill_synth_kernel(OUT* out, long n, uint32_t seed, int kind) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (OUT)synth_value(seed, (uint64_t)i, kind);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5: u8 tiles [N,S,S,3] (HWC) or fp32 pixel_values [N,3,S,S] -> normalised im2col rows
+//     out[(n*G + py)*G + px][c*P*P + ky*P + kx]  (K padded with zeros to ldo)
+//     value law = SiglipImageProcessor: x*(1/255) then (x-0.5)/0.5   (EVAL:403-404)
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool FROM_U8>
+__global__ void im2col_kernel(const void* in, T* out, int n_tiles, int S, int P, int ldo) {
+    const int G = S / P, KD = 3 * P * P;
+    const long total = (long)n_tiles * G * G * ldo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % ldo);
+        const long row = i / ldo;
+        float v = 0.f;
+        if (col < KD) {
+            const int c = col / (P * P), rem = col - c * P * P, ky = rem / P, kx = rem - ky * P;
+            const int px = (int)(row % G), py = (int)((row / G) % G);
+            const long n = row / ((long)G * G);
+            const int y = py * P + ky, x = px * P + kx;
+            if (FROM_U8) {
+                const float u = (float)((const uint8_t*)in)[((n * S + y) * S + x) * 3 + c];
+                v = (u * (1.0f / 255.0f) - 0.5f) / 0.5f;
+            } else {
+                v = ((const float*)in)[((n * 3 + c) * S + y) * (long)S + x];
+            }
+        }
+        out[i] = (T)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (SigLIP, eps 1e-6) / RMSNorm (Llama, eps 1e-5): fp32 stream row -> 16-bit GEMM operand row.
+// One wave per row, row kept in registers, statistics in fp32 with two passes (mean, then centred variance).
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool RMS, int MAXV>     // MAXV = max float4 chunks per lane (D <= MAXV*256)
+__global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* w, const float* b, T* out,
+                                                   int M, int D, int ldx, int ldo, float eps) {
+    typedef typename vec_of<T>::x4 T4;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long)row * ldx;
+    const int nvec = D >> 2;                         // float4 chunks in the row (D % 4 == 0)
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            v[i] = *(const f32x4*)(xr + c * 4);
+            s += RMS ? (v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3])
+                     : (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
+        }
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = 1.0f / sqrtf(s / (float)D + eps);
+    } else {
+        mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        rstd = 1.0f / sqrtf(q / (float)D + eps);
+    }
+    T* orow = out + (long)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            const f32x4 ww = *(const f32x4*)(w + c * 4);
+            T4 o;
+            if (RMS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)(ww[e] * (v[i][e] * rstd));
+            } else {
+                const f32x4 bb = *(const f32x4*)(b + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)((v[i][e] - mean) * rstd * ww[e] + bb[e]);
+            }
+            *(T4*)(orow + c * 4) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE (rotate-half, cos/sin tables [S, D/2] fp32 built by the host from position_ids and the llama3-scaled
+// inverse frequencies) applied in place to the q and k heads of the packed qkv rows; optionally writes the
+// rotated K and the V rows into the KV cache [S_cache, n_kv*D] at row cache_pos0 + s.
+// One thread = one 8-element chunk d..d+7 of the first half and its partner chunk d+D/2..  (D = 128)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rope_kernel(T* qkv, int S, int ld, int n_q, int n_kv, int D, const float* cosT, const float* sinT,
+                            T* k_cache, T* v_cache, int ld_cache, int cache_pos0) {
+    typedef typename vec_of<T>::x8 T8;
+    const int half = D >> 1, cpr = half >> 3;                 // chunks per half row
+    const int rot_heads = n_q + n_kv;
+    const int per_tok = rot_heads * cpr + (v_cache ? n_kv * (D >> 3) : 0);
+    const long total = (long)S * per_tok;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(i / per_tok);
+        int w = (int)(i - (long)s * per_tok);
+        T* row = qkv + (long)s * ld;
+        if (w < rot_heads * cpr) {
+            const int h = w / cpr, c = w - h * cpr;
+            T* p1 = row + h * D + c * 8;
+            T* p2 = p1 + half;
+            const T8 a = *(const T8*)p1, b = *(const T8*)p2;
+            const float* cs = cosT + (long)s * half + c * 8;
+            const float* sn = sinT + (long)s * half + c * 8;
+            T8 oa, ob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x1 = (float)a[e], x2 = (float)b[e];
+                oa[e] = (T)(x1 * cs[e] - x2 * sn[e]);
+                ob[e] = (T)(x2 * cs[e] + x1 * sn[e]);
+            }
+            *(T8*)p1 = oa;
+            *(T8*)p2 = ob;
+            if (k_cache && h >= n_q) {
+                T* kc = k_cache + (long)(cache_pos0 + s) * ld_cache + (h - n_q) * D + c * 8;
+                *(T8*)kc = oa;
+                *(T8*)(kc + half) = ob;
+            }
+        } else {
+            w -= rot_heads * cpr;
+            const int h = w / (D >> 3), c = w - h * (D >> 3);
+            const T8 a = *(const T8*)(row + (n_q + n_kv + h) * D + c * 8);
+            *(T8*)(v_cache + (long)(cache_pos0 + s) * ld_cache + h * D + c * 8) = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a10: embedding gather + image/text merge into the fp32 residual stream.
+//   src[s] >= 0 : row = embed_table[ids[src[s]]]   (16-bit -> fp32)
+//   src[s] <  0 : row = visual_tokens[-src[s]-1]   (fp32 projector output)
+// one workgroup per output row
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_merge_kernel(const long* ids, const long* src, const T* table, const float* feats,
+                                   float* out, int D, int ld_feats) {
+    typedef typename vec_of<T>::x8 T8;
+    const long s = blockIdx.x;
+    const long sv = src[s];
+    float* o = out + s * D;
+    if (sv >= 0) {
+        const T* t = table + ids[sv] * (long)D;
+        for (int c = threadIdx.x; c < (D >> 3); c += blockDim.x) {
+            const T8 a = *(const T8*)(t + c * 8);
+            f32x4 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = (float)a[e]; hi[e] = (float)a[e + 4]; }
+            *(f32x4*)(o + c * 8) = lo;
+            *(f32x4*)(o + c * 8 + 4) = hi;
+        }
+    } else {
+        const float* f = feats + (-sv - 1) * (long)ld_feats;
+        for (int c = threadIdx.x; c < (D >> 2); c += blockDim.x) *(f32x4*)(o + c * 4) = *(const f32x4*)(f + c * 4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-streaming GEMV (M = 1): out[n] = W[n,:] . x  — last-token lm_head and the decode step.
+// One wave per output row (per gate/up row pair for SwiGLU); x is held in registers; W streams 16 B / lane.
+// ------------------------------------------------------------------------------------------------
+enum { GEMV_STORE_F32 = 0, GEMV_STORE_T = 1, GEMV_RESID_F32 = 2, GEMV_SWIGLU_T = 3 };
+
+template <typename T, int EPI, int KCH>       // KCH = 16-byte chunks per lane (K = KCH*512)
+__global__ void __launch_bounds__(256) gemv_kernel(const T* W, const T* x, const float* bias, void* out,
+                                                   int N, int K, int ldw) {
+    typedef typename vec_of<T>::x8 T8;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    T8 xv[KCH];
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c * 8 < K) xv[i] = *(const T8*)(x + c * 8);
+    }
+    auto dot = [&](const T* wrow) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = i * 64 + lane;
+            if (c * 8 < K) {
+                const T8 wv = *(const T8*)(wrow + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float)wv[e] * (float)xv[i][e];
+            }
+        }
+        return wave_sum(acc);
+    };
+    if (EPI == GEMV_SWIGLU_T) {
+        // rows interleaved in 32-row blocks [gate | up]: output j pairs rows 64*(j/32) + j%32 and +32
+        const int n_out = N >> 1;
+        for (int j = wave; j < n_out; j += nwaves) {
+            const int r0 = ((j >> 5) << 6) + (j & 31);
+            const float g = dot(W + (long)r0 * ldw), u = dot(W + (long)(r0 + 32) * ldw);
+            if (lane == 0) ((T*)out)[j] = (T)(g / (1.0f + lmi::fexp(-g)) * u);
+        }
+    } else {
+        for (int n = wave; n < N; n += nwaves) {
+            float v = dot(W + (long)n * ldw);
+            if (lane == 0) {
+                if (bias) v += bias[n];
+                if (EPI == GEMV_STORE_F32) ((float*)out)[n] = v;
+                else if (EPI == GEMV_STORE_T) ((T*)out)[n] = (T)v;
+                else ((float*)out)[n] += v;
+            }
+        }
+    }
+}
+
+}  // namespace lmi

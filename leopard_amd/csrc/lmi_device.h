@@ -1,0 +1,245 @@
+// lmi_device.h — the few hardware primitives every Leopard-MI kernel is written against.
+//
+// Device build (hipcc --offload-arch=gfx950): thin inline wrappers over the CDNA4 builtins
+// (v_mfma_f32_32x32x16_{bf16,f16}, global_load_lds_dwordx4, ds_read_b64_tr_b16, wave64 shuffles).
+//
+// LMI_EMU build (host clang, tools/hipemu): the same names implemented by a lock-step fibre emulator
+// so that kernel *logic* (tile indexing, swizzles, masks, epilogues) can be unit-tested on a machine
+// without a GPU.  The emulator is a development tool only; the product library never contains it.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef LMI_EMU
+#include "hipemu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+namespace lmi {
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct vec_of;
+template <> struct vec_of<f16_t> { typedef f16x8 x8; typedef f16x4 x4; typedef f16x2 x2; };
+template <> struct vec_of<bf16_t> { typedef bf16x8 x8; typedef bf16x4 x4; typedef bf16x2 x2; };
+
+#define LMI_WAVE 64
+
+#ifndef LMI_EMU
+// ------------------------------------------------------------------------------------------------
+// device
+// ------------------------------------------------------------------------------------------------
+#define LMI_DEV __device__ __forceinline__
+#define LMI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+
+LMI_DEV int lane_id() { return threadIdx.x & 63; }
+
+// D[32x32] += A[32x16] * B[16x32].  Lane l supplies A[l&31][8*(l>>5)+j] and B[8*(l>>5)+j][l&31], j=0..7;
+// receives D[(r&3)+8*(r>>2)+4*(l>>5)][l&31], r=0..15.
+LMI_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+LMI_DEV f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// D[16x16] += A[16x32] * B[32x16].  Lane l supplies A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15];
+// receives D[4*(l>>4)+r][l&15], r=0..3.
+LMI_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+LMI_DEV f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// async 16-byte global -> LDS copy: LDS destination = lds_wave_base + lane*16 (wave-uniform base).
+LMI_DEV void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS transpose read: within each 16-lane group, lane i = 4*j+g supplies the address of 4 consecutive
+// 16-bit elements (row j, column group g); lane c receives {row0[c], row1[c], row2[c], row3[c]}.
+LMI_DEV u32x2 ds_read_tr16_b64(const void* lds_ptr) {
+    u32x2 r;
+    unsigned addr = (unsigned)(size_t)lds_ptr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+
+// Batched form used by attention: for d-block i = 0..N-1 read the 4-key groups at byte offsets i*64 and
+// i*64 + ROW8 from one base address, one wait for all 2N reads.  out[i] = {lo.x, lo.y, hi.x, hi.y}.
+template <int N, int ROW8>
+LMI_DEV void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
+    static_assert(N == 3 || N == 4, "d-block count");
+    unsigned addr = (unsigned)(size_t)lds_ptr;
+    u32x2 a0, a1, a2, a3, b0, b1, b2, b3;
+    if constexpr (N == 4) {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8 offset:%c9\n\t"
+            "ds_read_b64_tr_b16 %1, %8 offset:%c10\n\t"
+            "ds_read_b64_tr_b16 %2, %8 offset:%c11\n\t"
+            "ds_read_b64_tr_b16 %3, %8 offset:%c12\n\t"
+            "ds_read_b64_tr_b16 %4, %8 offset:%c13\n\t"
+            "ds_read_b64_tr_b16 %5, %8 offset:%c14\n\t"
+            "ds_read_b64_tr_b16 %6, %8 offset:%c15\n\t"
+            "ds_read_b64_tr_b16 %7, %8 offset:%c16\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2), "=&v"(a3), "=&v"(b3)
+            : "v"(addr), "i"(0), "i"(ROW8), "i"(64), "i"(64 + ROW8), "i"(128), "i"(128 + ROW8), "i"(192), "i"(192 + ROW8)
+            : "memory");
+        out[3] = u32x4{a3[0], a3[1], b3[0], b3[1]};
+    } else {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %6 offset:%c7\n\t"
+            "ds_read_b64_tr_b16 %1, %6 offset:%c8\n\t"
+            "ds_read_b64_tr_b16 %2, %6 offset:%c9\n\t"
+            "ds_read_b64_tr_b16 %3, %6 offset:%c10\n\t"
+            "ds_read_b64_tr_b16 %4, %6 offset:%c11\n\t"
+            "ds_read_b64_tr_b16 %5, %6 offset:%c12\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2)
+            : "v"(addr), "i"(0), "i"(ROW8), "i"(64), "i"(64 + ROW8), "i"(128), "i"(128 + ROW8)
+            : "memory");
+    }
+    out[0] = u32x4{a0[0], a0[1], b0[0], b0[1]};
+    out[1] = u32x4{a1[0], a1[1], b1[0], b1[1]};
+    out[2] = u32x4{a2[0], a2[1], b2[0], b2[1]};
+}
+
+LMI_DEV float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+LMI_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
+LMI_DEV float shfl(float v, int l) { return __shfl(v, l, 64); }
+LMI_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+LMI_DEV void setprio_hi() { __builtin_amdgcn_s_setprio(1); }
+LMI_DEV void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
+LMI_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+LMI_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+LMI_DEV float fexp(float x) { return __expf(x); }
+
+#define LMI_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+
+#else
+// ------------------------------------------------------------------------------------------------
+// host emulation (tools/hipemu/hipemu.cpp)
+// ------------------------------------------------------------------------------------------------
+#define LMI_DEV inline
+#define LMI_DYN_SMEM(name) char* name = hipemu::dyn_smem()
+
+inline int lane_id() { return threadIdx.x & 63; }
+
+template <typename V8>
+inline f32x16 emu_mfma32(V8 a, V8 b, f32x16 c) {
+    struct Slot { float a[8], b[8]; };
+    Slot* s = (Slot*)hipemu::wave_buf();
+    const int l = lane_id();
+    for (int j = 0; j < 8; ++j) { s[l].a[j] = (float)a[j]; s[l].b[j] = (float)b[j]; }
+    hipemu::wave_sync();
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc += s[row + 32 * (k >> 3)].a[k & 7] * s[col + 32 * (k >> 3)].b[k & 7];
+        c[r] = acc;
+    }
+    hipemu::wave_sync();
+    return c;
+}
+template <typename V8>
+inline f32x4 emu_mfma16(V8 a, V8 b, f32x4 c) {
+    struct Slot { float a[8], b[8]; };
+    Slot* s = (Slot*)hipemu::wave_buf();
+    const int l = lane_id();
+    for (int j = 0; j < 8; ++j) { s[l].a[j] = (float)a[j]; s[l].b[j] = (float)b[j]; }
+    hipemu::wave_sync();
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc += s[row + 16 * (k >> 3)].a[k & 7] * s[col + 16 * (k >> 3)].b[k & 7];
+        c[r] = acc;
+    }
+    hipemu::wave_sync();
+    return c;
+}
+inline f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return emu_mfma32(a, b, c); }
+inline f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return emu_mfma32(a, b, c); }
+inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return emu_mfma16(a, b, c); }
+inline f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return emu_mfma16(a, b, c); }
+
+inline void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_memcpy((char*)lds_wave_base + lane_id() * 16, gptr, 16);
+}
+
+inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {
+    struct Slot { uint16_t e[4]; };
+    Slot* s = (Slot*)hipemu::wave_buf();
+    const int l = lane_id();
+    __builtin_memcpy(s[l].e, lds_ptr, 8);
+    hipemu::wave_sync();
+    const int grp = l & ~15, c = l & 15;
+    uint16_t o[4];
+    for (int j = 0; j < 4; ++j) o[j] = s[grp + 4 * j + (c >> 2)].e[c & 3];
+    hipemu::wave_sync();
+    u32x2 r;
+    r[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+    r[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+    return r;
+}
+
+template <int N, int ROW8>
+inline void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
+    for (int i = 0; i < N; ++i) {
+        const u32x2 lo = ds_read_tr16_b64((const char*)lds_ptr + i * 64);
+        const u32x2 hi = ds_read_tr16_b64((const char*)lds_ptr + i * 64 + ROW8);
+        out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+
+template <typename S>
+inline S emu_shfl_idx(S v, int src) {
+    S* s = (S*)hipemu::wave_buf();
+    s[lane_id()] = v;
+    hipemu::wave_sync();
+    S r = s[src & 63];
+    hipemu::wave_sync();
+    return r;
+}
+inline float shfl_xor(float v, int m) { return emu_shfl_idx(v, lane_id() ^ m); }
+inline int shfl_xor(int v, int m) { return emu_shfl_idx(v, lane_id() ^ m); }
+inline float shfl(float v, int l) { return emu_shfl_idx(v, l); }
+inline void sched_fence() {}
+inline void setprio_hi() {}
+inline void setprio_lo() {}
+inline float fast_exp2(float x) { return exp2f(x); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+inline float fexp(float x) { return expf(x); }
+
+#define LMI_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipemu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
+
+#endif  // LMI_EMU
+
+// ------------------------------------------------------------------------------------------------
+// shared helpers
+// ------------------------------------------------------------------------------------------------
+LMI_DEV int imin(int a, int b) { return a < b ? a : b; }
+LMI_DEV int imax(int a, int b) { return a > b ? a : b; }
+template <typename T> LMI_DEV float to_f32(T v) { return (float)v; }
+template <typename T> LMI_DEV T from_f32(float v) { return (T)v; }
+
+LMI_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
+LMI_DEV float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+    return v;
+}
+
+}  // namespace lmi

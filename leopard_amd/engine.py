@@ -1,0 +1,313 @@
+"""Prefill / decode orchestration of the Leopard-LLaVA hot path on one MI355X.
+
+Host Python only sequences kernel launches on the current HIP stream; every arithmetic step is a call into
+libleopard_amd.so (see leopard_amd/ops.py).  The data path mirrors the reference forward
+(evaluations/models/llava_multiimg_siglip_anyres.py:261-333, "EVAL"):
+
+    u8 tiles / pixel_values --lmi_preprocess_tiles--> im2col rows
+      --GEMM(+bias +pos-emb)--> fp32 ViT stream --27x[LN, QKV GEMM, varlen attention (one 676-token sequence per
+      tile), out-proj GEMM(+residual), LN, fc1 GEMM(+gelu_tanh), fc2 GEMM(+residual)]--> post-LN           (EVAL:268-273)
+      --GEMM(pixel-shuffle gather, +gelu_erf)--GEMM--> visual tokens [N*169, 4096] fp32                      (EVAL:283)
+      --lmi_embed_merge (host-planned index map)--> fp32 LLM stream [S, 4096]                                (EVAL:263,285)
+      --32x[RMSNorm, QKV GEMM, RoPE(+KV cache), causal GQA attention, o GEMM(+residual), RMSNorm,
+            gate/up GEMM(+SwiGLU), down GEMM(+residual)]--> final RMSNorm --> lm_head                        (EVAL:322-333)
+
+HBM residency: the residual streams are fp32 (ViT [N*676,1152], LLM [S,4096]); GEMM operands and activations
+between kernels are the 16-bit compute type; weights are converted once at load (leopard_amd/weights.py).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import LeopardConfig
+from .ops import Ops
+from .weights import EngineWeights
+
+
+def llama3_inv_freq(head_dim: int, theta: float, scaling) -> torch.Tensor:
+    """Inverse RoPE frequencies with the llama3.1 wavelength-dependent scaling
+    (Megatron-LM-240603/megatron/core/models/common/embeddings/rotary_pos_embedding.py:48-83)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    if scaling is None:
+        return inv
+    lo_wl = scaling.original_max_position_embeddings / scaling.low_freq_factor
+    hi_wl = scaling.original_max_position_embeddings / scaling.high_freq_factor
+    wl = 2 * math.pi / inv
+    scaled = torch.where(wl > lo_wl, inv / scaling.factor, inv)
+    smooth = (scaling.original_max_position_embeddings / wl - scaling.low_freq_factor) / (
+        scaling.high_freq_factor - scaling.low_freq_factor)
+    mid = (1 - smooth) * scaled / scaling.factor + smooth * scaled
+    return torch.where(~(wl < hi_wl) & ~(wl > lo_wl), mid, scaled)
+
+
+def plan_merge(input_ids: np.ndarray, image_token_index: int, n_feature_rows: int, tokens_per_tile: int) -> np.ndarray:
+    """Index map of the merged sequence (transformers-4.38 ``_merge_input_ids_with_image_features`` semantics for
+    one unpadded sample, EVAL:284-287): ``src[s] >= 0`` -> text embedding of input position ``src[s]``;
+    ``src[s] < 0`` -> visual token row ``-src[s]-1``.  Raises ValueError on an image-token / feature count
+    mismatch, before any kernel is launched."""
+    ids = np.asarray(input_ids, dtype=np.int64).reshape(-1)
+    is_img = ids == image_token_index
+    n_img = int(is_img.sum())
+    if n_img * tokens_per_tile != n_feature_rows:
+        raise ValueError(
+            f"The input provided to the model are wrong. The number of image tokens is {n_img} while the number of "
+            f"image given to the model is {n_feature_rows // max(tokens_per_tile, 1)}. This prevents correct indexing "
+            "and breaks batch generation.")
+    width = np.where(is_img, tokens_per_tile, 1)
+    start = np.cumsum(width) - width
+    S = int(width.sum())
+    src = np.empty(S, dtype=np.int64)
+    text_pos = np.nonzero(~is_img)[0]
+    src[start[text_pos]] = text_pos
+    img_pos = np.nonzero(is_img)[0]
+    if n_img:
+        rows = (start[img_pos][:, None] + np.arange(tokens_per_tile)[None, :]).reshape(-1)
+        src[rows] = -(np.arange(n_img * tokens_per_tile) + 1)
+    return src
+
+
+@dataclass
+class PrefillResult:
+    logits_last: torch.Tensor                    # fp32 [vocab]
+    seq_len: int
+    n_tiles: int
+    logits_all: Optional[torch.Tensor] = None    # fp32 [S, vocab] when requested (what the reference computes)
+    parts: Optional[Dict[str, torch.Tensor]] = None
+
+
+class KVCache:
+    def __init__(self, cfg: LeopardConfig, capacity: int, dtype, device):
+        tc = cfg.text_config
+        w = tc.num_key_value_heads * tc.head_dim
+        self.k = [torch.zeros(capacity, w, dtype=dtype, device=device) for _ in range(tc.num_hidden_layers)]
+        self.v = [torch.zeros(capacity, w, dtype=dtype, device=device) for _ in range(tc.num_hidden_layers)]
+        self.capacity, self.length = capacity, 0
+
+
+class LeopardEngine:
+    def __init__(self, cfg: LeopardConfig, weights: EngineWeights, ops: Optional[Ops] = None, device=None,
+                 use_tr: bool = True):
+        self.cfg, self.W = cfg, weights
+        self.ops = ops if ops is not None else Ops()
+        self.dtype = weights.dtype
+        self.device = device if device is not None else weights.embed.device
+        self.use_tr = use_tr
+        tc = cfg.text_config
+        self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
+
+    # ------------------------------------------------------------------------------------------------
+    def _empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    def rope_tables(self, positions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """cos/sin [S, head_dim/2] fp32 on device (tiny; torch used as plumbing for a table build)."""
+        f = positions.to(device=self.device, dtype=torch.float32).reshape(-1, 1) * self._inv_freq.reshape(1, -1)
+        return f.cos().contiguous(), f.sin().contiguous()
+
+    # ------------------------------------------------------------------------------------------------
+    # a5 + a7: vision tower
+    # ------------------------------------------------------------------------------------------------
+    def vision_tower(self, tiles: torch.Tensor, shard: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """tiles: u8 [N,S,S,3] (HWC) or fp32 pixel_values [N,3,S,S].  Returns post-LN features T [N*T, D]."""
+        ops, W, vc = self.ops, self.W, self.cfg.vision_config
+        n = tiles.shape[0]
+        T, D, H, hd = vc.num_patches, vc.hidden_size, vc.num_attention_heads, vc.head_dim
+        M = n * T
+        patches = self._empty(M, W.patch_k)
+        ops.preprocess_tiles(tiles, patches, vc.image_size, vc.patch_size)
+        x = self._empty(M, D, dtype=torch.float32)
+        ops.gemm(patches, W.patch_w, x, bias=W.patch_b, addmat=W.pos_emb, epilogue=_lib.EPI_STORE_F32)
+        del patches
+        h = self._empty(M, D)
+        qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0]) if W.vit_layers else None
+        att = self._empty(M, D)
+        ff = self._empty(M, W.vit_ff)
+        cu = torch.arange(0, (n + 1) * T, T, dtype=torch.int32, device=self.device)
+        scale = hd ** -0.5
+        for L in W.vit_layers:
+            ops.layernorm(x, L.ln1_w, L.ln1_b, h, vc.layer_norm_eps)
+            ops.gemm(h, L.qkv_w, qkv, bias=L.qkv_b)
+            ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, cu, cu, T, H, H, hd, scale, False,
+                          self.use_tr)
+            ops.gemm(att, L.o_w, x, bias=L.o_b, epilogue=_lib.EPI_RESIDUAL)
+            ops.layernorm(x, L.ln2_w, L.ln2_b, h, vc.layer_norm_eps)
+            ops.gemm(h, L.fc1_w, ff, bias=L.fc1_b, act=_lib.ACT_GELU_TANH)
+            ops.gemm(ff, L.fc2_w, x, bias=L.fc2_b, epilogue=_lib.EPI_RESIDUAL)
+        ops.layernorm(x, W.post_ln_w, W.post_ln_b, h, vc.layer_norm_eps)
+        return h
+
+    # ------------------------------------------------------------------------------------------------
+    # a8 + a9: pixel shuffle + projector
+    # ------------------------------------------------------------------------------------------------
+    def project(self, vit_out: torch.Tensor, n_tiles: int) -> torch.Tensor:
+        """T [N*T, Dv] -> visual tokens fp32 [N*T/4, Dt] (pixel shuffle folded into linear_1's A gather)."""
+        ops, W, cfg = self.ops, self.W, self.cfg
+        rows = n_tiles * cfg.tokens_per_tile
+        Dt = cfg.text_config.hidden_size
+        h1 = self._empty(rows, Dt)
+        ops.gemm(vit_out, W.proj1_w, h1, bias=W.proj1_b, act=_lib.ACT_GELU_ERF, a_mode=_lib.A_PIXEL_SHUFFLE,
+                 ps_grid=cfg.vision_config.grid, M=rows)
+        vis = self._empty(rows, Dt, dtype=torch.float32)
+        ops.gemm(h1, W.proj2_w, vis, bias=W.proj2_b, epilogue=_lib.EPI_STORE_F32)
+        return vis
+
+    def encode_images(self, tiles: torch.Tensor) -> torch.Tensor:
+        return self.project(self.vision_tower(tiles), tiles.shape[0])
+
+    # ------------------------------------------------------------------------------------------------
+    # a10: embedding gather + merge
+    # ------------------------------------------------------------------------------------------------
+    def embed_merge(self, input_ids: torch.Tensor, visual_tokens: Optional[torch.Tensor]) -> torch.Tensor:
+        cfg = self.cfg
+        ids_host = input_ids.detach().reshape(-1).cpu().numpy()
+        n_rows = 0 if visual_tokens is None else visual_tokens.shape[0]
+        src = plan_merge(ids_host, cfg.image_token_index, n_rows, cfg.tokens_per_tile)
+        ids_dev = input_ids.reshape(-1).to(device=self.device, dtype=torch.int64).contiguous()
+        src_dev = torch.from_numpy(src).to(self.device)
+        x = self._empty(len(src), cfg.text_config.hidden_size, dtype=torch.float32)
+        self.ops.embed_merge(ids_dev, src_dev, self.W.embed, visual_tokens, x)
+        return x
+
+    # ------------------------------------------------------------------------------------------------
+    # a11: LLM prefill over one or several packed causal sequences
+    # ------------------------------------------------------------------------------------------------
+    def llm_prefill(self, x: torch.Tensor, seq_lens: Sequence[int], cache: Optional[KVCache] = None,
+                    all_logits: bool = False):
+        """x: fp32 [sum(seq_lens), D] residual stream (updated in place).  Returns (logits_last [n_seq, V],
+        logits_all or None).  ``cache`` (single sequence only) receives rotated K and V."""
+        ops, W, tc = self.ops, self.W, self.cfg.text_config
+        S, D = x.shape
+        H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        qw, kw = H * hd, KV * hd
+        cu_list = [0]
+        for l in seq_lens:
+            cu_list.append(cu_list[-1] + int(l))
+        assert cu_list[-1] == S
+        cu = torch.tensor(cu_list, dtype=torch.int32, device=self.device)
+        pos = torch.cat([torch.arange(int(l)) for l in seq_lens])
+        cos, sin = self.rope_tables(pos)
+        if cache is not None:
+            assert len(seq_lens) == 1 and cache.length == 0 and cache.capacity >= S
+        h = self._empty(S, D)
+        qkv = self._empty(S, qw + 2 * kw)
+        att = self._empty(S, qw)
+        gu = self._empty(S, W.llm_ff)
+        scale = hd ** -0.5
+        max_len = max(int(l) for l in seq_lens)
+        for i, L in enumerate(W.llm_layers):
+            ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
+            ops.gemm(h, L.qkv_w, qkv)
+            ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
+            ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
+                          True, self.use_tr)
+            ops.gemm(att, L.o_w, x, epilogue=_lib.EPI_RESIDUAL)
+            ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
+            ops.gemm(h, L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
+            ops.gemm(gu, L.down_w, x, epilogue=_lib.EPI_RESIDUAL)
+        if cache is not None:
+            cache.length = S
+        return self._lm_head(x, cu_list, all_logits)
+
+    def _lm_head(self, x, cu_list, all_logits):
+        ops, W, tc = self.ops, self.W, self.cfg.text_config
+        V = tc.vocab_size
+        last_rows = torch.tensor([c - 1 for c in cu_list[1:]], device=self.device)
+        xl = x.index_select(0, last_rows).contiguous()                   # [n_seq, D] fp32 (plumbing gather)
+        hl = self._empty(xl.shape[0], xl.shape[1])
+        ops.rmsnorm(xl, W.final_norm, hl, tc.rms_norm_eps)
+        logits_last = self._empty(xl.shape[0], W.lm_head.shape[0], dtype=torch.float32)
+        for r in range(xl.shape[0]):
+            ops.gemv(W.lm_head, hl[r], logits_last[r])
+        logits_all = None
+        if all_logits:
+            hall = self._empty(*x.shape)
+            ops.rmsnorm(x, W.final_norm, hall, tc.rms_norm_eps)
+            logits_all = self._empty(x.shape[0], W.lm_head.shape[0], dtype=torch.float32)
+            ops.gemm(hall, W.lm_head, logits_all, epilogue=_lib.EPI_STORE_F32)
+            logits_all = logits_all[:, :V]
+        return logits_last[:, :V], logits_all
+
+    # ------------------------------------------------------------------------------------------------
+    # the whole prefill for one sample (EVAL:261-333)
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def prefill(self, input_ids: torch.Tensor, tiles: Optional[torch.Tensor], cache: Optional[KVCache] = None,
+                all_logits: bool = False, keep_parts: bool = False, visual_tokens: Optional[torch.Tensor] = None
+                ) -> PrefillResult:
+        parts = {} if keep_parts else None
+        n_tiles = 0
+        if visual_tokens is None and tiles is not None and tiles.shape[0] > 0:
+            n_tiles = tiles.shape[0]
+            vit = self.vision_tower(tiles)
+            visual_tokens = self.project(vit, n_tiles)
+            if keep_parts:
+                parts["vit"] = vit
+        elif visual_tokens is not None:
+            n_tiles = visual_tokens.shape[0] // self.cfg.tokens_per_tile
+        if keep_parts and visual_tokens is not None:
+            parts["visual_tokens"] = visual_tokens
+        x = self.embed_merge(input_ids, visual_tokens)
+        if keep_parts:
+            parts["inputs_embeds"] = x.clone()
+        S = x.shape[0]
+        last, all_ = self.llm_prefill(x, [S], cache=cache, all_logits=all_logits)
+        return PrefillResult(logits_last=last[0], seq_len=S, n_tiles=n_tiles, logits_all=all_, parts=parts)
+
+    # ------------------------------------------------------------------------------------------------
+    # a12: one greedy decode step with the KV cache (EVAL:291-320 semantics: position = number of cached tokens)
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode_step(self, token_id: int, cache: KVCache) -> torch.Tensor:
+        ops, W, tc = self.ops, self.W, self.cfg.text_config
+        H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        qw, kw, D = H * hd, KV * hd, tc.hidden_size
+        pos = cache.length
+        if pos >= cache.capacity:
+            raise RuntimeError("KV cache is full")
+        ids = torch.tensor([token_id], dtype=torch.int64, device=self.device)
+        x = self._empty(1, D, dtype=torch.float32)
+        ops.embed_merge(ids, torch.zeros(1, dtype=torch.int64, device=self.device), W.embed, None, x)
+        cos, sin = self.rope_tables(torch.tensor([pos]))
+        h, qkv, att, gu = self._empty(1, D), self._empty(1, qw + 2 * kw), self._empty(1, qw), self._empty(1, W.llm_ff)
+        cu_q = torch.tensor([0, 1], dtype=torch.int32, device=self.device)
+        cu_k = torch.tensor([0, pos + 1], dtype=torch.int32, device=self.device)
+        scale = hd ** -0.5
+        for i, L in enumerate(W.llm_layers):
+            ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
+            ops.gemv(L.qkv_w, h[0], qkv[0], epilogue=1)
+            ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i], cache.v[i], pos)
+            ops.attention(qkv[:, :qw], cache.k[i], cache.v[i], att, cu_q, cu_k, 1, H, KV, hd, scale, True, self.use_tr)
+            ops.gemv(L.o_w, att[0], x[0], epilogue=2)
+            ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
+            ops.gemv(L.gu_w, h[0], gu[0], epilogue=3)
+            ops.gemv(L.down_w, gu[0], x[0], epilogue=2)
+        cache.length = pos + 1
+        ops.rmsnorm(x, W.final_norm, h, tc.rms_norm_eps)
+        logits = self._empty(W.lm_head.shape[0], dtype=torch.float32)
+        ops.gemv(W.lm_head, h[0], logits)
+        return logits[:tc.vocab_size]
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, tiles: Optional[torch.Tensor], max_new_tokens: int = 128,
+                 eos_token_id: Sequence[int] = (128001, 128009)) -> torch.Tensor:
+        """Greedy generation (EVAL:448-452): returns LongTensor [1, S_in + T] on the input device."""
+        ids = input_ids.reshape(1, -1)
+        n_img = int((ids == self.cfg.image_token_index).sum())
+        S = ids.shape[1] + n_img * (self.cfg.tokens_per_tile - 1)
+        cache = KVCache(self.cfg, S + max_new_tokens, self.dtype, self.device)
+        res = self.prefill(ids, tiles, cache=cache)
+        out = [int(t) for t in ids.reshape(-1).tolist()]
+        nxt = int(res.logits_last.argmax())
+        eos = set(int(e) for e in eos_token_id)
+        for step in range(max_new_tokens):
+            out.append(nxt)
+            if nxt in eos or step == max_new_tokens - 1:
+                break
+            nxt = int(self.decode_step(nxt, cache).argmax())
+        return torch.tensor([out], dtype=torch.long, device=input_ids.device)

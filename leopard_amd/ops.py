@@ -1,0 +1,110 @@
+"""Thin torch-tensor front end over the C ABI (raw pointers, explicit shapes, current HIP stream).
+
+PyTorch is used for device memory and streams only; every arithmetic step below is a call into
+libleopard_amd.so.  ``Ops(lib)`` takes the ctypes handle so that the CPU kernel-logic emulator build
+(tools/hipemu, tests only) can be driven through the very same wrappers with host tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (A_PIXEL_SHUFFLE, A_PLAIN, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, EPI_RESIDUAL, EPI_STORE,
+                   EPI_STORE_F32, EPI_SWIGLU, LMI_BF16, LMI_F16, LMI_F32)
+
+_DT = {torch.float16: LMI_F16, torch.bfloat16: LMI_BF16, torch.float32: LMI_F32}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class Ops:
+    def __init__(self, lib=None, emulated: bool = False):
+        self.lib = lib if lib is not None else _lib.load()
+        self.emulated = emulated
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self, ref: torch.Tensor):
+        if self.emulated:
+            return C.c_void_p(0)
+        if not ref.is_cuda:
+            raise RuntimeError("leopard_amd ops need device (HIP) tensors; there is no CPU path")
+        return C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(f"libleopard_amd error {rc}: {self.lib.lmi_last_error().decode()}")
+
+    # ------------------------------------------------------------------------------------------
+    def fill_synthetic(self, out: torch.Tensor, seed: int, kind: int):
+        assert out.is_contiguous()
+        self._check(self.lib.lmi_fill_synthetic(_ptr(out), out.numel(), seed & 0xFFFFFFFF, kind, _DT[out.dtype],
+                                                self._stream(out)))
+        return out
+
+    def preprocess_tiles(self, src: torch.Tensor, out: torch.Tensor, image_size: int, patch: int):
+        """src: u8 [N,S,S,3] or fp32 [N,3,S,S]; out: T [N*(S/P)^2, ldo]."""
+        from_u8 = src.dtype == torch.uint8
+        assert src.is_contiguous() and out.is_contiguous() and (from_u8 or src.dtype == torch.float32)
+        self._check(self.lib.lmi_preprocess_tiles(_ptr(src), int(from_u8), _ptr(out), src.shape[0], image_size, patch,
+                                                  out.shape[1], _DT[out.dtype], self._stream(out)))
+        return out
+
+    def layernorm(self, x, w, b, out, eps):
+        M, D = x.shape
+        self._check(self.lib.lmi_layernorm(_ptr(x), _ptr(w), _ptr(b), _ptr(out), M, D, x.stride(0), out.stride(0),
+                                           float(eps), _DT[out.dtype], self._stream(out)))
+        return out
+
+    def rmsnorm(self, x, w, out, eps):
+        M, D = x.shape
+        self._check(self.lib.lmi_rmsnorm(_ptr(x), _ptr(w), _ptr(out), M, D, x.stride(0), out.stride(0), float(eps),
+                                         _DT[out.dtype], self._stream(out)))
+        return out
+
+    def gemm(self, a, w, out, bias=None, addmat=None, row_map=None, epilogue=EPI_STORE, act=ACT_NONE,
+             a_mode=A_PLAIN, ps_grid=0, M=None):
+        """out = epilogue(a @ w.T).  a: T [M,K] (or the ViT output for pixel-shuffle mode), w: T [N,K]."""
+        N, K = w.shape
+        if M is None:
+            M = a.shape[0]
+        add_period = 0 if addmat is None else addmat.shape[0]
+        self._check(self.lib.lmi_gemm(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(addmat), _ptr(row_map), M, N, K,
+                                      a.stride(0), w.stride(0), out.stride(0), add_period, epilogue, act, a_mode,
+                                      ps_grid, _DT[w.dtype], self._stream(out)))
+        return out
+
+    def attention(self, q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, scale, causal,
+                  use_tr=True):
+        """q/k/v/out are 2-D row views [rows, >= heads*head_dim] (possibly column slices of a packed qkv buffer)."""
+        n_seq = cu_q.numel() - 1
+        self._check(self.lib.lmi_attn_varlen_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(cu_q), _ptr(cu_k), n_seq,
+                                                 int(max_seqlen_q), n_heads, n_kv_heads, head_dim, q.stride(0),
+                                                 k.stride(0), v.stride(0), out.stride(0), float(scale), int(causal),
+                                                 int(use_tr), _DT[q.dtype], self._stream(out)))
+        return out
+
+    def rope_qk(self, qkv, n_q_heads, n_kv_heads, head_dim, cos, sin, k_cache=None, v_cache=None, cache_pos0=0):
+        S = qkv.shape[0]
+        ldc = 0 if k_cache is None else k_cache.stride(0)
+        self._check(self.lib.lmi_rope_qk(_ptr(qkv), S, qkv.stride(0), n_q_heads, n_kv_heads, head_dim, _ptr(cos),
+                                         _ptr(sin), _ptr(k_cache), _ptr(v_cache), ldc, cache_pos0, _DT[qkv.dtype],
+                                         self._stream(qkv)))
+        return qkv
+
+    def embed_merge(self, ids, src, table, feats, out):
+        S, D = out.shape
+        ldf = 0 if feats is None else feats.stride(0)
+        self._check(self.lib.lmi_embed_merge(_ptr(ids), _ptr(src), _ptr(table), _ptr(feats), _ptr(out), S, D, ldf,
+                                             _DT[table.dtype], self._stream(out)))
+        return out
+
+    def gemv(self, w, x, out, bias=None, epilogue=0):
+        N, K = w.shape
+        self._check(self.lib.lmi_gemv(_ptr(w), _ptr(x), _ptr(bias), _ptr(out), N, K, w.stride(0), epilogue,
+                                      _DT[w.dtype], self._stream(out)))
+        return out

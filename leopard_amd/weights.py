@@ -1,0 +1,177 @@
+"""Parameter sources and the device-side weight layout of the engine.
+
+``SynthSource`` materialises the deterministic synthetic parameters of leopard_amd.synth directly on the GPU
+with ``lmi_fill_synthetic`` (bit-identical to the numpy generator the CPU oracle uses).  ``TensorSource`` wraps
+an in-memory state dict (tests, HF checkpoints loaded by leopard_amd.checkpoint).  Both speak the HF key layout
+written by the reference's converter (toolkits/model_checkpoints_convertor/llava/hf2megatron_llava.py:1050-1484).
+
+``EngineWeights`` holds what the kernels consume: 16-bit GEMM operands fused / padded / interleaved once at load
+time (q|k|v concatenated; gate/up interleaved in 32-row blocks for the SwiGLU epilogue; N padded to 128 and K
+to 64 with zeros), fp32 biases / norm gains / position embedding.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from .config import LeopardConfig
+from .synth import KIND_WEIGHT, name_seed, spec_table
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class SynthSource:
+    def __init__(self, cfg: LeopardConfig, ops, device, dtype):
+        self.cfg, self.ops, self.device, self.dtype = cfg, ops, device, dtype
+        self.specs = spec_table(cfg)
+
+    def get(self, name: str) -> torch.Tensor:
+        shape, kind = self.specs[name]
+        dt = self.dtype if kind == KIND_WEIGHT else torch.float32
+        out = torch.empty(shape, dtype=dt, device=self.device)
+        self.ops.fill_synthetic(out, name_seed(name), kind)
+        return out
+
+
+class TensorSource:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device, dtype):
+        self.sd, self.device, self.dtype = state_dict, device, dtype
+
+    def get(self, name: str) -> torch.Tensor:
+        t = self.sd[name]
+        if not torch.is_tensor(t):
+            t = torch.from_numpy(t)
+        is_matrix = t.dim() >= 2
+        return t.to(device=self.device, dtype=self.dtype if is_matrix else torch.float32)
+
+
+def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    if w.shape == (rows, cols):
+        return w.contiguous()
+    out = torch.zeros(rows, cols, dtype=w.dtype, device=w.device)
+    out[:w.shape[0], :w.shape[1]] = w
+    return out
+
+
+def _pad1(b: torch.Tensor, n: int) -> torch.Tensor:
+    b = b.to(torch.float32)
+    if b.numel() == n:
+        return b.contiguous()
+    out = torch.zeros(n, dtype=torch.float32, device=b.device)
+    out[:b.numel()] = b
+    return out
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[F,K],[F,K] -> [2F,K] with rows in blocks of 32: g[0:32] u[0:32] g[32:64] u[32:64] ... (F % 32 == 0)."""
+    F, K = gate.shape
+    return torch.stack([gate.view(F // 32, 32, K), up.view(F // 32, 32, K)], dim=1).reshape(2 * F, K).contiguous()
+
+
+@dataclass
+class VitLayerW:
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor
+    qkv_w: torch.Tensor; qkv_b: torch.Tensor
+    o_w: torch.Tensor; o_b: torch.Tensor
+    ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    fc1_w: torch.Tensor; fc1_b: torch.Tensor
+    fc2_w: torch.Tensor; fc2_b: torch.Tensor
+
+
+@dataclass
+class LlmLayerW:
+    in_norm: torch.Tensor
+    qkv_w: torch.Tensor
+    o_w: torch.Tensor
+    post_norm: torch.Tensor
+    gu_w: torch.Tensor
+    down_w: torch.Tensor
+
+
+@dataclass
+class EngineWeights:
+    cfg: LeopardConfig
+    dtype: torch.dtype
+    patch_w: torch.Tensor = None; patch_b: torch.Tensor = None; pos_emb: torch.Tensor = None
+    vit_layers: List[VitLayerW] = field(default_factory=list)
+    post_ln_w: torch.Tensor = None; post_ln_b: torch.Tensor = None
+    proj1_w: torch.Tensor = None; proj1_b: torch.Tensor = None
+    proj2_w: torch.Tensor = None; proj2_b: torch.Tensor = None
+    embed: torch.Tensor = None
+    llm_layers: List[LlmLayerW] = field(default_factory=list)
+    final_norm: torch.Tensor = None
+    lm_head: torch.Tensor = None
+    # padded geometry
+    patch_k: int = 0        # im2col K padded to 64
+    vit_ff: int = 0         # fc1 width padded to 128
+    llm_ff: int = 0
+
+    @classmethod
+    def build(cls, cfg: LeopardConfig, source, dtype) -> "EngineWeights":
+        vc, tc = cfg.vision_config, cfg.text_config
+        W = cls(cfg=cfg, dtype=dtype)
+        for dim, what in ((vc.hidden_size, "vision hidden"), (tc.hidden_size, "text hidden"),
+                          (tc.num_attention_heads * tc.head_dim, "q width"), (tc.num_key_value_heads * tc.head_dim, "kv width")):
+            if dim % 128:
+                raise ValueError(f"{what} size {dim} must be a multiple of 128 for the MFMA GEMM tiles")
+        if tc.intermediate_size % 64:
+            raise ValueError("LLM FFN width must be a multiple of 64")
+        g = source.get
+        v = "vision_tower.vision_model."
+        W.patch_k = _round_up(vc.patch_dim, 64)
+        W.vit_ff = _round_up(vc.intermediate_size, 128)
+        W.llm_ff = tc.intermediate_size
+        W.patch_w = _pad2(g(v + "embeddings.patch_embedding.weight").reshape(vc.hidden_size, -1), vc.hidden_size, W.patch_k)
+        W.patch_b = _pad1(g(v + "embeddings.patch_embedding.bias"), vc.hidden_size)
+        W.pos_emb = g(v + "embeddings.position_embedding.weight").to(torch.float32).contiguous()
+        for i in range(vc.num_hidden_layers):
+            p = f"{v}encoder.layers.{i}."
+            qkv_w = torch.cat([g(p + f"self_attn.{n}_proj.weight") for n in "qkv"], dim=0).contiguous()
+            qkv_b = torch.cat([g(p + f"self_attn.{n}_proj.bias").to(torch.float32) for n in "qkv"], dim=0).contiguous()
+            W.vit_layers.append(VitLayerW(
+                ln1_w=g(p + "layer_norm1.weight").float().contiguous(), ln1_b=g(p + "layer_norm1.bias").float().contiguous(),
+                qkv_w=_pad2(qkv_w, _round_up(qkv_w.shape[0], 128), vc.hidden_size), qkv_b=_pad1(qkv_b, _round_up(qkv_b.numel(), 128)),
+                o_w=g(p + "self_attn.out_proj.weight").contiguous(), o_b=_pad1(g(p + "self_attn.out_proj.bias"), vc.hidden_size),
+                ln2_w=g(p + "layer_norm2.weight").float().contiguous(), ln2_b=g(p + "layer_norm2.bias").float().contiguous(),
+                fc1_w=_pad2(g(p + "mlp.fc1.weight"), W.vit_ff, vc.hidden_size), fc1_b=_pad1(g(p + "mlp.fc1.bias"), W.vit_ff),
+                fc2_w=_pad2(g(p + "mlp.fc2.weight"), vc.hidden_size, W.vit_ff), fc2_b=_pad1(g(p + "mlp.fc2.bias"), vc.hidden_size)))
+        W.post_ln_w = g(v + "post_layernorm.weight").float().contiguous()
+        W.post_ln_b = g(v + "post_layernorm.bias").float().contiguous()
+        m = "multi_modal_projector."
+        W.proj1_w = g(m + "linear_1.weight").contiguous(); W.proj1_b = _pad1(g(m + "linear_1.bias"), tc.hidden_size)
+        W.proj2_w = g(m + "linear_2.weight").contiguous(); W.proj2_b = _pad1(g(m + "linear_2.bias"), tc.hidden_size)
+        l = "language_model.model."
+        W.embed = g(l + "embed_tokens.weight").contiguous()
+        for i in range(tc.num_hidden_layers):
+            p = f"{l}layers.{i}."
+            qkv_w = torch.cat([g(p + f"self_attn.{n}_proj.weight") for n in "qkv"], dim=0).contiguous()
+            W.llm_layers.append(LlmLayerW(
+                in_norm=g(p + "input_layernorm.weight").float().contiguous(),
+                qkv_w=qkv_w,
+                o_w=g(p + "self_attn.o_proj.weight").contiguous(),
+                post_norm=g(p + "post_attention_layernorm.weight").float().contiguous(),
+                gu_w=interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")),
+                down_w=g(p + "mlp.down_proj.weight").contiguous()))
+        W.final_norm = g(l + "norm.weight").float().contiguous()
+        head = g("language_model.lm_head.weight")
+        W.lm_head = _pad2(head, _round_up(head.shape[0], 128), tc.hidden_size)
+        return W
+
+    def nbytes(self) -> int:
+        n = 0
+        def add(t):
+            nonlocal n
+            if torch.is_tensor(t):
+                n += t.numel() * t.element_size()
+        for k, val in self.__dict__.items():
+            if isinstance(val, list):
+                for lay in val:
+                    for t in lay.__dict__.values():
+                        add(t)
+            else:
+                add(val)
+        return n

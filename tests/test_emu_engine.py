@@ -1,0 +1,87 @@
+"""End-to-end orchestration test on CPU: LeopardEngine driven over the emulated kernels (tools/hipemu) vs the
+CPU oracle, on a micro configuration that still satisfies the kernel shape rules (ViT width 1152 = 16 x 72,
+LLM head_dim 128).  Checks weight preparation (fusing / padding / gate-up interleave), the launch sequence,
+the merge plan, KV-cache decode and greedy generation."""
+import numpy as np
+import pytest
+import torch
+
+from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+from leopard_amd.engine import KVCache, LeopardEngine, plan_merge
+from leopard_amd.synth import synth_state_dict_numpy
+from leopard_amd.weights import EngineWeights, SynthSource, TensorSource
+from oracle import leopard_oracle as O
+from tests.emu_util import emu_ops
+
+
+def micro_config():
+    return LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16,
+                                   image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1,
+                               num_key_value_heads=1, vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    ops = emu_ops()
+    cfg = micro_config()
+    Wn = synth_state_dict_numpy(cfg)
+    return ops, cfg, Wn
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_engine_prefill_matches_oracle(setup, dtype, tol):
+    ops, cfg, Wn = setup
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", dtype), dtype)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    u8 = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (3, 28, 28, 3), dtype=np.uint8))
+    ids = torch.tensor([[5, 250, 9, 250, 250, 17, 33]])
+    res = eng.prefill(ids, u8, all_logits=True, keep_parts=True)
+    from leopard_amd.tiler import siglip_normalize
+    pix = torch.from_numpy(siglip_normalize(u8.numpy()))
+    Wt = O.weights_from_numpy(Wn)
+    logits, parts = O.prefill_logits(ids, pix, Wt, cfg, return_parts=True)
+    assert (res.parts["vit"].float().view(3, 4, -1) - parts["vit"]).abs().max() <= tol * 4
+    assert (res.parts["visual_tokens"].view(3, 1, -1) - parts["visual_tokens"]).abs().max() <= tol * 2
+    assert (res.parts["inputs_embeds"] - parts["inputs_embeds"][0]).abs().max() <= tol * 2
+    assert res.seq_len == logits.shape[1] == 7
+    assert (res.logits_all - logits[0]).abs().max() <= tol * 2
+    assert (res.logits_last - logits[0, -1]).abs().max() <= tol * 2
+
+
+def test_synth_source_equals_tensor_source(setup):
+    ops, cfg, Wn = setup
+    a = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    b = EngineWeights.build(cfg, TensorSource(Wn, "cpu", torch.float16), torch.float16)
+    assert torch.equal(a.vit_layers[0].qkv_w, b.vit_layers[0].qkv_w)
+    assert torch.equal(a.llm_layers[1].gu_w, b.llm_layers[1].gu_w)
+    assert torch.equal(a.patch_w, b.patch_w) and a.patch_w.shape[1] == 640
+    assert a.vit_ff == 128 and a.vit_layers[0].fc1_w.shape == (128, 1152)
+    assert torch.equal(a.lm_head, b.lm_head) and torch.equal(a.pos_emb, b.pos_emb)
+
+
+def test_generate_matches_oracle_greedy(setup):
+    ops, cfg, Wn = setup
+    dtype = torch.float16
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", dtype), dtype)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    u8 = torch.from_numpy(np.random.default_rng(4).integers(0, 256, (1, 28, 28, 3), dtype=np.uint8))
+    ids = torch.tensor([[7, 250, 11, 12]])
+    out = eng.generate(ids, u8, max_new_tokens=3, eos_token_id=())
+    from leopard_amd.tiler import siglip_normalize
+    ref = O.greedy_generate(ids, torch.from_numpy(siglip_normalize(u8.numpy())), O.weights_from_numpy(Wn), cfg, 3)
+    assert out.shape == (1, 7) and torch.equal(out, ref)
+
+
+def test_plan_merge_matches_oracle_and_raises():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        n = int(rng.integers(1, 40))
+        ids = rng.integers(0, 20, n)
+        tpt = int(rng.integers(1, 6))
+        k = int((ids == 7).sum())
+        assert np.array_equal(plan_merge(ids, 7, k * tpt, tpt), O.merge_plan(ids, 7, k * tpt, tpt))
+    with pytest.raises(ValueError, match="number of image tokens"):
+        plan_merge(np.array([1, 7, 2]), 7, 8, 4)

@@ -1,0 +1,286 @@
+"""Kernel LOGIC tests on CPU: the HIP kernel sources compiled against tools/hipemu (a lock-step fibre emulator
+of workgroups / wave64 collectives / MFMA fragment layouts) and driven through the same C ABI + Python
+wrappers as the GPU build.  These check tile indexing, LDS swizzles, masks, epilogues and the fragment
+bookkeeping of the attention kernel against plain PyTorch fp32 — not hardware semantics (those are pinned by
+the -m gpu tests on the real chip).  Shapes are small: the emulator runs ~1e5x slower than the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from leopard_amd import _lib
+from leopard_amd.synth import KIND_BIAS, KIND_NORM, KIND_WEIGHT, name_seed, synth_array
+from tests.emu_util import emu_ops
+
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return emu_ops()
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def tol(dtype):
+    return 2e-3 if dtype == torch.float16 else 1.6e-2
+
+
+def test_abi_exports_every_declared_symbol(ops):
+    for name in _lib.SIGNATURES:
+        assert hasattr(ops.lib, name)
+    assert ops.lib.lmi_abi_version() == 1
+
+
+def test_fill_synthetic_bit_exact(ops):
+    for kind in (KIND_WEIGHT, KIND_BIAS, KIND_NORM):
+        for dt in (torch.float32, torch.float16, torch.bfloat16):
+            out = torch.empty(5000, dtype=dt)
+            ops.fill_synthetic(out, name_seed("some.param"), kind)
+            ref = torch.from_numpy(synth_array("some.param", (5000,), kind))
+            assert torch.equal(out.float(), ref), (kind, dt)       # exactly representable in every dtype
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_store_bias_act_ragged_m(ops, dtype):
+    M, N, K = 200, 256, 192                                # 2 row tiles (second ragged), 2 col tiles, 3 k-tiles
+    a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, 0.1)
+    bias = rnd((N,), torch.float32, 3)
+    ref = a.float() @ w.float().T + bias
+    for act, f in ((_lib.ACT_NONE, lambda x: x), (_lib.ACT_GELU_TANH, lambda x: torch.nn.functional.gelu(x, approximate="tanh")),
+                   (_lib.ACT_GELU_ERF, torch.nn.functional.gelu)):
+        out = torch.full((M, N), float("nan"), dtype=dtype)
+        ops.gemm(a, w, out, bias=bias, act=act)
+        assert (out.float() - f(ref)).abs().max() <= tol(dtype) * max(1.0, f(ref).abs().max().item())
+
+
+def test_gemm_transpose_detecting(ops):
+    """A = one-hot rows, asymmetric W: catches swapped row/col in the accumulator write-out."""
+    M, N, K = 128, 128, 64
+    a = torch.zeros(M, K, dtype=torch.float16)
+    a[torch.arange(M), torch.arange(M) % K] = 1
+    w = (torch.arange(N * K).reshape(N, K) % 97).to(torch.float16) / 16
+    out = torch.empty(M, N, dtype=torch.float16)
+    ops.gemm(a, w, out)
+    assert torch.equal(out.float(), a.float() @ w.float().T)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_residual_f32_storef32_addmat_rowmap(ops, dtype):
+    M, N, K = 130, 128, 128
+    a, w = rnd((M, K), dtype, 4), rnd((N, K), dtype, 5, 0.1)
+    bias = rnd((N,), torch.float32, 6)
+    ref = a.float() @ w.float().T + bias
+    x = rnd((M, N), torch.float32, 7)
+    x0 = x.clone()
+    ops.gemm(a, w, x, bias=bias, epilogue=_lib.EPI_RESIDUAL)
+    assert (x - (x0 + ref)).abs().max() <= 1e-4
+    pos = rnd((13, N), torch.float32, 8)
+    out = torch.empty(M, N)
+    ops.gemm(a, w, out, bias=bias, addmat=pos, epilogue=_lib.EPI_STORE_F32)
+    assert (out - (ref + pos[torch.arange(M) % 13])).abs().max() <= 1e-4
+    perm = torch.randperm(M + 20, generator=torch.Generator().manual_seed(9))[:M].to(torch.int32)
+    big = torch.zeros(M + 20, N)
+    ops.gemm(a, w, big, bias=bias, row_map=perm, epilogue=_lib.EPI_STORE_F32)
+    assert (big[perm.long()] - ref).abs().max() <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_swiglu_interleaved(ops, dtype):
+    M, F, K = 70, 128, 64                                   # F gate rows + F up rows -> N = 256
+    a = rnd((M, K), dtype, 10)
+    gate, up = rnd((F, K), dtype, 11, 0.2), rnd((F, K), dtype, 12, 0.2)
+    w = torch.stack([gate.view(F // 32, 32, K), up.view(F // 32, 32, K)], dim=1).reshape(2 * F, K).contiguous()
+    out = torch.empty(M, F, dtype=dtype)
+    ops.gemm(a, w, out, epilogue=_lib.EPI_SWIGLU)
+    g, u = a.float() @ gate.float().T, a.float() @ up.float().T
+    ref = torch.nn.functional.silu(g) * u
+    assert (out.float() - ref).abs().max() <= tol(dtype) * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_pixel_shuffle_gather(ops, dtype):
+    """projector linear_1 with the 2x2 pixel shuffle folded into the A-row gather (EVAL:165-192)."""
+    from oracle.leopard_oracle import pixel_shuffle
+    tiles, G, Cc, N = 3, 4, 64, 128                          # 16 ViT tokens / tile -> 4 shuffled rows of 256
+    x = rnd((tiles * G * G, Cc), dtype, 13)
+    w = rnd((N, 4 * Cc), dtype, 14, 0.1)
+    bias = rnd((N,), torch.float32, 15)
+    out = torch.empty(tiles * 4, N, dtype=dtype)
+    ops.gemm(x, w, out, bias=bias, act=_lib.ACT_GELU_ERF, a_mode=_lib.A_PIXEL_SHUFFLE, ps_grid=G, M=tiles * 4)
+    shuf = pixel_shuffle(x.float().view(tiles, G * G, Cc)).reshape(tiles * 4, 4 * Cc)
+    ref = torch.nn.functional.gelu(shuf @ w.float().T + bias)
+    assert (out.float() - ref).abs().max() <= tol(dtype) * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    a, w, out = torch.zeros(8, 64, dtype=torch.float16), torch.zeros(100, 64, dtype=torch.float16), torch.zeros(8, 100, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="128"):
+        ops.gemm(a, w, out)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_norms(ops, dtype):
+    for D in (1152, 4096, 64):
+        M = 7
+        x = rnd((M, D), torch.float32, 20) * 3 + 0.5
+        w = torch.from_numpy(synth_array("w", (D,), KIND_NORM))
+        b = torch.from_numpy(synth_array("b", (D,), KIND_BIAS))
+        out = torch.empty(M, D, dtype=dtype)
+        ops.layernorm(x, w, b, out, 1e-6)
+        ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-6)
+        assert (out.float() - ref).abs().max() <= tol(dtype) * 4
+        ops.rmsnorm(x, w, out, 1e-5)
+        ref = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5))
+        assert (out.float() - ref).abs().max() <= tol(dtype) * 4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rope_and_kv_cache(ops, dtype):
+    from oracle.leopard_oracle import rope_tables, rotate_half
+    from leopard_amd.config import RopeScaling
+    S, nq, nkv, D = 9, 4, 2, 128
+    qkv = rnd((S, (nq + 2 * nkv) * D), dtype, 30)
+    orig = qkv.clone()
+    pos = torch.arange(100, 100 + S)
+    cos, sin = rope_tables(pos, D, 5e5, RopeScaling())
+    kc, vc = torch.zeros(20, nkv * D, dtype=dtype), torch.zeros(20, nkv * D, dtype=dtype)
+    ops.rope_qk(qkv, nq, nkv, D, cos[:, :D // 2].contiguous(), sin[:, :D // 2].contiguous(), kc, vc, cache_pos0=5)
+    x = orig.float().view(S, nq + 2 * nkv, D)
+    rot = x[:, :nq + nkv] * cos[:, None, :] + rotate_half(x[:, :nq + nkv]) * sin[:, None, :]
+    got = qkv.float().view(S, nq + 2 * nkv, D)
+    assert (got[:, :nq + nkv] - rot).abs().max() <= tol(dtype) * 4
+    assert torch.equal(got[:, nq + nkv:], x[:, nq + nkv:])
+    assert torch.equal(kc[5:5 + S].view(S, nkv, D), qkv.view(S, -1, D)[:, nq:nq + nkv])
+    assert torch.equal(vc[5:5 + S].view(S, nkv, D), orig.view(S, -1, D)[:, nq + nkv:])
+    assert kc[:5].abs().max() == 0 and kc[5 + S:].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_merge(ops, dtype):
+    from oracle.leopard_oracle import merge_plan
+    D, V, tpt = 64, 50, 4
+    table = rnd((V, D), dtype, 40)
+    ids = torch.tensor([3, 49, 7, 49, 49, 1])
+    feats = rnd((3 * tpt, D), torch.float32, 41)
+    src = torch.from_numpy(merge_plan(ids.numpy(), 49, 3 * tpt, tpt))
+    out = torch.empty(src.numel(), D)
+    ops.embed_merge(ids, src, table, feats, out)
+    ref = torch.stack([table[ids[s]].float() if s >= 0 else feats[-s - 1] for s in src.tolist()])
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_preprocess_tiles(ops, dtype):
+    from leopard_amd.tiler import siglip_normalize
+    n, S, P, ldo = 2, 28, 14, 640
+    u8 = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (n, S, S, 3), dtype=np.uint8))
+    out = torch.full((n * 4, ldo), 7.0, dtype=dtype)
+    ops.preprocess_tiles(u8, out, S, P)
+    pix = torch.from_numpy(siglip_normalize(u8.numpy()))                        # [n,3,S,S]
+    ref = torch.nn.functional.unfold(pix, kernel_size=P, stride=P).transpose(1, 2).reshape(n * 4, 3 * P * P)
+    assert torch.equal(out[:, :588].float(), ref.to(dtype).float())
+    assert out[:, 588:].abs().max() == 0
+    out2 = torch.empty_like(out)
+    ops.preprocess_tiles(pix.contiguous(), out2, S, P)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemv(ops, dtype):
+    N, K = 192, 1152
+    w, x = rnd((N, K), dtype, 50, 0.1), rnd((K,), dtype, 51)
+    ref = w.float() @ x.float()
+    out = torch.empty(N)
+    ops.gemv(w, x, out)
+    assert (out - ref).abs().max() <= 1e-3
+    o16 = torch.empty(N, dtype=dtype)
+    ops.gemv(w, x, o16, epilogue=1)
+    assert (o16.float() - ref).abs().max() <= tol(dtype) * 4
+    acc = torch.ones(N)
+    ops.gemv(w, x, acc, epilogue=2)
+    assert (acc - 1 - ref).abs().max() <= 1e-3
+    wi = torch.stack([w[:96].view(3, 32, K), w[96:].view(3, 32, K)], dim=1).reshape(N, K).contiguous()
+    sw = torch.empty(96, dtype=dtype)
+    ops.gemv(wi, x, sw, epilogue=3)
+    r = torch.nn.functional.silu(ref[:96]) * ref[96:]
+    assert ((sw.float() - r).abs() / (1 + r.abs())).max() <= tol(dtype)
+
+
+def attn_ref(q, k, v, cu_q, cu_k, H, KV, D, scale, causal):
+    out = torch.zeros(q.shape[0], H * D)
+    for s in range(len(cu_q) - 1):
+        qs = q[cu_q[s]:cu_q[s + 1]].float().view(-1, H, D).transpose(0, 1)
+        ks = k[cu_k[s]:cu_k[s + 1]].float().view(-1, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+        vs = v[cu_k[s]:cu_k[s + 1]].float().view(-1, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+        sc = qs @ ks.transpose(-1, -2) * scale
+        if causal:
+            lq, lk = qs.shape[1], ks.shape[1]
+            m = torch.arange(lk)[None, :] <= torch.arange(lq)[:, None] + (lk - lq)
+            sc = sc.masked_fill(~m, float("-inf"))
+        o = torch.softmax(sc, -1) @ vs
+        out[cu_q[s]:cu_q[s + 1]] = o.transpose(0, 1).reshape(-1, H * D)
+    return out
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_tr", [True, False])
+def test_attention_llama_causal_gqa(ops, dtype, use_tr):
+    H, KV, D = 2, 1, 128
+    lens = [150, 40]                                          # 2 q-blocks (ragged) + a short sequence
+    cu = [0, 150, 190]
+    T = cu[-1]
+    qkv = rnd((T, (H + 2 * KV) * D), dtype, 60)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    out = torch.full((T, H * D), float("nan"), dtype=dtype)
+    cu_t = torch.tensor(cu, dtype=torch.int32)
+    ops.attention(q, k, v, out, cu_t, cu_t, max(lens), H, KV, D, D ** -0.5, True, use_tr)
+    ref = attn_ref(q, k, v, cu, cu, H, KV, D, D ** -0.5, True)
+    assert (out.float() - ref).abs().max() <= tol(dtype) * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_siglip_noncausal_d72(ops, dtype):
+    H, D = 2, 72
+    cu = [0, 100, 170]                                        # two "tiles" with ragged key tails
+    T = cu[-1]
+    qkv = rnd((T, 3 * H * D), dtype, 61)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    out = torch.full((T, H * D), float("nan"), dtype=dtype)
+    cu_t = torch.tensor(cu, dtype=torch.int32)
+    ops.attention(q, k, v, out, cu_t, cu_t, 100, H, H, D, D ** -0.5, False, True)
+    ref = attn_ref(q, k, v, cu, cu, H, H, D, D ** -0.5, False)
+    assert (out.float() - ref).abs().max() <= tol(dtype) * 2
+
+
+def test_attention_decode_shape_bottom_right_causal(ops):
+    """len_q = 1 against a longer key cache (the decode step) and a chunked-prefill shape (len_q < len_k)."""
+    H, KV, D = 2, 2, 128
+    dtype = torch.float16
+    k, v = rnd((70, KV * D), dtype, 62), rnd((70, KV * D), dtype, 63)
+    for lq in (1, 33):
+        q = rnd((lq, H * D), dtype, 64)
+        out = torch.empty(lq, H * D, dtype=dtype)
+        ops.attention(q, k, v, out, torch.tensor([0, lq], dtype=torch.int32), torch.tensor([0, 70], dtype=torch.int32),
+                      lq, H, KV, D, D ** -0.5, True, True)
+        ref = attn_ref(q, k, v, [0, lq], [0, 70], H, KV, D, D ** -0.5, True)
+        assert (out.float() - ref).abs().max() <= 4e-3
+
+
+def test_gemm_lds_swizzle_is_conflict_free():
+    """The ds_read_b128 lane groups of gfx950 (MI355X_MICROARCH LDS table) must hit 16 distinct 16-byte slots of
+    the 256-byte bank row for the fragment reads of gemm.h (rows fr, chunk 2ks+fh, swizzle c ^ ((r>>1)&7))."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for ks in range(4):
+        for base in (0, 32, 64, 96):
+            for g in groups:
+                slots = set()
+                for lane in g:
+                    r, lc = base + (lane & 31), 2 * ks + (lane >> 5)
+                    off = r * 128 + ((lc ^ ((r >> 1) & 7)) << 4)
+                    slots.add((off % 256) // 16)
+                assert len(slots) == 16

@@ -1,0 +1,131 @@
+#include "hipemu.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <ucontext.h>
+#include <vector>
+
+dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace hipemu {
+namespace {
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+    bool waiting = false;
+    dim3 tid;
+};
+constexpr size_t kStack = 256 * 1024;
+std::vector<Fiber> fibers;
+ucontext_t main_ctx;
+int cur = -1;
+const std::function<void()>* body_fn = nullptr;
+int bar_count = 0;
+unsigned bar_gen = 0;
+std::vector<int> wave_count;
+std::vector<unsigned> wave_gen;
+std::vector<char> wave_scratch;
+std::vector<char> smem;
+int n_threads = 0;
+unsigned long ticks = 0;     // bumped on every barrier arrival / thread exit: the scheduler's progress signal
+
+void yield() {
+    Fiber& f = fibers[cur];
+    swapcontext(&f.ctx, &main_ctx);
+}
+void trampoline() {
+    (*body_fn)();
+    fibers[cur].done = true;
+    swapcontext(&fibers[cur].ctx, &main_ctx);
+}
+}  // namespace
+
+char* dyn_smem() { return smem.data(); }
+void* wave_buf() { return wave_scratch.data() + (size_t)(cur / 64) * 64 * 256; }
+
+void wave_sync() {
+    const int w = cur / 64;
+    const int lanes = std::min(64, n_threads - w * 64);
+    const unsigned gen = wave_gen[w];
+    ++ticks;
+    if (++wave_count[w] == lanes) {
+        wave_count[w] = 0;
+        wave_gen[w]++;
+    } else {
+        fibers[cur].waiting = true;
+        while (wave_gen[w] == gen) yield();
+        fibers[cur].waiting = false;
+    }
+}
+
+void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<void()>& body) {
+    n_threads = (int)(block.x * block.y * block.z);
+    gridDim = grid;
+    blockDim = block;
+    body_fn = &body;
+    smem.assign(dyn_smem_bytes + 64, 0);
+    wave_count.assign((n_threads + 63) / 64, 0);
+    wave_gen.assign((n_threads + 63) / 64, 0);
+    wave_scratch.assign((size_t)((n_threads + 63) / 64) * 64 * 256, 0);
+    if ((int)fibers.size() < n_threads) {
+        size_t old = fibers.size();
+        fibers.resize(n_threads);
+        for (size_t i = old; i < fibers.size(); ++i) fibers[i].stack = (char*)malloc(kStack);
+    }
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx = dim3(bx, by, bz);
+                bar_count = 0;
+                for (auto& c : wave_count) c = 0;
+                for (int t = 0; t < n_threads; ++t) {
+                    Fiber& f = fibers[t];
+                    f.done = false;
+                    f.waiting = false;
+                    f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = &main_ctx;
+                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                }
+                int alive = n_threads;
+                long spins = 0;
+                while (alive > 0) {
+                    const unsigned long before = ticks;
+                    for (int t = 0; t < n_threads; ++t) {
+                        Fiber& f = fibers[t];
+                        if (f.done) continue;
+                        cur = t;
+                        threadIdx = f.tid;
+                        swapcontext(&main_ctx, &f.ctx);
+                        if (f.done) { --alive; ++ticks; }
+                    }
+                    if (ticks == before) {
+                        if (++spins > 2) {
+                            fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): %d threads stuck at a barrier\n", bx, by, bz, alive);
+                            abort();
+                        }
+                    } else {
+                        spins = 0;
+                    }
+                }
+            }
+    cur = -1;
+}
+}  // namespace hipemu
+
+void __syncthreads() {
+    using namespace hipemu;
+    const unsigned gen = bar_gen;
+    ++ticks;
+    if (++bar_count == n_threads) {
+        bar_count = 0;
+        bar_gen++;
+    } else {
+        fibers[cur].waiting = true;
+        while (bar_gen == gen) yield();
+        fibers[cur].waiting = false;
+    }
+}
