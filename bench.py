@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py — Leopard-LLaVA multi-image prefill throughput on MI355X (the BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
+
+A "step" is one pass of the hot path over one synthetic sample of BASELINE config C3 — 6 images of 1344x896 ->
+adaptive tiler -> 42 ViT inputs (364x364) -> SigLIP-SO400M (27 layers) -> pixel-shuffle + projector -> 7098
+visual tokens merged into a 7187-token sequence -> Llama-3.1-8B prefill (32 layers, KV cache written) ->
+last-position logits.  Inputs (u8 tiles, token ids) are resident in HBM when the timed region starts; weights are
+seeded synthetic values of the real architecture (no checkpoints exist offline).
+
+Multi-GPU: the path shards by SAMPLE exactly as the reference does (run_eval_llava_siglip_multiimg.sh:9-11, one
+process per GPU over dataset shards, no collective on the data path): every rank prefills its own sample, so
+per-GPU work is fixed ("weak" scaling) and the job value is ranks x images / max-over-ranks time.
+
+One JSON line on rank 0:  metric/value/unit + roofline (dominant kernel = the MFMA GEMM family, HIP-event timed on
+the launch stream) + cpu_baseline (the CPU oracle timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from leopard_amd.config import full_config  # noqa: E402
+from leopard_amd.synth import synth_image_u8, synth_prompt_ids  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops(cfg, n_tiles: int, S: int) -> dict:
+    """SURVEY.md 8(d) per-unit figures (2*MAC): ViT tile, projector tile, LLM prefill of S tokens, last-token head."""
+    v, t = cfg.vision_config, cfg.text_config
+    T, d, ff = v.num_patches, v.hidden_size, v.intermediate_size
+    vit_tile = 2 * T * v.patch_dim * d + v.num_hidden_layers * (2 * T * (4 * d * d + 2 * d * ff) + 4 * T * T * d)
+    proj_tile = 2 * cfg.tokens_per_tile * (cfg.projector_in * t.hidden_size + t.hidden_size ** 2)
+    qkv = t.hidden_size * (t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim
+    lin = t.num_hidden_layers * 2 * S * (qkv + t.num_attention_heads * t.head_dim * t.hidden_size + 3 * t.hidden_size * t.intermediate_size)
+    attn = t.num_hidden_layers * 2 * t.num_attention_heads * t.head_dim * S * (S + 1)
+    head = 2 * t.hidden_size * t.vocab_size
+    return {"vit": n_tiles * vit_tile, "projector": n_tiles * proj_tile, "llm_linear": lin, "llm_attention": attn,
+            "lm_head_last": head, "total": n_tiles * (vit_tile + proj_tile) + lin + attn + head}
+
+
+def make_sample(cfg, n_images: int, width: int, height: int, seed: int):
+    """Host side of the path (EVAL:384-446): synthetic u8 images -> tiler (PIL) -> u8 ViT inputs + prompt ids."""
+    from PIL import Image
+    from leopard_amd.tiler import tile_sample, to_u8_tiles
+    imgs = [Image.fromarray(synth_image_u8(seed * 100 + i, width, height)) for i in range(n_images)]
+    t0 = time.perf_counter()
+    vit_inputs, plan = tile_sample(imgs)
+    u8 = to_u8_tiles(vit_inputs)
+    host_s = time.perf_counter() - t0
+    ids = synth_prompt_ids(plan.vit_inputs_per_image, cfg, seed=seed)
+    return u8, ids, plan, host_s
+
+
+class GemmTimer:
+    """HIP-event pairs around every lmi_gemm launch, recorded on the launch stream."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, ops):
+        inner = ops.gemm
+        timer = self
+
+        def gemm(a, w, out, *args, **kw):
+            M = kw.get("M", None)
+            if M is None:
+                M = a.shape[0]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            r = inner(a, w, out, *args, **kw)
+            e1.record(torch.cuda.current_stream())
+            timer.records.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1))
+            return r
+        ops.gemm = gemm
+        return inner
+
+    def summary(self):
+        torch.cuda.synchronize()
+        flops = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        return flops, ms, len(self.records)
+
+
+def cpu_baseline(cfg):
+    """The CPU oracle (fp32 PyTorch restatement of the reference path) timed on the host cores on a bounded sample
+    of the same workload: 2 SigLIP layers on 2 tiles + 1 Llama layer at S=1024, converted to images/s of the C3
+    workload through the algorithmic FLOP count."""
+    from leopard_amd.synth import param_specs, synth_array
+    from oracle import leopard_oracle as O
+    specs = {n: (s, k) for n, s, k in param_specs(cfg)}
+    want = [n for n in specs if n.startswith("vision_tower.vision_model.encoder.layers.0.")
+            or n.startswith("vision_tower.vision_model.encoder.layers.1.") or n.startswith("language_model.model.layers.0.")]
+    W = O.weights_from_numpy({n: synth_array(n, *specs[n]) for n in want})
+    g = torch.Generator().manual_seed(0)
+    xv = torch.randn(2, cfg.vision_config.num_patches, cfg.vision_config.hidden_size, generator=g)
+    S = 1024
+    xl = torch.randn(1, S, cfg.text_config.hidden_size, generator=g)
+    tc = cfg.text_config
+    cos, sin = O.rope_tables(torch.arange(S), tc.head_dim, tc.rope_theta, tc.rope_scaling)
+    v = cfg.vision_config
+    T, d, ff = v.num_patches, v.hidden_size, v.intermediate_size
+    fl_v = 2 * 2 * (2 * T * (4 * d * d + 2 * d * ff) + 4 * T * T * d)
+    qkv = tc.hidden_size * (tc.num_attention_heads + 2 * tc.num_key_value_heads) * tc.head_dim
+    fl_l = 2 * S * (qkv + tc.hidden_size ** 2 + 3 * tc.hidden_size * tc.intermediate_size) + 2 * tc.num_attention_heads * tc.head_dim * S * (S + 1)
+
+    def run():
+        with torch.no_grad():
+            y = O.siglip_layer(O.siglip_layer(xv, W, 0, cfg), W, 1, cfg)
+            z = O.llama_layer(xl, W, 0, cfg, cos, sin)
+        return y, z
+    run()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[1]
+    tflops = (fl_v + fl_l) / t / 1e12
+    return tflops, t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--images", type=int, default=6)
+    ap.add_argument("--width", type=int, default=1344)
+    ap.add_argument("--height", type=int, default=896)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from leopard_amd.engine import KVCache, LeopardEngine
+    from leopard_amd.ops import Ops
+    from leopard_amd.weights import EngineWeights, SynthSource
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    cfg = full_config()
+    ops = Ops()
+    t0 = time.perf_counter()
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
+    torch.cuda.synchronize()
+    eng = LeopardEngine(cfg, W, ops=ops, device=dev)
+    load_s = time.perf_counter() - t0
+
+    u8, ids_np, plan, host_tiler_s = make_sample(cfg, args.images, args.width, args.height, seed=rank)
+    tiles = torch.from_numpy(u8).to(dev)                       # resident before the timed region
+    ids = torch.from_numpy(ids_np).reshape(1, -1)
+    ids_dev = ids.to(dev)
+    n_tiles = u8.shape[0]
+    S = ids.shape[1] + n_tiles * (cfg.tokens_per_tile - 1)
+    cache = KVCache(cfg, S, dtype, dev)
+
+    def step():
+        cache.length = 0
+        return eng.prefill(ids_dev, tiles, cache=cache)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert res.seq_len == S and torch.isfinite(res.logits_last).all()
+    ms_per_step = elapsed / args.steps * 1e3
+    images_per_s = world * args.images * args.steps / elapsed
+    fl = algorithmic_flops(cfg, n_tiles, S)
+
+    out = {
+        "metric": "multi-image prefill images/sec (Leopard-LLaVA, 6x1344x896 per sample)",
+        "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"C3: {args.images}x({args.width}x{args.height}) images -> {n_tiles} ViT inputs (364x364), "
+                               f"{n_tiles * cfg.tokens_per_tile} visual tokens, S={S}; SigLIP-SO400M/14 (27L) + Llama-3.1-8B (32L) "
+                               "prefill to last-token logits, KV cache written; synthetic seeded weights",
+                   "samples_per_rank_per_step": 1, "parallelism": f"sample-sharded x{world} (no data-path collective)"},
+        "visual_tokens_per_s": round(world * n_tiles * cfg.tokens_per_tile * args.steps / elapsed, 1),
+        "algorithmic_tflop_per_step": round(fl["total"] / 1e12, 2),
+        "prefill_mfma_frac": round(world * fl["total"] / 1e12 / (elapsed / args.steps) / (MFMA_PEAK_TFLOPS * world), 4),
+        "host_tiler_ms_per_sample": round(host_tiler_s * 1e3, 1), "weight_load_s": round(load_s, 1),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        timer = GemmTimer()
+        inner = timer.wrap(ops)
+        for _ in range(min(args.steps, 2)):
+            step()
+        gflops, gms, n = timer.summary()
+        ops.gemm = inner
+        per_launch_flops = gflops / n
+        avg_ms = gms / n
+        achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "lmi::gemm_kernel (all epilogues)", "achieved": round(achieved, 1),
+                           "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                           "traffic": None, "launches_per_step": n // min(args.steps, 2),
+                           "avg_launch_ms": round(avg_ms, 4), "gemm_ms_per_step": round(gms / min(args.steps, 2), 2)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        tflops, t = cpu_baseline(cfg)
+        out["cpu_baseline"] = {"value": round(args.images / (fl["total"] / 1e12 / tflops), 5), "unit": "images/s",
+                               "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"CPU oracle (fp32 PyTorch): 2 SigLIP layers x 2 tiles + 1 Llama layer at S=1024 "
+                                         f"({t:.2f} s, {tflops:.3f} TFLOP/s), scaled to the C3 sample by algorithmic FLOPs"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,310 @@
+"""-m gpu: every kernel of libleopard_amd.so on a real MI355X, through the C ABI, at production shapes, against
+plain PyTorch fp32 of the same op (computed on the device in fp32 as the checker) — plus bit-exact checks for
+the integer / byte work (synthetic fill, im2col gather, merge gather, KV-cache copy)."""
+import numpy as np
+import pytest
+import torch
+
+from leopard_amd import _lib
+from leopard_amd.synth import KIND_BIAS, KIND_NORM, KIND_WEIGHT, name_seed, synth_array
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from leopard_amd.ops import Ops
+    assert torch.cuda.is_available()
+    return Ops()
+
+
+DEV = "cuda:0"
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def eps(dtype):
+    return 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7          # one rounding of the 16-bit type
+
+
+def check(out, ref, dtype, k=4.0, what=""):
+    out, ref = out.float(), ref.float()
+    err = ((out - ref).abs() / (1.0 + ref.abs())).max().item()
+    assert err <= k * eps(dtype), f"{what}: rel err {err:.3e} > {k * eps(dtype):.3e}"
+
+
+def test_native_library_loaded(ops):
+    import os
+    assert os.path.exists(_lib.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "libleopard_amd.so" in maps
+
+
+def test_fill_synthetic_bit_exact(ops):
+    for kind in (KIND_WEIGHT, KIND_BIAS, KIND_NORM):
+        for dt in (torch.float32, torch.float16, torch.bfloat16):
+            out = torch.empty(100003, dtype=dt, device=DEV)
+            ops.fill_synthetic(out, name_seed("language_model.lm_head.weight"), kind)
+            ref = torch.from_numpy(synth_array("language_model.lm_head.weight", (100003,), kind))
+            assert torch.equal(out.float().cpu(), ref)
+    big = torch.empty((1 << 32) + 4096, dtype=torch.float16, device=DEV)      # exercises the 64-bit index path
+    ops.fill_synthetic(big, 123, KIND_WEIGHT)
+    from leopard_amd.synth import hash_bytes, values_from_bytes
+    tail = values_from_bytes(hash_bytes(123, (1 << 32), 4096), KIND_WEIGHT)
+    assert torch.equal(big[-4096:].float().cpu(), torch.from_numpy(tail))
+    del big
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(1000, 1152, 1152), (676 * 3, 3456, 1152), (333, 4352, 1152), (700, 1152, 4352),
+                                   (257, 4096, 4096), (128, 128, 64), (1, 256, 128)])
+def test_gemm_store_bias(ops, dtype, shape):
+    M, N, K = shape
+    a, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, 0.05)
+    bias = rnd((N,), torch.float32, 3)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a, w, out, bias=bias)
+    check(out, a.float() @ w.float().T + bias, dtype, what=f"gemm {shape}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_activations(ops, dtype):
+    M, N, K = 500, 4352, 1152
+    a, w = rnd((M, K), dtype, 4), rnd((N, K), dtype, 5, 0.05)
+    bias = rnd((N,), torch.float32, 6)
+    ref = a.float() @ w.float().T + bias
+    out = torch.empty(M, N, dtype=dtype, device=DEV)
+    ops.gemm(a, w, out, bias=bias, act=_lib.ACT_GELU_TANH)
+    check(out, torch.nn.functional.gelu(ref, approximate="tanh"), dtype, what="gelu_tanh")
+    ops.gemm(a, w, out, bias=bias, act=_lib.ACT_GELU_ERF)
+    check(out, torch.nn.functional.gelu(ref), dtype, what="gelu_erf")
+
+
+def test_gemm_transpose_detecting(ops):
+    M, N, K = 256, 256, 128
+    a = torch.zeros(M, K, dtype=torch.float16, device=DEV)
+    a[torch.arange(M), torch.arange(M) % K] = 1
+    w = ((torch.arange(N * K).reshape(N, K) % 97).to(torch.float16) / 16).to(DEV)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a, w, out)
+    assert torch.equal(out.float(), a.float() @ w.float().T)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_residual_storef32_addmat_rowmap(ops, dtype):
+    M, N, K = 1400, 1152, 640
+    a, w = rnd((M, K), dtype, 7), rnd((N, K), dtype, 8, 0.05)
+    bias = rnd((N,), torch.float32, 9)
+    ref = a.float() @ w.float().T + bias
+    x = rnd((M, N), torch.float32, 10)
+    x0 = x.clone()
+    ops.gemm(a, w, x, bias=bias, epilogue=_lib.EPI_RESIDUAL)
+    assert (x - (x0 + ref)).abs().max() <= 2e-4
+    pos = rnd((676, N), torch.float32, 11)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(a, w, out, bias=bias, addmat=pos, epilogue=_lib.EPI_STORE_F32)
+    assert (out - (ref + pos[torch.arange(M, device=DEV) % 676])).abs().max() <= 2e-4
+    perm = torch.randperm(M + 50, generator=torch.Generator().manual_seed(12))[:M].to(torch.int32).to(DEV)
+    big = torch.zeros(M + 50, N, device=DEV)
+    ops.gemm(a, w, big, bias=bias, row_map=perm, epilogue=_lib.EPI_STORE_F32)
+    assert (big[perm.long()] - ref).abs().max() <= 2e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_swiglu_llama_shape(ops, dtype):
+    from leopard_amd.weights import interleave_gate_up
+    M, F, K = 300, 14336, 4096
+    a = rnd((M, K), dtype, 13)
+    gate, up = rnd((F, K), dtype, 14, 0.02), rnd((F, K), dtype, 15, 0.02)
+    out = torch.empty(M, F, dtype=dtype, device=DEV)
+    ops.gemm(a, interleave_gate_up(gate, up), out, epilogue=_lib.EPI_SWIGLU)
+    ref = torch.nn.functional.silu(a.float() @ gate.float().T) * (a.float() @ up.float().T)
+    check(out, ref, dtype, what="swiglu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_pixel_shuffle_projector_shape(ops, dtype):
+    from oracle.leopard_oracle import pixel_shuffle
+    tiles, G, C, N = 3, 26, 1152, 4096
+    x = rnd((tiles * G * G, C), dtype, 16)
+    w = rnd((N, 4 * C), dtype, 17, 0.02)
+    bias = rnd((N,), torch.float32, 18)
+    out = torch.empty(tiles * 169, N, dtype=dtype, device=DEV)
+    ops.gemm(x, w, out, bias=bias, act=_lib.ACT_GELU_ERF, a_mode=_lib.A_PIXEL_SHUFFLE, ps_grid=G, M=tiles * 169)
+    shuf = pixel_shuffle(x.float().cpu().view(tiles, G * G, C)).reshape(tiles * 169, 4 * C).to(DEV)
+    check(out, torch.nn.functional.gelu(shuf @ w.float().T + bias), dtype, what="pixel-shuffle gemm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_norms(ops, dtype):
+    for D in (1152, 4096):
+        M = 3001
+        x = rnd((M, D), torch.float32, 20) * 3 + 0.5
+        w = torch.from_numpy(synth_array("w", (D,), KIND_NORM)).to(DEV)
+        b = torch.from_numpy(synth_array("b", (D,), KIND_BIAS)).to(DEV)
+        out = torch.empty(M, D, dtype=dtype, device=DEV)
+        ops.layernorm(x, w, b, out, 1e-6)
+        check(out, torch.nn.functional.layer_norm(x, (D,), w, b, 1e-6), dtype, k=2, what="layernorm")
+        ops.rmsnorm(x, w, out, 1e-5)
+        check(out, w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5)), dtype, k=2, what="rmsnorm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rope_and_kv_cache(ops, dtype):
+    from leopard_amd.config import RopeScaling
+    from oracle.leopard_oracle import rope_tables, rotate_half
+    S, nq, nkv, D = 777, 32, 8, 128
+    qkv = rnd((S, (nq + 2 * nkv) * D), dtype, 30)
+    orig = qkv.clone()
+    cos, sin = rope_tables(torch.arange(3000, 3000 + S), D, 5e5, RopeScaling())
+    kc = torch.zeros(S + 9, nkv * D, dtype=dtype, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.rope_qk(qkv, nq, nkv, D, cos[:, :D // 2].contiguous().to(DEV), sin[:, :D // 2].contiguous().to(DEV), kc, vc, 4)
+    x = orig.float().cpu().view(S, nq + 2 * nkv, D)
+    rot = x[:, :nq + nkv] * cos[:, None, :] + rotate_half(x[:, :nq + nkv]) * sin[:, None, :]
+    got = qkv.float().cpu().view(S, nq + 2 * nkv, D)
+    check(got[:, :nq + nkv], rot, dtype, k=2, what="rope")
+    assert torch.equal(got[:, nq + nkv:], x[:, nq + nkv:])
+    assert torch.equal(kc[4:4 + S].view(S, nkv, D), qkv.view(S, -1, D)[:, nq:nq + nkv])
+    assert torch.equal(vc[4:4 + S].view(S, nkv, D), orig.view(S, -1, D)[:, nq + nkv:])
+    assert kc[:4].abs().max() == 0 and kc[4 + S:].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_merge_bit_exact(ops, dtype):
+    from leopard_amd.engine import plan_merge
+    D, V, tpt, n_img = 4096, 5000, 169, 3
+    table = rnd((V, D), dtype, 40)
+    ids = torch.randint(0, V - 1, (60,), generator=torch.Generator().manual_seed(41))
+    ids[[5, 20, 21]] = V - 1
+    feats = rnd((n_img * tpt, D), torch.float32, 42)
+    src = torch.from_numpy(plan_merge(ids.numpy(), V - 1, n_img * tpt, tpt))
+    out = torch.empty(src.numel(), D, device=DEV)
+    ops.embed_merge(ids.to(DEV), src.to(DEV), table, feats, out)
+    src_d = src.to(DEV)
+    ref = torch.where((src_d >= 0)[:, None], table[ids.to(DEV)[src_d.clamp(min=0)]].float(), feats[(-src_d - 1).clamp(min=0)])
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_preprocess_tiles_bit_exact(ops, dtype):
+    from leopard_amd.tiler import siglip_normalize
+    n, S, P, ldo = 3, 364, 14, 640
+    u8 = np.random.default_rng(0).integers(0, 256, (n, S, S, 3), dtype=np.uint8)
+    out = torch.full((n * 676, ldo), 7.0, dtype=dtype, device=DEV)
+    ops.preprocess_tiles(torch.from_numpy(u8).to(DEV), out, S, P)
+    pix = torch.from_numpy(siglip_normalize(u8))
+    ref = torch.nn.functional.unfold(pix, kernel_size=P, stride=P).transpose(1, 2).reshape(n * 676, 588)
+    assert torch.equal(out[:, :588].float().cpu(), ref.to(dtype).float())
+    assert out[:, 588:].abs().max() == 0
+    out2 = torch.empty_like(out)
+    ops.preprocess_tiles(pix.contiguous().to(DEV), out2, S, P)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemv_shapes(ops, dtype):
+    from leopard_amd.weights import interleave_gate_up
+    x = rnd((4096,), dtype, 51)
+    w = rnd((8192, 4096), dtype, 50, 0.02)
+    ref = w.float() @ x.float()
+    out = torch.empty(8192, device=DEV)
+    ops.gemv(w, x, out)
+    assert (out - ref).abs().max() <= 2e-3
+    o16 = torch.empty(8192, dtype=dtype, device=DEV)
+    ops.gemv(w, x, o16, epilogue=1)
+    check(o16, ref, dtype, k=2, what="gemv store T")
+    acc = torch.ones(8192, device=DEV)
+    ops.gemv(w, x, acc, epilogue=2)
+    assert (acc - 1 - ref).abs().max() <= 2e-3
+    gate, up = rnd((14336, 4096), dtype, 52, 0.02), rnd((14336, 4096), dtype, 53, 0.02)
+    sw = torch.empty(14336, dtype=dtype, device=DEV)
+    ops.gemv(interleave_gate_up(gate, up), x, sw, epilogue=3)
+    check(sw, torch.nn.functional.silu(gate.float() @ x.float()) * (up.float() @ x.float()), dtype, k=2, what="gemv swiglu")
+    wd, xd = rnd((4096, 14336), dtype, 54, 0.02), rnd((14336,), dtype, 55)
+    od = torch.zeros(4096, device=DEV)
+    ops.gemv(wd, xd, od, epilogue=2)
+    assert (od - wd.float() @ xd.float()).abs().max() <= 5e-3
+
+
+def attn_ref(q, k, v, cu_q, cu_k, H, KV, D, scale, causal):
+    out = torch.zeros(q.shape[0], H * D, device=q.device)
+    for s in range(len(cu_q) - 1):
+        qs = q[cu_q[s]:cu_q[s + 1]].float().reshape(-1, H, D).transpose(0, 1)
+        ks = k[cu_k[s]:cu_k[s + 1]].float().reshape(-1, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+        vs = v[cu_k[s]:cu_k[s + 1]].float().reshape(-1, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+        sc = qs @ ks.transpose(-1, -2) * scale
+        if causal:
+            lq, lk = qs.shape[1], ks.shape[1]
+            m = torch.arange(lk, device=q.device)[None, :] <= torch.arange(lq, device=q.device)[:, None] + (lk - lq)
+            sc = sc.masked_fill(~m, float("-inf"))
+        out[cu_q[s]:cu_q[s + 1]] = (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(-1, H * D)
+    return out
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_tr", [False, True])
+def test_attention_llama_causal_gqa(ops, dtype, use_tr):
+    H, KV, D = 32, 8, 128
+    cu = [0, 1000, 1000 + 77, 1000 + 77 + 333]
+    T = cu[-1]
+    qkv = rnd((T, (H + 2 * KV) * D), dtype, 60)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    out = torch.full((T, H * D), float("nan"), dtype=dtype, device=DEV)
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    ops.attention(q, k, v, out, cu_t, cu_t, 1000, H, KV, D, D ** -0.5, True, use_tr)
+    ref = attn_ref(q, k, v, cu, cu, H, KV, D, D ** -0.5, True)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 3 * eps(dtype), f"use_tr={use_tr}: {err}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_tr", [False, True])
+def test_attention_siglip_noncausal_d72(ops, dtype, use_tr):
+    H, D, n = 16, 72, 3
+    cu = [676 * i for i in range(n + 1)]
+    T = cu[-1]
+    qkv = rnd((T, 3 * H * D), dtype, 61)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    out = torch.full((T, H * D), float("nan"), dtype=dtype, device=DEV)
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    ops.attention(q, k, v, out, cu_t, cu_t, 676, H, H, D, D ** -0.5, False, use_tr)
+    ref = attn_ref(q, k, v, cu, cu, H, H, D, D ** -0.5, False)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 3 * eps(dtype), f"use_tr={use_tr}: {err}"
+
+
+def test_attention_decode_and_chunk_shapes(ops):
+    H, KV, D = 32, 8, 128
+    dtype = torch.float16
+    k, v = rnd((700, KV * D), dtype, 62), rnd((700, KV * D), dtype, 63)
+    for lq in (1, 33, 200):
+        q = rnd((lq, H * D), dtype, 64)
+        out = torch.empty(lq, H * D, dtype=dtype, device=DEV)
+        ops.attention(q, k, v, out, torch.tensor([0, lq], dtype=torch.int32, device=DEV),
+                      torch.tensor([0, 700], dtype=torch.int32, device=DEV), lq, H, KV, D, D ** -0.5, True, True)
+        ref = attn_ref(q, k, v, [0, lq], [0, 700], H, KV, D, D ** -0.5, True)
+        assert (out.float() - ref).abs().max() <= 3 * eps(dtype)
+
+
+def test_attention_full_size_properties(ops):
+    """C3-size causal sequence (S=7187): size-independent properties — with V == 1 every output is exactly 1
+    (softmax rows sum to one), row 0 returns V[0], and two launches are bit-identical."""
+    H, KV, D, S = 32, 8, 128, 7187
+    dtype = torch.bfloat16
+    qkv = rnd((S, (H + 2 * KV) * D), dtype, 70)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    cu = torch.tensor([0, S], dtype=torch.int32, device=DEV)
+    out = torch.empty(S, H * D, dtype=dtype, device=DEV)
+    ops.attention(q, k, v, out, cu, cu, S, H, KV, D, D ** -0.5, True, True)
+    out2 = torch.empty_like(out)
+    ops.attention(q, k, v, out2, cu, cu, S, H, KV, D, D ** -0.5, True, True)
+    assert torch.equal(out, out2)
+    assert torch.equal(out[0].view(H, D), v[0].view(KV, D).repeat_interleave(H // KV, 0))
+    ones = torch.ones(S, KV * D, dtype=dtype, device=DEV)
+    ops.attention(q, k, ones, out, cu, cu, S, H, KV, D, D ** -0.5, True, True)
+    assert (out.float() - 1).abs().max() <= 2.0 ** -7
