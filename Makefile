@@ -9,13 +9,13 @@ EMULIB := tools/hipemu/libleopard_amd_emu.so
 all: $(LIB)
 
 $(LIB): $(CSRC)/capi.hip $(HDRS)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffast-math -fno-finite-math-only \
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
 	    -Wno-unused-value -o $@ $(CSRC)/capi.hip
 
 emu: $(EMULIB)
 
 $(EMULIB): $(CSRC)/capi.hip $(HDRS) tools/hipemu/hipemu.cpp tools/hipemu/hipemu.h
-	$(HOSTCXX) -x c++ -DLMI_EMU -O1 -std=c++17 -fPIC -shared -Itools/hipemu -I$(CSRC) -Wno-unused-value \
+	$(HOSTCXX) -x c++ -DLMI_EMU -O1 -ffp-contract=off -std=c++17 -fPIC -shared -Itools/hipemu -I$(CSRC) -Wno-unused-value \
 	    -o $@ $(CSRC)/capi.hip tools/hipemu/hipemu.cpp
 
 clean:

@@ -43,6 +43,10 @@ enum { LMI_A_PLAIN = 0, LMI_A_PIXEL_SHUFFLE = 1 };
 const char* lmi_last_error(void);
 int lmi_abi_version(void);
 
+/* Tuning knobs (process-global).  "gemm.config": -1 = choose the GEMM tile geometry per shape (default),
+ * 0..4 = force one of the geometries listed in csrc/capi.hip (used by tools/bench_kernels.py for A/B runs). */
+int lmi_set_option(const char* key, int value);
+
 /* Deterministic synthetic parameters (no checkpoints exist offline): element i = f(seed, i, kind); bit-identical
  * to leopard_amd/synth.py.  out_dtype in {LMI_F16, LMI_BF16, LMI_F32}. */
 int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dtype, void* stream);

@@ -22,6 +22,7 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes  (restype is int unless noted); mirrors include/leopard_amd.h one to one
 SIGNATURES = {
     "lmi_abi_version": [],
+    "lmi_set_option": [C.c_char_p, _I],
     "lmi_fill_synthetic": [_P, C.c_int64, C.c_uint32, _I, _I, _P],
     "lmi_preprocess_tiles": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "lmi_layernorm": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],

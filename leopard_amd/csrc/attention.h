@@ -251,4 +251,164 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn_fwd_dma_kernel — head_dim 128 production variant.  Same register-level design as attn_fwd_kernel, but K and V
+// tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 2-slot ring: no staging VGPRs, no ds_write
+// pass, one counted wait + one raw barrier per 64-key tile, and the register budget fits 2 waves per SIMD so a
+// second workgroup's MFMAs run under this one's softmax.  LDS-DMA writes lane-linearly, so the LDS images are
+// unpadded [64][256 B] and de-conflicted by XOR swizzles applied to the per-lane SOURCE chunk and again on read:
+//   K: 16-byte chunk c of row r at c ^ (r & 15)          -> conflict-free ds_read_b128 (16 distinct rows / group)
+//   V: 16-byte chunk c of row r at c ^ ((r & 3) << 2)    -> the 4 key rows of one transpose read use 4 distinct
+//                                                            64-byte bank groups
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int ATTD_TILE_BYTES = ATT_BKV * 256;                 // one K or V tile image
+constexpr int ATTD_SMEM = 4 * ATTD_TILE_BYTES;                 // 2 slots x (K + V) = 64 KiB
+
+template <typename T, bool CAUSAL>
+__global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p) {
+    constexpr int D = 128, NKS = 8, NDB = 4;
+    typedef typename vec_of<T>::x8 T8;
+    typedef typename vec_of<T>::x4 T4;
+    LMI_DYN_SMEM(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int fr = lane & 31, fh = lane >> 5;
+    const int seq = blockIdx.z, head = blockIdx.y;
+    const int kvh = head / (p.n_heads / p.n_kv_heads);
+    const int q_beg = p.cu_q[seq], len_q = p.cu_q[seq + 1] - q_beg;
+    const int k_beg = p.cu_k[seq], len_k = p.cu_k[seq + 1] - k_beg;
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+    const int q0 = qb * ATT_BQ;
+    if (q0 >= len_q) return;
+    const int shift = len_k - len_q;
+    int kv_end = len_k;
+    if (CAUSAL) kv_end = imin(len_k, q0 + ATT_BQ + shift);
+    const int n_tiles = (kv_end + ATT_BKV - 1) / ATT_BKV;
+
+    const int my_q = q0 + wave * 32 + fr;
+    const T* q_row = (const T*)p.q + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldq + head * D;
+    T8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const T8*)(q_row + (2 * ks + fh) * 8);
+
+    // ---- LDS-DMA sources: piece i covers rows i*16 .. i*16+15; this lane owns (row, physical chunk) -------------
+    const T* k_base = (const T*)p.k + (long)k_beg * p.ldk + kvh * D;
+    const T* v_base = (const T*)p.v + (long)k_beg * p.ldv + kvh * D;
+    const int prow = tid >> 4, pchunk = tid & 15;
+    auto issue_tile = [&](int t, int slot) {
+        char* kdst = smem + slot * 2 * ATTD_TILE_BYTES + wave * 1024;
+        char* vdst = kdst + ATTD_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + prow;
+            const int key = imin(t * ATT_BKV + r, len_k - 1);
+            glds16(k_base + (long)key * p.ldk + ((pchunk ^ (r & 15)) << 3), kdst + i * 4096);
+            glds16(v_base + (long)key * p.ldv + ((pchunk ^ ((r & 3) << 2)) << 3), vdst + i * 4096);
+        }
+    };
+
+    f32x16 o_acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = p.scale * 1.4426950408889634f;
+    const int wave_q_lo = q0 + wave * 32, wave_q_hi = wave_q_lo + 31;
+
+    // transpose-read lane geometry: lane i = 4j+g of a 16-lane group addresses key row j, 8-byte column group g;
+    // for d-block db the 64-byte granule is db ^ j (V swizzle), constant per lane
+    const int tr_j = (lane & 15) >> 2, tr_g = lane & 3, tr_half = (lane >> 4) & 1;
+    int v_off[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) v_off[db] = (4 * fh + tr_j) * 256 + ((db ^ tr_j) << 6) + tr_half * 32 + tr_g * 8;
+
+    issue_tile(0, 0);
+    for (int t = 0; t < n_tiles; ++t) {
+        wait_vmcnt_barrier<0>();                                   // tile t landed; slot of tile t-1 is free
+        if (t + 1 < n_tiles) issue_tile(t + 1, (t + 1) & 1);
+        const int kv0 = t * ATT_BKV;
+        if (CAUSAL && kv0 > wave_q_hi + shift) continue;
+        const char* k_lds = smem + (t & 1) * 2 * ATTD_TILE_BYTES;
+        const char* v_lds = k_lds + ATTD_TILE_BYTES;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+            const int row = b * 32 + fr;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const T8 kf = *(const T8*)(k_lds + row * 256 + (((2 * ks + fh) ^ (row & 15)) << 4));
+                s[b] = mfma32(kf, qf[ks], s[b]);
+            }
+        }
+        const bool need_mask = (kv0 + ATT_BKV > len_k) || (CAUSAL && (kv0 + ATT_BKV - 1 > wave_q_lo + shift));
+        if (need_mask) {
+            const int lim = CAUSAL ? imin(len_k - 1, my_q + shift) : len_k - 1;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (key > lim) s[b][r] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][r]);
+        mx = fmaxf(mx, shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2((m_run - m_use) * c2);
+        m_run = m_new;
+        const float mc = m_use * c2;
+        float psum = 0.f;
+        T8 pf[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(s[b][r] * c2 - mc);
+                psum += pv;
+                pf[b][r >> 3][r & 7] = (T)pv;
+            }
+        l_run = l_run * alpha + psum;
+        if (alpha != 1.0f) {                                        // per-lane: rescale only rows whose max moved
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4 vraw[NDB];
+                ds_read_tr16_gather4(v_lds, v_off, (b * 32 + 16 * u) * 256, vraw);
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+                    o_acc[db] = mfma32(__builtin_bit_cast(T8, vraw[db]), pf[b][u], o_acc[db]);
+            }
+    }
+
+    const float l_tot = l_run + shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (my_q < len_q) {
+        T* o_row = (T*)p.out + (long)(q_beg + my_q) * p.ldo + head * D;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                T4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)(o_acc[db][qd * 4 + e] * inv);
+                *(T4*)(o_row + db * 32 + 8 * qd + 4 * fh) = o;
+            }
+    }
+}
+
 }  // namespace lmi

@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "attention.h"
 #include "elementwise.h"
@@ -47,12 +48,53 @@ int grid_for(long n, int block, int cap = 256 * 8) {
 }
 
 // ---- GEMM dispatch ---------------------------------------------------------------------------------------
+// tile geometries (see gemm.h GemmCfg<BM, BN, WAVES_M, WAVES_N, STAGES>)
+typedef GemmCfg<128, 128, 2, 2, 2> Cfg0;   //  64 KiB LDS, 256 threads, 2 workgroups / CU
+typedef GemmCfg<256, 256, 2, 4, 2> Cfg1;   // 128 KiB LDS, 512 threads, wave tile 128x64
+typedef GemmCfg<256, 128, 4, 2, 3> Cfg2;   // 144 KiB LDS, 512 threads, wave tile 64x64, 3-slot ring
+typedef GemmCfg<256, 128, 4, 2, 2> Cfg3;   //  96 KiB LDS
+typedef GemmCfg<128, 256, 2, 4, 3> Cfg4;   // 144 KiB LDS, wave tile 64x64, 3-slot ring
+constexpr int kNumGemmCfg = 6;              // 5 = Cfg1 geometry on the staggered two-group schedule
+int g_gemm_cfg = -1;                        // -1 = choose per shape
+
+template <typename T, int EPI, int ACT, int AMODE, typename C>
+int launch_gemm_cfg(const GemmArgs& a, void* stream) {
+    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    static bool attr_set = false;
+    if (!attr_set) { allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE, C>, C::SMEM); attr_set = true; }
+    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
+    return check_launch("lmi_gemm");
+}
+
+template <typename T, int EPI, int ACT, int AMODE, typename C>
+int launch_gemm_stagger(const GemmArgs& a, void* stream) {
+    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    static bool attr_set = false;
+    if (!attr_set) { allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C>, C::SMEM); attr_set = true; }
+    LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
+    return check_launch("lmi_gemm");
+}
+
+// Geometry per shape, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_geometries.md): wide outputs take the
+// staggered 256x256 schedule; narrow-N / deep-K (SigLIP fc2) the 256x128 3-slot ring; small problems 128x128.
+int choose_gemm_cfg(const GemmArgs& a) {
+    if (g_gemm_cfg >= 0) return g_gemm_cfg;
+    if (a.M < 512) return 0;
+    if (a.N >= 2048) return 5;
+    if (a.K >= 2048) return 2;
+    return 0;
+}
+
 template <typename T, int EPI, int ACT, int AMODE>
 int launch_gemm(const GemmArgs& a, void* stream) {
-    const int tiles = ((a.M + GEMM_BM - 1) / GEMM_BM) * (a.N / GEMM_BN);
-    allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE>, GEMM_SMEM_BYTES);
-    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE>), dim3(tiles), dim3(GEMM_THREADS), GEMM_SMEM_BYTES, stream, a);
-    return check_launch("lmi_gemm");
+    switch (choose_gemm_cfg(a)) {
+        case 1: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg1>(a, stream);
+        case 2: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg2>(a, stream);
+        case 3: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg3>(a, stream);
+        case 4: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg4>(a, stream);
+        case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1>(a, stream);
+        default: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg0>(a, stream);
+    }
 }
 
 template <typename T>
@@ -90,8 +132,21 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
                AttnGeom<D>::SMEM, stream, a);
     return check_launch("lmi_attn_varlen_fwd");
 }
+int g_attn_dma = 1;                          // head_dim 128: 1 = LDS-DMA kernel, 0 = register-staged kernel
+
+template <typename T, bool CAUSAL>
+int launch_attn_dma(const AttnArgs& a, int n_seq, int max_q, void* stream) {
+    const int qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
+    static bool attr_set = false;
+    if (!attr_set) { allow_big_lds(attn_fwd_dma_kernel<T, CAUSAL>, ATTD_SMEM); attr_set = true; }
+    LMI_LAUNCH((attn_fwd_dma_kernel<T, CAUSAL>), dim3(qblocks, a.n_heads, n_seq), dim3(ATT_THREADS), ATTD_SMEM, stream, a);
+    return check_launch("lmi_attn_varlen_fwd");
+}
+
 template <typename T, int D>
 int dispatch_attn(const AttnArgs& a, int n_seq, int max_q, int causal, int use_tr, void* stream) {
+    if (D == 128 && use_tr && g_attn_dma)
+        return causal ? launch_attn_dma<T, true>(a, n_seq, max_q, stream) : launch_attn_dma<T, false>(a, n_seq, max_q, stream);
     if (causal) return use_tr ? launch_attn<T, D, true, true>(a, n_seq, max_q, stream)
                               : launch_attn<T, D, true, false>(a, n_seq, max_q, stream);
     return use_tr ? launch_attn<T, D, false, true>(a, n_seq, max_q, stream)
@@ -166,6 +221,17 @@ extern "C" {
 const char* lmi_last_error(void) { return g_err; }
 int lmi_abi_version(void) { return 1; }
 
+int lmi_set_option(const char* key, int value) {
+    if (!key) return fail(LMI_EINVAL, "lmi_set_option: null key");
+    if (!strcmp(key, "gemm.config")) {
+        if (value < -1 || value >= kNumGemmCfg) return fail(LMI_EINVAL, "lmi_set_option: gemm.config in [-1, %d)", kNumGemmCfg);
+        g_gemm_cfg = value;
+        return LMI_OK;
+    }
+    if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
+    return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);
+}
+
 int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dtype, void* stream) {
     if (!out || n < 0 || kind < 0 || kind > 2) return fail(LMI_EINVAL, "lmi_fill_synthetic: bad argument");
     if (n == 0) return LMI_OK;
@@ -204,7 +270,7 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
              int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
              int ps_grid, int dtype, void* stream) {
     if (!A || !W || !out) return fail(LMI_EINVAL, "lmi_gemm: null pointer");
-    if (M < 0 || N <= 0 || K <= 0 || (N % GEMM_BN) || (K % GEMM_BK))
+    if (M < 0 || N <= 0 || K <= 0 || (N % 128) || (K % GEMM_BK))
         return fail(LMI_EINVAL, "lmi_gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
     if ((lda & 7) || (ldw & 7) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out) ||
         (bias && !aligned16(bias)) || (addmat && !aligned16(addmat)))

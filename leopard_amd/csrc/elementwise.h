@@ -48,7 +48,7 @@ __global__ void im2col_kernel(const void* in, T* out, int n_tiles, int S, int P,
             const int y = py * P + ky, x = px * P + kx;
             if (FROM_U8) {
                 const float u = (float)((const uint8_t*)in)[((n * S + y) * S + x) * 3 + c];
-                v = (u * (1.0f / 255.0f) - 0.5f) / 0.5f;
+                v = mul_rn(sub_rn(mul_rn(u, 1.0f / 255.0f), 0.5f), 2.0f);     // no FMA contraction: bit-exact vs the processor
             } else {
                 v = ((const float*)in)[((n * 3 + c) * S + y) * (long)S + x];
             }

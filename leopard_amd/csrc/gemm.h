@@ -4,21 +4,27 @@
 // projector's linear_1 (with the 2x2 pixel-shuffle folded into the A-row gather, EVAL:165-192) and
 // linear_2; Llama q/k/v/o, gate/up (SwiGLU fused in the epilogue), down; all-position lm_head.
 //
-// Kernel shape (gfx950): 128x128 output tile, BK=64, 256 threads = 4 waves in a 2x2 grid, each wave
-// owns a 64x64 sub-tile as 2x2 v_mfma_f32_32x32x16 accumulators (64 fp32 / lane).
-//   * Both operands are K-contiguous, staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round trip),
-//     double buffered (2 x 32 KiB): the next k-tile streams in while the current one feeds the MFMAs.
-//   * LDS image is lane-linear per wave instruction (hardware rule), so the bank-conflict swizzle is applied
-//     on the SOURCE address and again on the ds_read_b128 address: 16-byte chunk c of row r is stored at
-//     chunk c ^ ((r>>1)&7).  With 128-byte rows this makes every 16-lane ds_read_b128 group hit 16
-//     distinct 16-byte slots of the 256-byte bank row (checked in tests/test_emu_kernels.py).
+// One kernel template, several tile geometries (GemmCfg): BM x BN output tile, BK = 64, WAVES_M x WAVES_N
+// waves, each wave owning a (BM/WAVES_M) x (BN/WAVES_N) sub-tile as MI x NI v_mfma_f32_32x32x16 accumulators.
+//   * Both operands are K-contiguous and go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip)
+//     into a ring of STAGES k-tile slots.  Loads for tile t+STAGES-1 are issued, interleaved between the MFMAs,
+//     while tile t is being multiplied; the only synchronisation per k-tile is one counted `s_waitcnt vmcnt(N)`
+//     (never 0 in steady state for STAGES >= 3) + one raw s_barrier.
+//   * The LDS image is lane-linear per wave instruction (hardware rule), so the bank-conflict swizzle is applied
+//     on the SOURCE address and again on the ds_read_b128 address: 16-byte chunk c of row r is stored at chunk
+//     c ^ ((r>>1)&7).  With 128-byte rows every 16-lane ds_read_b128 group hits 16 distinct 16-byte slots of the
+//     256-byte bank row (checked in tests/test_emu_kernels.py).
 //   * The MFMA is issued "swapped": A-operand = W rows (n), B-operand = A rows (m), so that a lane owns ONE
-//     output row m and 4 consecutive n per accumulator quad -> 8/16-byte vector epilogue stores, row-wise
-//     fused epilogues (bias, GELU, residual add into the fp32 stream, SwiGLU on interleaved gate/up blocks).
+//     output row m and 4 consecutive n per accumulator quad -> 8/16-byte vector epilogue stores and row-wise
+//     fused epilogues (bias, GELU, residual add into the fp32 stream, SwiGLU on interleaved gate/up blocks,
+//     position-table add, row scatter).
 //   * blockIdx -> tile map is XCD-aware: the 8 XCDs each get a contiguous slab of the tile space, walked in
 //     groups of GROUP_M row-tiles so that a slab's A/W panels stay in that XCD's private 4 MiB L2.
-// Requirements (met by weight preparation, leopard_amd/engine.py): N % 128 == 0, K % 64 == 0, 16-byte
-// aligned rows.  M is arbitrary (tail rows are clamped on load and masked on store).
+// Why big tiles: at full MFMA rate a 128x128 tile needs 64 B/clk/CU of L2->LDS traffic — the whole per-CU vector
+// memory path; 256x256 halves it.
+// Requirements (met by weight preparation, leopard_amd/weights.py): N % 128 == 0, K % 64 == 0, 16-byte aligned
+// rows.  M is arbitrary and N may be a non-multiple of BN (tail rows / columns are clamped on load and masked
+// on store).
 #pragma once
 #include "lmi_device.h"
 
@@ -41,21 +47,45 @@ struct GemmArgs {
     int ps_grid;          // pixel-shuffle: G (26); output tokens per tile = (G/2)^2; C = K/4
 };
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64, GEMM_THREADS = 256;
-constexpr int GEMM_TILE_BYTES = GEMM_BM * GEMM_BK * 2;            // 16 KiB per operand per stage
-constexpr int GEMM_SMEM_BYTES = 4 * GEMM_TILE_BYTES;              // 2 stages x (A + W) = 64 KiB
+constexpr int GEMM_BK = 64;
 constexpr int GEMM_GROUP_M = 8;
 
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int STAGES_>
+struct GemmCfg {
+    static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, STAGES = STAGES_;
+    static constexpr int NT = 64 * WAVES_M * WAVES_N;
+    static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    static constexpr int MI = WTM / 32, NI = WTN / 32;
+    static constexpr int ROWS_PER_PASS = NT / 8;               // 8 lanes cover one 128-byte row
+    static constexpr int A_PASSES = BM / ROWS_PER_PASS, W_PASSES = BN / ROWS_PER_PASS;
+    static constexpr int G = A_PASSES + W_PASSES;              // LDS-DMA instructions per thread per k-tile
+    static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int SMEM = STAGES * STAGE_BYTES;
+    static constexpr int D = STAGES - 1;                       // prefetch distance in k-tiles (>= 1)
+    static_assert(STAGES >= 2, "ring needs at least two slots");
+    static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows vs threads");
+    static_assert(WTM % 32 == 0 && WTN % 64 == 0, "wave tile must hold gate/up block pairs");
+    static_assert(G * D <= 63, "vmcnt range");
+};
+
+// ---- fast activations (v_exp_f32 / v_rcp_f32; abs error ~1e-7, far below the 16-bit output rounding) ----------
+LMI_DEV float fast_tanh(float u) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2(u * 2.8853900817779268f)); }
+LMI_DEV float fast_erf(float x) {                              // Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
+    const float ax = fabsf(x);
+    const float t = fast_rcp(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * fast_exp2(-ax * ax * 1.4426950408889634f);
+    return x < 0.f ? -r : r;
+}
+LMI_DEV float fast_silu(float g) { return g * fast_rcp(1.0f + fast_exp2(-g * 1.4426950408889634f)); }
+
 LMI_DEV float act_apply(float x, int act) {
-    if (act == ACT_GELU_TANH) {
-        const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-        return 0.5f * x * (1.0f + tanhf(u));
-    }
-    if (act == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+    if (act == ACT_GELU_TANH) return 0.5f * x * (1.0f + fast_tanh(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    if (act == ACT_GELU_ERF) return 0.5f * x * (1.0f + fast_erf(x * 0.7071067811865476f));
     return x;
 }
 
-// byte offset of logical 16-byte chunk `lc` of row `r` inside a [128][64] 16-bit tile
+// byte offset of logical 16-byte chunk `lc` of row `r` inside a [rows][64] 16-bit tile (128-byte rows)
 LMI_DEV int gemm_lds_off(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); }
 
 // XCD-aware, grouped tile order (bijective for any tile count)
@@ -73,135 +103,42 @@ LMI_DEV void gemm_tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& t
     tn = in_g / gsize;
 }
 
-template <typename T, int EPI, int ACT, int AMODE>
-__global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmArgs p) {
-    typedef typename vec_of<T>::x8 T8;
+// ---- epilogue shared by every geometry: lane owns row m = .. + fr and 4 consecutive n per accumulator quad -----
+template <typename T, int EPI, int ACT, typename C>
+LMI_DEV void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[C::NI][C::MI], int m0, int n0, int wm, int wn, int fr, int fh) {
     typedef typename vec_of<T>::x4 T4;
-    LMI_DYN_SMEM(smem);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = p.N / GEMM_BN;
-    int tm, tn;
-    gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-
-    // ---- per-thread staging sources: 4 passes x (one A row, one W row); chunk position is fixed --------
-    const int srow = tid >> 3;                       // physical row inside a 32-row pass
-    const int pc = tid & 7;                          // physical 16-byte chunk inside the 128-byte row
-    const char* a_src[4];
-    const char* w_src[4];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int r = ps * 32 + srow;
-        const int lc = pc ^ ((r >> 1) & 7);
-        int am = imin(m0 + r, p.M - 1);
-        long arow;
-        if (AMODE == AMODE_PIXSHUF) {
-            const int g = p.ps_grid, h = g >> 1, per = h * h;
-            const int tile = am / per, pp = am - tile * per;
-            const int ph = pp / h, pw = pp - ph * h;
-            arow = (long)tile * g * g + (long)(2 * ph) * g + 2 * pw;
-        } else {
-            arow = am;
-        }
-        a_src[ps] = (const char*)p.A + (arow * p.lda + lc * 8) * 2;
-        w_src[ps] = (const char*)p.W + ((long)(n0 + r) * p.ldw + lc * 8) * 2;
-    }
-    const int ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 0;     // channels per shuffle segment
-
-    auto stage = [&](int kt, int buf) {
-        char* a_dst = smem + buf * 2 * GEMM_TILE_BYTES + wave * 1024;
-        char* w_dst = a_dst + GEMM_TILE_BYTES;
-        long a_off = (long)kt * GEMM_BK * 2;
-        if (AMODE == AMODE_PIXSHUF) {
-            const int k0 = kt * GEMM_BK;
-            const int seg = k0 / ps_c;                               // 0..3 = (dh, dw)
-            a_off = ((long)((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2;
-        }
-        const long w_off = (long)kt * GEMM_BK * 2;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            glds16(a_src[ps] + a_off, a_dst + ps * 4096);
-            glds16(w_src[ps] + w_off, w_dst + ps * 4096);
-        }
-    };
-
-    f32x16 acc[2][2];                                 // [ni][mi]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int fr = lane & 31, fh = lane >> 5;
-    const int nt = p.K / GEMM_BK;
-    stage(0, 0);
-#ifndef LMI_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) stage(t + 1, buf ^ 1);
-        const char* a_t = smem + buf * 2 * GEMM_TILE_BYTES;
-        const char* w_t = a_t + GEMM_TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            T8 af[2], wf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *(const T8*)(a_t + gemm_lds_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
-                wf[i] = *(const T8*)(w_t + gemm_lds_off(wn * 64 + i * 32 + fr, ks * 2 + fh));
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
-        }
-#ifndef LMI_EMU
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane owns row m = .. + fr and 4 consecutive n per accumulator quad ------------------
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + fr;
+    for (int mi = 0; mi < C::MI; ++mi) {
+        const int m = m0 + wm * C::WTM + mi * 32 + fr;
         if (m >= p.M) continue;
         const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
         if (EPI == EPI_SWIGLU_T) {
-            // W rows are interleaved in 32-row blocks [gate | up]; this wave holds gate in ni=0, up in ni=1
-            const int ocol0 = ((n0 + wn * 64) >> 1);
+            // W rows are interleaved in 32-row blocks [gate | up]: accumulator ni = 2j holds gate, 2j+1 holds up
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                T4 v;
+            for (int nj = 0; nj < C::NI / 2; ++nj) {
+                const int nb = n0 + wn * C::WTN + nj * 64;
+                if (nb >= p.N) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float g = acc[0][mi][q * 4 + e], u = acc[1][mi][q * 4 + e];
-                    v[e] = (T)(g / (1.0f + lmi::fexp(-g)) * u);
+                for (int q = 0; q < 4; ++q) {
+                    T4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (T)(fast_silu(acc[2 * nj][mi][q * 4 + e]) * acc[2 * nj + 1][mi][q * 4 + e]);
+                    *(T4*)((T*)p.out + orow * p.ldo + (nb >> 1) + q * 8 + fh * 4) = v;
                 }
-                *(T4*)((T*)p.out + orow * p.ldo + ocol0 + q * 8 + fh * 4) = v;
             }
         } else {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < C::NI; ++ni) {
+                const int nb = n0 + wn * C::WTN + ni * 32;
+                if (nb >= p.N) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + ni * 32 + q * 8 + fh * 4;
+                    const int n = nb + q * 8 + fh * 4;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][q * 4 + e];
-                    if (p.bias) {
-                        const f32x4 b = *(const f32x4*)(p.bias + n);
-                        v += b;
-                    }
-                    if (p.addmat) {
-                        const f32x4 a = *(const f32x4*)(p.addmat + (long)(m % p.add_period) * p.N + n);
-                        v += a;
-                    }
+                    if (p.bias) v += *(const f32x4*)(p.bias + n);
+                    if (p.addmat) v += *(const f32x4*)(p.addmat + (long)(m % p.add_period) * p.N + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
                     if (EPI == EPI_STORE_T) {
@@ -216,8 +153,234 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmArgs p) {
                         *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
                     }
                 }
+            }
         }
     }
+}
+
+template <typename T, int EPI, int ACT, int AMODE, typename C>
+__global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
+    typedef typename vec_of<T>::x8 T8;
+    typedef typename vec_of<T>::x4 T4;
+    LMI_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = wave_id();
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+    const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = (p.N + C::BN - 1) / C::BN;
+    int tm, tn;
+    gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * C::BM, n0 = tn * C::BN;
+
+    // ---- per-thread staging sources: one row per pass; the 16-byte chunk position is fixed per thread ----------
+    const int srow = tid >> 3;                       // physical row inside a pass
+    const int pc = tid & 7;                          // physical 16-byte chunk inside the 128-byte row
+    const char* a_src[C::A_PASSES];
+    const char* w_src[C::W_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < C::A_PASSES; ++ps) {
+        const int r = ps * C::ROWS_PER_PASS + srow;
+        const int lc = pc ^ ((r >> 1) & 7);
+        const int am = imin(m0 + r, p.M - 1);
+        long arow;
+        if (AMODE == AMODE_PIXSHUF) {
+            const int g = p.ps_grid, h = g >> 1, per = h * h;
+            const int tile = am / per, pp = am - tile * per;
+            const int ph = pp / h, pw = pp - ph * h;
+            arow = (long)tile * g * g + (long)(2 * ph) * g + 2 * pw;
+        } else {
+            arow = am;
+        }
+        a_src[ps] = (const char*)p.A + (arow * p.lda + lc * 8) * 2;
+    }
+#pragma unroll
+    for (int ps = 0; ps < C::W_PASSES; ++ps) {
+        const int r = ps * C::ROWS_PER_PASS + srow;
+        const int lc = pc ^ ((r >> 1) & 7);
+        w_src[ps] = (const char*)p.W + ((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2;
+    }
+    const int ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;     // channels per shuffle segment
+
+    // one LDS-DMA instruction: piece g (0..G-1) of k-tile kt into ring slot `slot`
+    auto issue_piece = [&](int g, int kt, int slot) {
+        char* base = smem + slot * C::STAGE_BYTES + wave * 1024;
+        if (g < C::A_PASSES) {
+            long a_off = (long)kt * GEMM_BK * 2;
+            if (AMODE == AMODE_PIXSHUF) {
+                const int k0 = kt * GEMM_BK;
+                const int seg = k0 / ps_c;                           // 0..3 = (dh, dw)
+                a_off = ((long)((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2;
+            }
+            glds16(a_src[g] + a_off, base + g * (C::ROWS_PER_PASS * 128));
+        } else {
+            const int gw = g - C::A_PASSES;
+            glds16(w_src[gw] + (long)kt * GEMM_BK * 2, base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
+        }
+    };
+
+    f32x16 acc[C::NI][C::MI];
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::MI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nt = p.K / GEMM_BK;
+
+    // ---- prologue: D tiles in flight -----------------------------------------------------------------------------
+#pragma unroll
+    for (int d = 0; d < C::D; ++d)
+        if (d < nt) {
+#pragma unroll
+            for (int g = 0; g < C::G; ++g) issue_piece(g, d, d);
+        }
+
+    for (int t = 0; t < nt; ++t) {
+        // tile t has landed once at most the D-1 younger tiles are outstanding (ring tail: everything)
+        if (C::D >= 2 && t + C::D - 1 < nt) wait_vmcnt_barrier<(C::D >= 2 ? C::G * (C::D - 1) : 0)>();
+        else wait_vmcnt_barrier<0>();
+        const int slot = t % C::STAGES;
+        const char* a_t = smem + slot * C::STAGE_BYTES;
+        const char* w_t = a_t + C::A_BYTES;
+        const int t_issue = t + C::D;                                // k-tile whose loads are issued under this tile
+        const bool do_issue = t_issue < nt;
+        const int slot_issue = t_issue % C::STAGES;                  // == slot of tile t-1: free since the barrier
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            T8 af[C::MI], wf[C::NI];
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) af[i] = *(const T8*)(a_t + gemm_lds_off(wm * C::WTM + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+            for (int i = 0; i < C::NI; ++i) wf[i] = *(const T8*)(w_t + gemm_lds_off(wn * C::WTN + i * 32 + fr, ks * 2 + fh));
+            if (do_issue) {
+#pragma unroll
+                for (int g = ks * C::G / 4; g < (ks + 1) * C::G / 4; ++g) issue_piece(g, t_issue, slot_issue);
+            }
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < C::MI; ++mi) acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
+        }
+    }
+
+    gemm_epilogue<T, EPI, ACT, C>(p, acc, m0, n0, wm, wn, fr, fh);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Staggered two-group schedule (8 waves, 2-slot ring).  Each k-step (one of the four 16-deep slices of a k-tile)
+// is a LOAD segment {6 ds_read_b128 of this wave's fragments + this wave's share of the NEXT tile's LDS-DMA} and
+// an MFMA segment {MI*NI MFMAs at raised priority}, each closed by a workgroup barrier.  Waves 4-7 run exactly
+// one barrier behind waves 0-3 (one extra barrier at entry, balanced by one for waves 0-3 at exit), so on every
+// SIMD — which hosts one wave of each group — one wave is always in its MFMA segment while its partner is in its
+// LOAD segment: matrix pipe beside LDS/VMEM issue instead of both waves competing for the same pipe in lock-step.
+// Hazards: fragments are read only in LOAD segments; the pieces of tile t+1 are issued in the LOAD segments of
+// k-steps 0 and 1 of tile t (the slot's previous tenant, tile t-1, was last read one full segment earlier by the
+// lagging group) and every wave drains its own pieces (vmcnt(0)) before the barrier that closes its k-step-3 LOAD
+// segment, which precedes the first read of tile t+1 by either group.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int EPI, int ACT, int AMODE, typename C>
+__global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
+    static_assert(C::STAGES == 2 && C::NT == 512, "staggered schedule: 8 waves, 2-slot ring");
+    typedef typename vec_of<T>::x8 T8;
+    LMI_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = wave_id();
+    const int grp = wave >> 2;
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+    const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = (p.N + C::BN - 1) / C::BN;
+    int tm, tn;
+    gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * C::BM, n0 = tn * C::BN;
+
+    const int srow = tid >> 3, pc = tid & 7;
+    const char* a_src[C::A_PASSES];
+    const char* w_src[C::W_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < C::A_PASSES; ++ps) {
+        const int r = ps * C::ROWS_PER_PASS + srow;
+        const int lc = pc ^ ((r >> 1) & 7);
+        const int am = imin(m0 + r, p.M - 1);
+        long arow;
+        if (AMODE == AMODE_PIXSHUF) {
+            const int g = p.ps_grid, h = g >> 1, per = h * h;
+            const int tile = am / per, pp = am - tile * per;
+            const int ph = pp / h, pw = pp - ph * h;
+            arow = (long)tile * g * g + (long)(2 * ph) * g + 2 * pw;
+        } else {
+            arow = am;
+        }
+        a_src[ps] = (const char*)p.A + (arow * p.lda + lc * 8) * 2;
+    }
+#pragma unroll
+    for (int ps = 0; ps < C::W_PASSES; ++ps) {
+        const int r = ps * C::ROWS_PER_PASS + srow;
+        const int lc = pc ^ ((r >> 1) & 7);
+        w_src[ps] = (const char*)p.W + ((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2;
+    }
+    const int ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;
+    auto issue_piece = [&](int g, int kt, int slot) {
+        char* base = smem + slot * C::STAGE_BYTES + wave * 1024;
+        if (g < C::A_PASSES) {
+            long a_off = (long)kt * GEMM_BK * 2;
+            if (AMODE == AMODE_PIXSHUF) {
+                const int k0 = kt * GEMM_BK;
+                const int seg = k0 / ps_c;
+                a_off = ((long)((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2;
+            }
+            glds16(a_src[g] + a_off, base + g * (C::ROWS_PER_PASS * 128));
+        } else {
+            const int gw = g - C::A_PASSES;
+            glds16(w_src[gw] + (long)kt * GEMM_BK * 2, base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
+        }
+    };
+
+    f32x16 acc[C::NI][C::MI];
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::MI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nt = p.K / GEMM_BK;
+#pragma unroll
+    for (int g = 0; g < C::G; ++g) issue_piece(g, 0, 0);
+    wait_vmcnt_barrier<0>();
+    if (grp == 1) raw_barrier();                                   // waves 4-7 run one barrier behind
+
+    for (int t = 0; t < nt; ++t) {
+        const char* a_t = smem + (t & 1) * C::STAGE_BYTES;
+        const char* w_t = a_t + C::A_BYTES;
+        const bool do_issue = t + 1 < nt;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            // ---- LOAD segment ---------------------------------------------------------------------------------
+            T8 af[C::MI], wf[C::NI];
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) af[i] = *(const T8*)(a_t + gemm_lds_off(wm * C::WTM + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+            for (int i = 0; i < C::NI; ++i) wf[i] = *(const T8*)(w_t + gemm_lds_off(wn * C::WTN + i * 32 + fr, ks * 2 + fh));
+            if (ks < 2 && do_issue) {
+#pragma unroll
+                for (int g = ks * C::G / 2; g < (ks + 1) * C::G / 2; ++g) issue_piece(g, t + 1, (t + 1) & 1);
+            }
+            if (ks == 3) wait_vmcnt_barrier<0>(); else raw_barrier();
+            // ---- MFMA segment ---------------------------------------------------------------------------------
+            sched_fence();
+            setprio_hi();
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < C::MI; ++mi) acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
+            setprio_lo();
+            sched_fence();
+            raw_barrier();
+        }
+    }
+    if (grp == 0) raw_barrier();                                   // balance the barrier count
+    gemm_epilogue<T, EPI, ACT, C>(p, acc, m0, n0, wm, wn, fr, fh);
 }
 
 }  // namespace lmi

@@ -46,6 +46,11 @@ template <> struct vec_of<bf16_t> { typedef bf16x8 x8; typedef bf16x4 x4; typede
 #define LMI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 
 LMI_DEV int lane_id() { return threadIdx.x & 63; }
+LMI_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }   // provably wave-uniform
+
+// Wait until at most N of this wave's VMEM operations (LDS-DMA pieces) are outstanding, then workgroup barrier.
+// Raw s_barrier on purpose: __syncthreads() would drain vmcnt to 0 while LDS-DMA is in flight.
+template <int N> LMI_DEV void wait_vmcnt_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
 
 // D[32x32] += A[32x16] * B[16x32].  Lane l supplies A[l&31][8*(l>>5)+j] and B[8*(l>>5)+j][l&31], j=0..7;
 // receives D[(r&3)+8*(r>>2)+4*(l>>5)][l&31], r=0..15.
@@ -64,6 +69,8 @@ LMI_DEV void glds16(const void* gptr, void* lds_wave_base) {
 
 // LDS transpose read: within each 16-lane group, lane i = 4*j+g supplies the address of 4 consecutive
 // 16-bit elements (row j, column group g); lane c receives {row0[c], row1[c], row2[c], row3[c]}.
+LMI_DEV void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
 LMI_DEV u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     u32x2 r;
     unsigned addr = (unsigned)(size_t)lds_ptr;
@@ -111,6 +118,31 @@ LMI_DEV void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
     out[2] = u32x4{a2[0], a2[1], b2[0], b2[1]};
 }
 
+// Attention V operand: 8 transpose reads (4 d-blocks x {keys +0..3, keys +8..11}) from per-lane addresses
+// base + off[db] + imm, one wait.  out[db] = {lo.x, lo.y, hi.x, hi.y}.  `imm` selects the 16-key step.
+LMI_DEV void ds_read_tr16_gather4(const void* base, const int (&off)[4], int imm, u32x4* out) {
+    const unsigned b = (unsigned)(size_t)base + (unsigned)imm;
+    const unsigned a0 = b + off[0], a1 = b + off[1], a2 = b + off[2], a3 = b + off[3];
+    u32x2 l0, l1, l2, l3, h0, h1, h2, h3;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %2, %9\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %4, %10\n\t"
+        "ds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %6, %11\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:2048\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+        : "memory");
+    out[0] = u32x4{l0[0], l0[1], h0[0], h0[1]};
+    out[1] = u32x4{l1[0], l1[1], h1[0], h1[1]};
+    out[2] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+    out[3] = u32x4{l3[0], l3[1], h3[0], h3[1]};
+}
+
 LMI_DEV float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 LMI_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 LMI_DEV float shfl(float v, int l) { return __shfl(v, l, 64); }
@@ -120,6 +152,8 @@ LMI_DEV void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 LMI_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 LMI_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 LMI_DEV float fexp(float x) { return __expf(x); }
+LMI_DEV float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+LMI_DEV float sub_rn(float a, float b) { return __fsub_rn(a, b); }
 
 #define LMI_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
@@ -132,6 +166,9 @@ LMI_DEV float fexp(float x) { return __expf(x); }
 #define LMI_DYN_SMEM(name) char* name = hipemu::dyn_smem()
 
 inline int lane_id() { return threadIdx.x & 63; }
+inline int wave_id() { return (int)(threadIdx.x >> 6); }
+template <int N> inline void wait_vmcnt_barrier() { __syncthreads(); }
+inline void raw_barrier() { __syncthreads(); }
 
 template <typename V8>
 inline f32x16 emu_mfma32(V8 a, V8 b, f32x16 c) {
@@ -199,6 +236,14 @@ inline void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
     }
 }
 
+inline void ds_read_tr16_gather4(const void* base, const int (&off)[4], int imm, u32x4* out) {
+    for (int i = 0; i < 4; ++i) {
+        const u32x2 lo = ds_read_tr16_b64((const char*)base + imm + off[i]);
+        const u32x2 hi = ds_read_tr16_b64((const char*)base + imm + off[i] + 2048);
+        out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+
 template <typename S>
 inline S emu_shfl_idx(S v, int src) {
     S* s = (S*)hipemu::wave_buf();
@@ -217,6 +262,8 @@ inline void setprio_lo() {}
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fexp(float x) { return expf(x); }
+inline float mul_rn(float a, float b) { return a * b; }
+inline float sub_rn(float a, float b) { return a - b; }
 
 #define LMI_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipemu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })

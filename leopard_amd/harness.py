@@ -1,0 +1,160 @@
+"""Evaluation-harness counterpart of the reference's ``run_llava_local_inference``
+(evaluations/models/llava_multiimg_siglip_anyres.py:364-500, "EVAL"), as separable functions.
+
+The reference harness is one inline loop; its Python never travels to the GPU box, so this module reproduces,
+for the same input record ``{images_path, question, answers, ques_type, options}`` + setting:
+  (i)   the exact prompt string                                  EVAL:408-442
+  (ii)  the ViT-input order and count                            EVAL:386-405
+  (iii) the generate() keyword arguments                         EVAL:448-452
+  (iv)  the result-row schema and the shard file name            EVAL:480-484, 496-497
+including the published script's quirks.  It is pinned against a capture of the reference harness
+itself (tests/golden/harness_capture.json, produced by oracle/gen_golden.py with mocked loaders).
+
+Scoring (eval_utils.py parse_*/eval_*) is CPU string processing outside the hot path: a ``scorer`` callable is
+injected; when none is given the row carries the raw response only.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+from .tiler import SAMPLE_BUDGET, TILE, cut_tiles, choose_canvas, letterbox, plan_tile_budget
+
+HEAD = "<|begin_of_text|><|start_header_id|>user<|end_header_id|>\n\n"        # EVAL:22
+TAIL = "<|eot_id|><|start_header_id|>assistant<|end_header_id|>\n\n"           # EVAL:23
+IMAGE_TAG = "<image>"
+TOK_OPEN, TOK_IMG, TOK_CLOSE = "<|reserved_special_token_20|>", "<|reserved_special_token_195|>", "<|reserved_special_token_21|>"
+EOS_IDS = [128001, 128009]                                                     # EVAL:450
+MAX_NEW_TOKENS = 128                                                           # EVAL:452
+MAX_PROMPT_TOKENS = 16384                                                      # EVAL:443
+
+
+def get_instruction(setting: str, ques_type: str) -> str:
+    """evaluations/models/eval_utils.py:104-119."""
+    table = {
+        True: {"cot": "First think step by step. Then answer with the letter of the correct option.",
+               "direct": "Answer with the option's letter from the given choices directly.", "none": ""},
+        False: {"cot": "First think step by step. Then answer with a single word or phrase.",
+                "direct": "Answer the question using a single word or phrase.", "none": ""},
+    }
+    return table[ques_type == "multiple-choice"][setting]
+
+
+def split_shard(rows: list, shard: int, num_shards: int) -> list:
+    """evaluations/models/eval_utils.py:84-89 (contiguous slices of len//num_shards + 1)."""
+    size = len(rows) // num_shards + 1
+    return rows[shard * size:(shard + 1) * size]
+
+
+def keep_first_image_tags(text: str, n: int) -> str:
+    """eval_utils.retain_n_images (:122-146): keep the first n ``<image>`` tags, drop the rest."""
+    seen = 0
+
+    def repl(m):
+        nonlocal seen
+        seen += 1
+        return m.group(0) if seen <= n else ""
+    return re.sub(re.escape(IMAGE_TAG), repl, text)
+
+
+@dataclass
+class PreparedSample:
+    prompt: str
+    question: str                 # the (possibly tag-patched) question stored in the result row
+    vit_inputs: list              # PIL images in ViT order: per image [original] + tiles
+    tiles_per_image: List[int]    # what the prompt builder believes (EVAL "num_patchs_per_images_real")
+    n_image_tokens: int
+
+
+def tile_images(images: Sequence) -> (list, List[int]):
+    """EVAL:386-401."""
+    budget = SAMPLE_BUDGET - len(images)
+    if budget <= 0:
+        return list(images), [1] * len(images)              # sic (EVAL:400-401)
+    allowance = plan_tile_budget([im.size for im in images], TILE, budget)
+    vit_inputs, real = [], []
+    for im, n in zip(images, allowance):
+        canvas = choose_canvas(im.size, n, TILE)
+        tiles = cut_tiles(letterbox(im, canvas), TILE) if canvas is not None else []
+        real.append(len(tiles))
+        vit_inputs.append(im)
+        vit_inputs.extend(tiles)
+    return vit_inputs, real
+
+
+def build_prompt(question: str, n_images: int, tiles_per_image: List[int], setting: str, ques_type: str):
+    """EVAL:408-442, quirks included: the tag count is taken BEFORE missing tags are prepended and is what
+    drives the number of image-token groups; more tags than images indexes past the tile list (IndexError,
+    exactly as the reference does)."""
+    instruction = get_instruction(setting, ques_type)
+    tag_count = question.count(IMAGE_TAG)
+    if tag_count < n_images:
+        question = f"{IMAGE_TAG * (n_images - tag_count)} {question}"
+    elif tag_count > n_images:
+        question = keep_first_image_tags(question, tag_count - n_images)         # sic (EVAL:418-419)
+    prompt = f"{HEAD}{question}\n{instruction}{TAIL}"
+    groups = []
+    for k in range(tag_count):
+        per_image = 1
+        if tiles_per_image:
+            per_image += tiles_per_image[k]                                      # IndexError if k >= len (reference too)
+        groups.append(f"image {k + 1}: {TOK_OPEN}{TOK_IMG * per_image}{TOK_CLOSE}")
+    for gtxt in groups:
+        prompt = prompt.replace(IMAGE_TAG, gtxt, 1)
+    prompt = prompt.replace("\r\n\t\t\r\n\t\t", " ")                             # EVAL:442
+    return prompt, question, sum(g.count(TOK_IMG) for g in groups)
+
+
+def prepare_sample(record: dict, setting: str, open_image: Optional[Callable] = None) -> PreparedSample:
+    from PIL import Image
+    opener = open_image or (lambda p: Image.open(p).convert("RGB"))
+    images = [opener(p) for p in record["images_path"]]
+    vit_inputs, real = tile_images(images)
+    prompt, question, n_tok = build_prompt(record["question"], len(images), real, setting, record["ques_type"])
+    return PreparedSample(prompt, question, vit_inputs, real, n_tok)
+
+
+def generate_kwargs(pad_token_id) -> dict:
+    """EVAL:448-452."""
+    return {"pad_token_id": pad_token_id, "eos_token_id": list(EOS_IDS), "max_new_tokens": MAX_NEW_TOKENS, "use_cache": True}
+
+
+def result_row(record: dict, question: str, response: str, n_vit_inputs: int, scorer: Optional[Callable] = None) -> dict:
+    """EVAL:456-484.  ``multi_img`` follows the reference: it tests the ViT-input list (thumbnails + tiles)."""
+    correct, chosen, anls = None, response, 0
+    if scorer is not None:
+        correct, chosen, anls = scorer(record, response)
+    return {"correct": correct, "chosen": chosen, "gold": record["answers"], "raw": response, "question": question,
+            "image_type": record.get("image_type", None), "multi_img": n_vit_inputs > 1, "correct_anls": anls}
+
+
+def shard_result_path(checkpoint: str, shard: int, setting: str, dataset: str) -> str:
+    return os.path.join(checkpoint, f"{shard}_{setting}_{dataset}_shard_details.jsonl")      # EVAL:496-497
+
+
+def run_inference(records: List[dict], model, tokenizer, setting: str = "direct", scorer: Optional[Callable] = None,
+                  device=None) -> List[dict]:
+    """The hot loop (EVAL:381-487) over already-sharded records, batch 1, greedy."""
+    import torch
+    from .tiler import siglip_preprocess
+    rows = []
+    for rec in records:
+        s = prepare_sample(rec, setting)
+        pixel_values = torch.from_numpy(siglip_preprocess(s.vit_inputs))
+        enc = tokenizer([s.prompt], return_tensors="pt", truncation=True, max_length=MAX_PROMPT_TOKENS)["input_ids"]
+        attn = enc != tokenizer.pad_token_id
+        dev = device if device is not None else model.device
+        out = model.generate(enc.to(dev), pixel_values=pixel_values.to(dev), attention_mask=attn.to(dev),
+                             **generate_kwargs(tokenizer.pad_token_id))
+        response = tokenizer.batch_decode(out[:, enc.shape[1]:], skip_special_tokens=True)[0]
+        rows.append(result_row(rec, s.question, response, len(s.vit_inputs), scorer))
+    return rows
+
+
+def write_jsonl(path: str, rows: List[dict]) -> None:
+    with open(path, "w") as f:
+        for r in rows:
+            f.write(json.dumps(r) + "\n")

@@ -39,6 +39,9 @@ class Ops:
         if rc != 0:
             raise RuntimeError(f"libleopard_amd error {rc}: {self.lib.lmi_last_error().decode()}")
 
+    def set_option(self, key: str, value: int):
+        self._check(self.lib.lmi_set_option(key.encode(), int(value)))
+
     # ------------------------------------------------------------------------------------------
     def fill_synthetic(self, out: torch.Tensor, seed: int, kind: int):
         assert out.is_contiguous()

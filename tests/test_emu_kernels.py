@@ -115,6 +115,35 @@ def test_gemm_pixel_shuffle_gather(ops, dtype):
     assert (out.float() - ref).abs().max() <= tol(dtype) * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+def test_gemm_every_tile_geometry(ops, cfg):
+    """All GemmCfg geometries (128x128 .. 256x256, 2- and 3-slot LDS rings) on ragged M, an N that is not a multiple
+    of the tile width, and enough k-tiles to wrap the ring several times."""
+    dtype = torch.float16
+    ops.set_option("gemm.config", cfg)
+    try:
+        M, N, K = 300, 384, 448
+        a, w = rnd((M, K), dtype, 70 + cfg), rnd((N, K), dtype, 80 + cfg, 0.1)
+        bias = rnd((N,), torch.float32, 90)
+        out = torch.full((M, N), float("nan"), dtype=dtype)
+        ops.gemm(a, w, out, bias=bias)
+        ref = a.float() @ w.float().T + bias
+        assert (out.float() - ref).abs().max() <= tol(dtype) * max(1.0, ref.abs().max().item())
+        F = 192
+        gate, up = rnd((F, K), dtype, 11, 0.2), rnd((F, K), dtype, 12, 0.2)
+        wi = torch.stack([gate.view(F // 32, 32, K), up.view(F // 32, 32, K)], dim=1).reshape(2 * F, K).contiguous()
+        o2 = torch.full((M, F), float("nan"), dtype=dtype)
+        ops.gemm(a, wi, o2, epilogue=_lib.EPI_SWIGLU)
+        r2 = torch.nn.functional.silu(a.float() @ gate.float().T) * (a.float() @ up.float().T)
+        assert (o2.float() - r2).abs().max() <= tol(dtype) * max(1.0, r2.abs().max().item())
+        x = rnd((M, N), torch.float32, 7)
+        x0 = x.clone()
+        ops.gemm(a, w, x, bias=bias, epilogue=_lib.EPI_RESIDUAL)
+        assert (x - (x0 + ref)).abs().max() <= 2e-4
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
 def test_gemm_rejects_bad_shapes(ops):
     a, w, out = torch.zeros(8, 64, dtype=torch.float16), torch.zeros(100, 64, dtype=torch.float16), torch.zeros(8, 100, dtype=torch.float16)
     with pytest.raises(RuntimeError, match="128"):
