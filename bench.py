@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16"])
     ap.add_argument("--images", type=int, default=6)
     ap.add_argument("--width", type=int, default=1344)
     ap.add_argument("--height", type=int, default=896)

@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// attn_fwd_dma_kernel — head_dim 128 production variant.  Same register-level design as attn_fwd_kernel, but K and V
+// attn_fwd_dma_kernel — production variant (head_dim 128 and 72).  Same register-level design as attn_fwd_kernel, but K and V
 // tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 2-slot ring: no staging VGPRs, no ds_write
 // pass, one counted wait + one raw barrier per 64-key tile, and the register budget fits 2 waves per SIMD so a
 // second workgroup's MFMAs run under this one's softmax.  LDS-DMA writes lane-linearly, so the LDS images are
@@ -261,12 +261,23 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
 //   V: 16-byte chunk c of row r at c ^ ((r & 3) << 2)    -> the 4 key rows of one transpose read use 4 distinct
 //                                                            64-byte bank groups
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int ATTD_TILE_BYTES = ATT_BKV * 256;                 // one K or V tile image
-constexpr int ATTD_SMEM = 4 * ATTD_TILE_BYTES;                 // 2 slots x (K + V) = 64 KiB
+template <int D> struct AttnDmaGeom {
+    static constexpr int ROWB = D * 2;                        // bytes per K/V row in LDS (unpadded: LDS-DMA is lane-linear)
+    static constexpr int CH = D / 8;                          // 16-byte chunks per row
+    static constexpr int NKS = (D + 15) / 16;                 // 16-deep QK^T steps (Q zero-padded past D)
+    static constexpr int NDB = (D + 31) / 32;                 // 32-row blocks of O^T
+    static constexpr int TILE_BYTES = ATT_BKV * ROWB;         // one K or V tile image
+    static constexpr int PIECES = TILE_BYTES / 1024;          // 1-KiB LDS-DMA wave pieces per image
+    static constexpr int PPW = (PIECES + 3) / 4;              // pieces per wave (4 waves)
+    static constexpr int SMEM = 4 * TILE_BYTES + 64;          // 2 slots x (K + V) (+ slack read by padded columns)
+    static constexpr bool SWZ = (D == 128);                   // XOR swizzles need power-of-two rows; 144-byte rows
+                                                              // (9 chunks, odd) are conflict-free for b128 as they are
+};
 
-template <typename T, bool CAUSAL>
+template <typename T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p) {
-    constexpr int D = 128, NKS = 8, NDB = 4;
+    typedef AttnDmaGeom<D> G;
+    constexpr int NKS = G::NKS, NDB = G::NDB;
     typedef typename vec_of<T>::x8 T8;
     typedef typename vec_of<T>::x4 T4;
     LMI_DYN_SMEM(smem);
@@ -289,21 +300,37 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     const T* q_row = (const T*)p.q + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldq + head * D;
     T8 qf[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const T8*)(q_row + (2 * ks + fh) * 8);
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int c = 2 * ks + fh;
+        if (c < G::CH) qf[ks] = *(const T8*)(q_row + c * 8);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (T)0.0f;
+        }
+    }
 
-    // ---- LDS-DMA sources: piece i covers rows i*16 .. i*16+15; this lane owns (row, physical chunk) -------------
+    // ---- LDS-DMA sources: wave w owns pieces w, w+4, ...; lane l of piece q is chunk q*64+l of the tile image ------
     const T* k_base = (const T*)p.k + (long)k_beg * p.ldk + kvh * D;
     const T* v_base = (const T*)p.v + (long)k_beg * p.ldv + kvh * D;
-    const int prow = tid >> 4, pchunk = tid & 15;
-    auto issue_tile = [&](int t, int slot) {
-        char* kdst = smem + slot * 2 * ATTD_TILE_BYTES + wave * 1024;
-        char* vdst = kdst + ATTD_TILE_BYTES;
+    int p_row[G::PPW], p_kc[G::PPW], p_vc[G::PPW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = i * 16 + prow;
-            const int key = imin(t * ATT_BKV + r, len_k - 1);
-            glds16(k_base + (long)key * p.ldk + ((pchunk ^ (r & 15)) << 3), kdst + i * 4096);
-            glds16(v_base + (long)key * p.ldv + ((pchunk ^ ((r & 3) << 2)) << 3), vdst + i * 4096);
+    for (int i = 0; i < G::PPW; ++i) {
+        const int ci = (wave + 4 * i) * 64 + lane;
+        const int r = ci / G::CH, c = ci - r * G::CH;
+        p_row[i] = r;
+        p_kc[i] = G::SWZ ? (c ^ (r & 15)) : c;
+        p_vc[i] = G::SWZ ? (c ^ ((r & 3) << 2)) : c;
+    }
+    auto issue_tile = [&](int t, int slot) {
+        char* kdst = smem + slot * 2 * G::TILE_BYTES;
+        char* vdst = kdst + G::TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            if (wave + 4 * i < G::PIECES) {                       // wave-uniform
+                const int key = imin(t * ATT_BKV + p_row[i], len_k - 1);
+                glds16(k_base + (long)key * p.ldk + (p_kc[i] << 3), kdst + (wave + 4 * i) * 1024);
+                glds16(v_base + (long)key * p.ldv + (p_vc[i] << 3), vdst + (wave + 4 * i) * 1024);
+            }
         }
     };
 
@@ -317,11 +344,12 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     const int wave_q_lo = q0 + wave * 32, wave_q_hi = wave_q_lo + 31;
 
     // transpose-read lane geometry: lane i = 4j+g of a 16-lane group addresses key row j, 8-byte column group g;
-    // for d-block db the 64-byte granule is db ^ j (V swizzle), constant per lane
+    // with the V swizzle the 64-byte granule of d-block db is db ^ j (constant per lane)
     const int tr_j = (lane & 15) >> 2, tr_g = lane & 3, tr_half = (lane >> 4) & 1;
     int v_off[NDB];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) v_off[db] = (4 * fh + tr_j) * 256 + ((db ^ tr_j) << 6) + tr_half * 32 + tr_g * 8;
+    for (int db = 0; db < NDB; ++db)
+        v_off[db] = (4 * fh + tr_j) * G::ROWB + ((G::SWZ ? (db ^ tr_j) : db) << 6) + tr_half * 32 + tr_g * 8;
 
     issue_tile(0, 0);
     for (int t = 0; t < n_tiles; ++t) {
@@ -329,8 +357,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         if (t + 1 < n_tiles) issue_tile(t + 1, (t + 1) & 1);
         const int kv0 = t * ATT_BKV;
         if (CAUSAL && kv0 > wave_q_hi + shift) continue;
-        const char* k_lds = smem + (t & 1) * 2 * ATTD_TILE_BYTES;
-        const char* v_lds = k_lds + ATTD_TILE_BYTES;
+        const char* k_lds = smem + (t & 1) * 2 * G::TILE_BYTES;
+        const char* v_lds = k_lds + G::TILE_BYTES;
 
         f32x16 s[2];
 #pragma unroll
@@ -340,7 +368,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
             const int row = b * 32 + fr;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const T8 kf = *(const T8*)(k_lds + row * 256 + (((2 * ks + fh) ^ (row & 15)) << 4));
+                const int c = 2 * ks + fh;
+                const T8 kf = *(const T8*)(k_lds + row * G::ROWB + ((G::SWZ ? (c ^ (row & 15)) : c) << 4));
                 s[b] = mfma32(kf, qf[ks], s[b]);
             }
         }
@@ -388,7 +417,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 u32x4 vraw[NDB];
-                ds_read_tr16_gather4(v_lds, v_off, (b * 32 + 16 * u) * 256, vraw);
+                ds_read_tr16_gather<NDB, 8 * G::ROWB>(v_lds, v_off, (b * 32 + 16 * u) * G::ROWB, vraw);
 #pragma unroll
                 for (int db = 0; db < NDB; ++db)
                     o_acc[db] = mfma32(__builtin_bit_cast(T8, vraw[db]), pf[b][u], o_acc[db]);
@@ -403,10 +432,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                T4 o;
+                const int d = db * 32 + 8 * qd + 4 * fh;
+                if (d < D) {
+                    T4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)(o_acc[db][qd * 4 + e] * inv);
-                *(T4*)(o_row + db * 32 + 8 * qd + 4 * fh) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = (T)(o_acc[db][qd * 4 + e] * inv);
+                    *(T4*)(o_row + d) = o;
+                }
             }
     }
 }

@@ -54,8 +54,9 @@ typedef GemmCfg<256, 256, 2, 4, 2> Cfg1;   // 128 KiB LDS, 512 threads, wave til
 typedef GemmCfg<256, 128, 4, 2, 3> Cfg2;   // 144 KiB LDS, 512 threads, wave tile 64x64, 3-slot ring
 typedef GemmCfg<256, 128, 4, 2, 2> Cfg3;   //  96 KiB LDS
 typedef GemmCfg<128, 256, 2, 4, 3> Cfg4;   // 144 KiB LDS, wave tile 64x64, 3-slot ring
-constexpr int kNumGemmCfg = 6;              // 5 = Cfg1 geometry on the staggered two-group schedule
+constexpr int kNumGemmCfg = 11;              // 5 = Cfg1 geometry on the staggered two-group schedule; 6 = staggered k-half phases
 int g_gemm_cfg = -1;                        // -1 = choose per shape
+int g_gemm_group_m = GEMM_GROUP_M;
 
 template <typename T, int EPI, int ACT, int AMODE, typename C>
 int launch_gemm_cfg(const GemmArgs& a, void* stream) {
@@ -66,21 +67,30 @@ int launch_gemm_cfg(const GemmArgs& a, void* stream) {
     return check_launch("lmi_gemm");
 }
 
-template <typename T, int EPI, int ACT, int AMODE, typename C>
+template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR>
 int launch_gemm_stagger(const GemmArgs& a, void* stream) {
     const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
     static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C>, C::SMEM); attr_set = true; }
-    LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
+    if (!attr_set) { allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>, C::SMEM); attr_set = true; }
+    LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
     return check_launch("lmi_gemm");
 }
 
 // Geometry per shape, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_geometries.md): wide outputs take the
 // staggered 256x256 schedule; narrow-N / deep-K (SigLIP fc2) the 256x128 3-slot ring; small problems 128x128.
+template <typename T, int EPI, int ACT, int AMODE>
+int launch_gemm_stagger2(const GemmArgs& a, void* stream) {
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    static bool attr_set = false;
+    if (!attr_set) { allow_big_lds(gemm_stagger2_kernel<T, EPI, ACT, AMODE>, 131072); attr_set = true; }
+    LMI_LAUNCH((gemm_stagger2_kernel<T, EPI, ACT, AMODE>), dim3(tiles), dim3(512), 131072, stream, a);
+    return check_launch("lmi_gemm");
+}
+
 int choose_gemm_cfg(const GemmArgs& a) {
     if (g_gemm_cfg >= 0) return g_gemm_cfg;
     if (a.M < 512) return 0;
-    if (a.N >= 2048) return 5;
+    if (a.N >= 2048) return 9;
     if (a.K >= 2048) return 2;
     return 0;
 }
@@ -92,7 +102,12 @@ int launch_gemm(const GemmArgs& a, void* stream) {
         case 2: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg2>(a, stream);
         case 3: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg3>(a, stream);
         case 4: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg4>(a, stream);
-        case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1>(a, stream);
+        case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 0>(a, stream);
+        case 7: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 1>(a, stream);
+        case 8: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 2>(a, stream);
+        case 9: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 3>(a, stream);
+        case 10: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 4>(a, stream);
+        case 6: return launch_gemm_stagger2<T, EPI, ACT, AMODE>(a, stream);
         default: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg0>(a, stream);
     }
 }
@@ -132,21 +147,22 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
                AttnGeom<D>::SMEM, stream, a);
     return check_launch("lmi_attn_varlen_fwd");
 }
-int g_attn_dma = 1;                          // head_dim 128: 1 = LDS-DMA kernel, 0 = register-staged kernel
+int g_attn_dma = 1;                          // 1 = LDS-DMA kernel (production), 0 = register-staged kernel
 
-template <typename T, bool CAUSAL>
+template <typename T, int D, bool CAUSAL>
 int launch_attn_dma(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     const int qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
     static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(attn_fwd_dma_kernel<T, CAUSAL>, ATTD_SMEM); attr_set = true; }
-    LMI_LAUNCH((attn_fwd_dma_kernel<T, CAUSAL>), dim3(qblocks, a.n_heads, n_seq), dim3(ATT_THREADS), ATTD_SMEM, stream, a);
+    if (!attr_set) { allow_big_lds(attn_fwd_dma_kernel<T, D, CAUSAL>, AttnDmaGeom<D>::SMEM); attr_set = true; }
+    LMI_LAUNCH((attn_fwd_dma_kernel<T, D, CAUSAL>), dim3(qblocks, a.n_heads, n_seq), dim3(ATT_THREADS),
+               AttnDmaGeom<D>::SMEM, stream, a);
     return check_launch("lmi_attn_varlen_fwd");
 }
 
 template <typename T, int D>
 int dispatch_attn(const AttnArgs& a, int n_seq, int max_q, int causal, int use_tr, void* stream) {
-    if (D == 128 && use_tr && g_attn_dma)
-        return causal ? launch_attn_dma<T, true>(a, n_seq, max_q, stream) : launch_attn_dma<T, false>(a, n_seq, max_q, stream);
+    if (use_tr && g_attn_dma)
+        return causal ? launch_attn_dma<T, D, true>(a, n_seq, max_q, stream) : launch_attn_dma<T, D, false>(a, n_seq, max_q, stream);
     if (causal) return use_tr ? launch_attn<T, D, true, true>(a, n_seq, max_q, stream)
                               : launch_attn<T, D, true, false>(a, n_seq, max_q, stream);
     return use_tr ? launch_attn<T, D, false, true>(a, n_seq, max_q, stream)
@@ -228,6 +244,11 @@ int lmi_set_option(const char* key, int value) {
         g_gemm_cfg = value;
         return LMI_OK;
     }
+    if (!strcmp(key, "gemm.group_m")) {
+        if (value < 1 || value > 64) return fail(LMI_EINVAL, "lmi_set_option: gemm.group_m in [1, 64]");
+        g_gemm_group_m = value;
+        return LMI_OK;
+    }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
     return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);
 }
@@ -285,7 +306,7 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
     if (M == 0) return LMI_OK;
     GemmArgs a;
     a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.row_map = row_map;
-    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m;
     LMI_DISPATCH_T(dtype, dispatch_gemm<f16_t>(a, epilogue, act, a_mode, stream),
                    dispatch_gemm<bf16_t>(a, epilogue, act, a_mode, stream));
 }

@@ -118,29 +118,46 @@ LMI_DEV void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
     out[2] = u32x4{a2[0], a2[1], b2[0], b2[1]};
 }
 
-// Attention V operand: 8 transpose reads (4 d-blocks x {keys +0..3, keys +8..11}) from per-lane addresses
-// base + off[db] + imm, one wait.  out[db] = {lo.x, lo.y, hi.x, hi.y}.  `imm` selects the 16-key step.
-LMI_DEV void ds_read_tr16_gather4(const void* base, const int (&off)[4], int imm, u32x4* out) {
+// Attention V operand: 2*N transpose reads (N d-blocks x {keys +0..3, keys +8..11}) from per-lane addresses
+// base + imm + off[db] (+ HI for the second key group), one wait.  out[db] = {lo.x, lo.y, hi.x, hi.y}.
+template <int N, int HI>
+LMI_DEV void ds_read_tr16_gather(const void* base, const int (&off)[N], int imm, u32x4* out) {
+    static_assert(N == 3 || N == 4, "d-block count");
     const unsigned b = (unsigned)(size_t)base + (unsigned)imm;
-    const unsigned a0 = b + off[0], a1 = b + off[1], a2 = b + off[2], a3 = b + off[3];
     u32x2 l0, l1, l2, l3, h0, h1, h2, h3;
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %8\n\t"
-        "ds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
-        "ds_read_b64_tr_b16 %2, %9\n\t"
-        "ds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
-        "ds_read_b64_tr_b16 %4, %10\n\t"
-        "ds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
-        "ds_read_b64_tr_b16 %6, %11\n\t"
-        "ds_read_b64_tr_b16 %7, %11 offset:2048\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
-        : "memory");
+    if constexpr (N == 4) {
+        const unsigned a0 = b + off[0], a1 = b + off[1], a2 = b + off[2], a3 = b + off[3];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\t"
+            "ds_read_b64_tr_b16 %1, %8 offset:%c12\n\t"
+            "ds_read_b64_tr_b16 %2, %9\n\t"
+            "ds_read_b64_tr_b16 %3, %9 offset:%c12\n\t"
+            "ds_read_b64_tr_b16 %4, %10\n\t"
+            "ds_read_b64_tr_b16 %5, %10 offset:%c12\n\t"
+            "ds_read_b64_tr_b16 %6, %11\n\t"
+            "ds_read_b64_tr_b16 %7, %11 offset:%c12\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "i"(HI)
+            : "memory");
+        out[3] = u32x4{l3[0], l3[1], h3[0], h3[1]};
+    } else {
+        const unsigned a0 = b + off[0], a1 = b + off[1], a2 = b + off[2];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %6\n\t"
+            "ds_read_b64_tr_b16 %1, %6 offset:%c9\n\t"
+            "ds_read_b64_tr_b16 %2, %7\n\t"
+            "ds_read_b64_tr_b16 %3, %7 offset:%c9\n\t"
+            "ds_read_b64_tr_b16 %4, %8\n\t"
+            "ds_read_b64_tr_b16 %5, %8 offset:%c9\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2)
+            : "v"(a0), "v"(a1), "v"(a2), "i"(HI)
+            : "memory");
+    }
     out[0] = u32x4{l0[0], l0[1], h0[0], h0[1]};
     out[1] = u32x4{l1[0], l1[1], h1[0], h1[1]};
     out[2] = u32x4{l2[0], l2[1], h2[0], h2[1]};
-    out[3] = u32x4{l3[0], l3[1], h3[0], h3[1]};
 }
 
 LMI_DEV float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
@@ -152,8 +169,10 @@ LMI_DEV void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 LMI_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 LMI_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 LMI_DEV float fexp(float x) { return __expf(x); }
-LMI_DEV float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-LMI_DEV float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+// individually rounded fp32 multiply / subtract: the empty asm makes the result opaque so that hipcc cannot contract
+// it into an FMA with a neighbouring operation (HIP's __fmul_rn is a plain `*` and does get contracted)
+LMI_DEV float mul_rn(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }
+LMI_DEV float sub_rn(float a, float b) { float r = a - b; asm volatile("" : "+v"(r)); return r; }
 
 #define LMI_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
@@ -236,10 +255,11 @@ inline void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
     }
 }
 
-inline void ds_read_tr16_gather4(const void* base, const int (&off)[4], int imm, u32x4* out) {
-    for (int i = 0; i < 4; ++i) {
+template <int N, int HI>
+inline void ds_read_tr16_gather(const void* base, const int (&off)[N], int imm, u32x4* out) {
+    for (int i = 0; i < N; ++i) {
         const u32x2 lo = ds_read_tr16_b64((const char*)base + imm + off[i]);
-        const u32x2 hi = ds_read_tr16_b64((const char*)base + imm + off[i] + 2048);
+        const u32x2 hi = ds_read_tr16_b64((const char*)base + imm + off[i] + HI);
         out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
     }
 }

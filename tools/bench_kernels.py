@@ -45,7 +45,10 @@ def bench_gemm(args):
     g = torch.Generator(device="cpu").manual_seed(0)
     print(f"{'shape':22s} {'M':>6s} {'N':>6s} {'K':>6s} | " + " | ".join(f"cfg{c}: ms  TF/s  err" for c in cfgs))
     total = {c: 0.0 for c in cfgs}
-    for name, M, N, K, epi, act in GEMM_SHAPES:
+    if args.group_m:
+        ops.set_option("gemm.group_m", args.group_m)
+    shapes = GEMM_SHAPES if args.only < 0 else [GEMM_SHAPES[args.only]]
+    for name, M, N, K, epi, act in shapes:
         a = (torch.randn(M, K, generator=g)).to(dtype).to(DEV)
         w = (torch.randn(N, K, generator=g) * 0.02).to(dtype).to(DEV)
         n_out = N // 2 if epi == _lib.EPI_SWIGLU else N
@@ -113,5 +116,7 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--group-m", type=int, default=0)
+    ap.add_argument("--only", type=int, default=-1, help="index of a single GEMM shape")
     a = ap.parse_args()
     bench_gemm(a) if a.what == "gemm" else bench_attn(a)
