@@ -152,10 +152,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    from leopard_amd import dist as D
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        D.init(backend="nccl", device=dev)            # RCCL over xGMI; used for barrier / max-over-ranks only
 
     from leopard_amd.engine import KVCache, LeopardEngine
     from leopard_amd.ops import Ops
@@ -183,8 +182,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -195,10 +193,7 @@ def main():
         res = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = D.max_over_ranks(elapsed, dev)
     assert res.seq_len == S and torch.isfinite(res.logits_last).all()
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = world * args.images * args.steps / elapsed
@@ -242,7 +237,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        import torch.distributed as dist
+        D.barrier()
         dist.destroy_process_group()
 
 

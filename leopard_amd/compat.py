@@ -1,0 +1,112 @@
+"""The model object the reference's evaluation script drives (evaluations/models/llava_multiimg_siglip_anyres.py,
+"EVAL"), backed by the HIP engine.
+
+EVAL:373-375   llava = myLlavaForConditionalGeneration.from_pretrained(ckpt, torch_dtype=torch.float32); .eval(); .to('cuda:0')
+EVAL:405,445   images.to(llava.device), input_ids.to(llava.device)
+EVAL:448-452   llava.generate(input_ids, pixel_values=, attention_mask=, pad_token_id=, eos_token_id=[128001,128009],
+                              max_new_tokens=128, use_cache=True) -> LongTensor [1, S_in + T]
+EVAL:201-361   forward(input_ids=, pixel_values=, attention_mask=, ..., return_dict=) -> .logits [1,S,V], .past_key_values
+
+``LeopardForConditionalGeneration`` honours exactly that surface (same argument names, same return shapes/devices,
+ValueError on an image-token / feature-count mismatch as transformers 4.38's merge raises).  ``torch_dtype`` is the
+dtype the caller's tensors use (fp32 in EVAL); the MFMA compute type is ``compute_dtype`` (fp16 by default: closest to
+the reference's fp32 results at the full matrix-core rate).  Batch is 1 per call, like the reference.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .checkpoint import CheckpointSource, load_config
+from .config import LeopardConfig
+from .engine import KVCache, LeopardEngine
+from .ops import Ops
+from .weights import EngineWeights
+
+
+@dataclass
+class LlavaCausalLMOutputWithPast:
+    """Field-compatible with transformers.models.llava.modeling_llava.LlavaCausalLMOutputWithPast (EVAL:355-361)."""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[object] = None
+    hidden_states: Optional[Tuple] = None
+    attentions: Optional[Tuple] = None
+
+    def __getitem__(self, i):
+        return [v for v in (self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions)
+                if v is not None][i]
+
+
+class LeopardForConditionalGeneration:
+    def __init__(self, config: LeopardConfig, source_factory, compute_dtype=torch.float16, ops: Optional[Ops] = None):
+        self.config = config
+        self._source_factory = source_factory            # (device, dtype) -> parameter source with .get(name)
+        self.compute_dtype = compute_dtype
+        self._ops = ops
+        self._engine: Optional[LeopardEngine] = None
+        self.device = torch.device("cpu")
+
+    # ---- loading ---------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=torch.float32, compute_dtype=torch.float16, ops: Optional[Ops] = None):
+        cfg = load_config(path)
+        return cls(cfg, lambda dev, dt: CheckpointSource(path, dev, dt), compute_dtype, ops)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if self._engine is None or device != self.device:
+            ops = self._ops if self._ops is not None else Ops()
+            W = EngineWeights.build(self.config, self._source_factory(device, self.compute_dtype), self.compute_dtype)
+            self._engine = LeopardEngine(self.config, W, ops=ops, device=device)
+            self.device = device
+        return self
+
+    @property
+    def engine(self) -> LeopardEngine:
+        if self._engine is None:
+            raise RuntimeError("call .to(device) first (the HIP engine is built on the target device)")
+        return self._engine
+
+    # ---- EVAL:201-361 ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, vision_feature_layer=None, vision_feature_select_strategy=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+        if inputs_embeds is not None or labels is not None or output_attentions or output_hidden_states:
+            raise NotImplementedError("inference surface only: input_ids (+ pixel_values), no labels / attentions")
+        if input_ids.shape[0] != 1:
+            raise NotImplementedError("batch 1 per call, as in the reference harness (EVAL:381-452)")
+        if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
+            raise NotImplementedError("padded prompts are not produced by the reference harness (batch 1)")
+        eng = self.engine
+        if past_key_values is not None and input_ids.shape[1] == 1:          # decode branch, EVAL:291-320
+            logits = eng.decode_step(int(input_ids[0, 0]), past_key_values)
+            return LlavaCausalLMOutputWithPast(logits=logits.view(1, 1, -1), past_key_values=past_key_values)
+        tiles = None if pixel_values is None else pixel_values.to(device=self.device, dtype=torch.float32).contiguous()
+        S = input_ids.shape[1] + int((input_ids == self.config.image_token_index).sum()) * (self.config.tokens_per_tile - 1)
+        cache = KVCache(self.config, S + 256, self.compute_dtype, self.device) if use_cache else None
+        res = eng.prefill(input_ids.to(self.device), tiles, cache=cache, all_logits=True)
+        return LlavaCausalLMOutputWithPast(logits=res.logits_all.unsqueeze(0), past_key_values=cache)
+
+    __call__ = forward
+
+    # ---- EVAL:448-452 ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids, pixel_values=None, attention_mask=None, pad_token_id=None, eos_token_id=None,
+                 max_new_tokens: int = 128, use_cache: bool = True, **unused):
+        if input_ids.shape[0] != 1:
+            raise NotImplementedError("batch 1 per call, as in the reference harness")
+        eos = eos_token_id if isinstance(eos_token_id, (list, tuple)) else ([] if eos_token_id is None else [eos_token_id])
+        tiles = None if pixel_values is None else pixel_values.to(device=self.device, dtype=torch.float32).contiguous()
+        return self.engine.generate(input_ids.to(self.device), tiles, max_new_tokens=max_new_tokens, eos_token_id=eos)
+
+
+def from_pretrained(path: str, torch_dtype=torch.float32, **kw) -> LeopardForConditionalGeneration:
+    """Drop-in for ``myLlavaForConditionalGeneration.from_pretrained``."""
+    return LeopardForConditionalGeneration.from_pretrained(path, torch_dtype=torch_dtype, **kw)

@@ -1,0 +1,85 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / gloo on CPU.
+
+How the path shards:
+  * by SAMPLE — the reference's own scheme (run_eval_llava_siglip_multiimg.sh:9-11 + eval_utils.split_shard): replicas,
+    no data-path collective.  ``shard_records`` is that split; bench.py uses ``barrier`` / ``max_over_ranks`` only.
+  * by ViT INPUT (tile) inside one sample: the 676-token tile sequences are independent through the tower and the
+    projector, so rank r encodes a contiguous, balanced slice of the tiles and ONE all-gather of the projected visual
+    tokens [N_r*169, 4096] restores the full, correctly ordered set on every rank (``encode_images_sharded``).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """Initialise the default process group from the torchrun environment.  Returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def barrier() -> None:
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_records(records: list, rank: int, world: int) -> list:
+    """eval_utils.split_shard (evaluations/models/eval_utils.py:84-89): contiguous slices of len//world + 1."""
+    size = len(records) // world + 1
+    return records[rank * size:(rank + 1) * size]
+
+
+def tile_slices(n_tiles: int, world: int) -> List[Tuple[int, int]]:
+    """Balanced contiguous tile ranges: the first n_tiles % world ranks take one extra tile."""
+    base, extra = divmod(n_tiles, world)
+    out, start = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+def encode_images_sharded(engine, tiles: torch.Tensor) -> torch.Tensor:
+    """Vision tower + projector with the tiles split across the ranks of the default group, then ONE all-gather of
+    the projected visual tokens.  Every rank returns the full fp32 [N*tokens_per_tile, D] tensor in tile order —
+    bit-identical to ``engine.encode_images(tiles)`` because tiles are independent sequences."""
+    world = world_size()
+    if world == 1:
+        return engine.encode_images(tiles)
+    rank = dist.get_rank()
+    slices = tile_slices(tiles.shape[0], world)
+    lo, hi = slices[rank]
+    tpt = engine.cfg.tokens_per_tile
+    D = engine.cfg.text_config.hidden_size
+    max_rows = max(b - a for a, b in slices) * tpt
+    mine = torch.zeros(max_rows, D, dtype=torch.float32, device=tiles.device)
+    if hi > lo:
+        mine[:(hi - lo) * tpt] = engine.encode_images(tiles[lo:hi].contiguous())
+    gathered = torch.empty(world * max_rows, D, dtype=torch.float32, device=tiles.device)
+    dist.all_gather_into_tensor(gathered, mine)                  # equal-size padded shards, one collective
+    parts = [gathered[r * max_rows:r * max_rows + (b - a) * tpt] for r, (a, b) in enumerate(slices)]
+    return torch.cat(parts, dim=0)
