@@ -54,7 +54,7 @@ typedef GemmCfg<256, 256, 2, 4, 2> Cfg1;   // 128 KiB LDS, 512 threads, wave til
 typedef GemmCfg<256, 128, 4, 2, 3> Cfg2;   // 144 KiB LDS, 512 threads, wave tile 64x64, 3-slot ring
 typedef GemmCfg<256, 128, 4, 2, 2> Cfg3;   //  96 KiB LDS
 typedef GemmCfg<128, 256, 2, 4, 3> Cfg4;   // 144 KiB LDS, wave tile 64x64, 3-slot ring
-constexpr int kNumGemmCfg = 11;              // 5 = Cfg1 geometry on the staggered two-group schedule; 6 = staggered k-half phases
+constexpr int kNumGemmCfg = 8;              // 0-4 ring geometries; 5-7 staggered 256x256 schedules
 int g_gemm_cfg = -1;                        // -1 = choose per shape
 int g_gemm_group_m = GEMM_GROUP_M;
 
@@ -78,19 +78,10 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
 
 // Geometry per shape, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_geometries.md): wide outputs take the
 // staggered 256x256 schedule; narrow-N / deep-K (SigLIP fc2) the 256x128 3-slot ring; small problems 128x128.
-template <typename T, int EPI, int ACT, int AMODE>
-int launch_gemm_stagger2(const GemmArgs& a, void* stream) {
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(gemm_stagger2_kernel<T, EPI, ACT, AMODE>, 131072); attr_set = true; }
-    LMI_LAUNCH((gemm_stagger2_kernel<T, EPI, ACT, AMODE>), dim3(tiles), dim3(512), 131072, stream, a);
-    return check_launch("lmi_gemm");
-}
-
 int choose_gemm_cfg(const GemmArgs& a) {
     if (g_gemm_cfg >= 0) return g_gemm_cfg;
     if (a.M < 512) return 0;
-    if (a.N >= 2048) return 9;
+    if (a.N >= 2048) return 7;
     if (a.K >= 2048) return 2;
     return 0;
 }
@@ -102,12 +93,9 @@ int launch_gemm(const GemmArgs& a, void* stream) {
         case 2: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg2>(a, stream);
         case 3: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg3>(a, stream);
         case 4: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg4>(a, stream);
-        case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 0>(a, stream);
-        case 7: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 1>(a, stream);
-        case 8: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 2>(a, stream);
-        case 9: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 3>(a, stream);
-        case 10: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 4>(a, stream);
-        case 6: return launch_gemm_stagger2<T, EPI, ACT, AMODE>(a, stream);
+        case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 0>(a, stream);   // setprio, DMA in LOAD segments
+        case 6: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 1>(a, stream);   // DMA in LOAD segments
+        case 7: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 2>(a, stream);   // DMA between MFMAs (production)
         default: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg0>(a, stream);
     }
 }

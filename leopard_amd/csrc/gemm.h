@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     LMI_DYN_SMEM(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = wave_id();
-    const int grp = wave >> 2;
+    const int grp = wave >> 2;                  // waves w and w+4 share a SIMD (measured: other pairings lose 20-25 %)
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = (p.N + C::BN - 1) / C::BN;
     int tm, tn;
@@ -363,170 +363,29 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
             for (int i = 0; i < C::MI; ++i) af[i] = *(const T8*)(a_t + gemm_lds_off(wm * C::WTM + i * 32 + fr, ks * 2 + fh));
 #pragma unroll
             for (int i = 0; i < C::NI; ++i) wf[i] = *(const T8*)(w_t + gemm_lds_off(wn * C::WTN + i * 32 + fr, ks * 2 + fh));
-            if (do_issue && VAR < 3) {
-                if (VAR == 1) {                                         // 3 / 3 / 2 / 0 pieces per k-step
-                    constexpr int lo[5] = {0, 3, 6, 8, 8};
+            if (VAR < 2 && ks < 2 && do_issue) {
 #pragma unroll
-                    for (int g = lo[ks]; g < lo[ks + 1]; ++g) issue_piece(g, t + 1, (t + 1) & 1);
-                } else if (ks < 2) {
-#pragma unroll
-                    for (int g = ks * C::G / 2; g < (ks + 1) * C::G / 2; ++g) issue_piece(g, t + 1, (t + 1) & 1);
-                }
+                for (int g = ks * C::G / 2; g < (ks + 1) * C::G / 2; ++g) issue_piece(g, t + 1, (t + 1) & 1);
             }
             if (ks == 3) wait_vmcnt_barrier<0>(); else raw_barrier();
             // ---- MFMA segment ---------------------------------------------------------------------------------
             sched_fence();
-            if (VAR == 0 || VAR == 1) setprio_hi();
-            if (VAR >= 3) {
-                // LDS-DMA pieces of tile t+1 ride in the issue slots between this segment's MFMAs
-                constexpr int lo4[5] = {0, 4, 8, 8, 8}, lo3[5] = {0, 3, 6, 8, 8};
-                const int g_lo = (VAR == 3) ? lo4[ks] : lo3[ks], g_hi = (VAR == 3) ? lo4[ks + 1] : lo3[ks + 1];
+            if (VAR == 0) setprio_hi();
 #pragma unroll
-                for (int ni = 0; ni < C::NI; ++ni)
+            for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < C::MI; ++mi) {
-                        acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
-                        const int idx = ni * C::MI + mi, g = g_lo + (idx >> 1);      // compile-time after unrolling
-                        if ((idx & 1) && g < g_hi && do_issue) issue_piece(g, t + 1, (t + 1) & 1);
-                    }
-            } else {
-#pragma unroll
-                for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < C::MI; ++mi) acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
-            }
-            if (VAR == 0 || VAR == 1) setprio_lo();
+                for (int mi = 0; mi < C::MI; ++mi) {
+                    acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
+                    // VAR 2: the LDS-DMA pieces of tile t+1 ride in the issue slots between the MFMAs of k-steps 0, 1
+                    const int idx = ni * C::MI + mi, g = ks * (C::G / 2) + (idx >> 1);    // compile-time after unrolling
+                    if (VAR == 2 && ks < 2 && (idx & 1) && (idx >> 1) < C::G / 2 && do_issue) issue_piece(g, t + 1, (t + 1) & 1);
+                }
+            if (VAR == 0) setprio_lo();
             sched_fence();
             raw_barrier();
         }
     }
     if (grp == 0) raw_barrier();                                   // balance the barrier count
-    gemm_epilogue<T, EPI, ACT, C>(p, acc, m0, n0, wm, wn, fr, fh);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Staggered schedule, k-half phases (the production schedule for wide outputs).  256x256 tile, 8 waves (2 x 4, wave
-// tile 128 x 64), 2-slot ring.  A k-tile is stored as two k-HALF images per operand ([256 rows][64 B] each), so the
-// unit of both synchronisation and prefetch is a half tile:
-//   phase (t, h):  LOAD  = 12 ds_read_b128 (fragments of both 16-deep steps of half h) + this wave's 4 LDS-DMA pieces
-//                          of half h of tile t+1, then `s_waitcnt vmcnt(4)` (everything but the 4 pieces just
-//                          issued has landed) + barrier;
-//                  MFMA  = 16 MFMAs at raised priority, + barrier.
-// Waves 4-7 run one barrier behind waves 0-3, so each SIMD always has one wave in an MFMA segment and its partner in
-// a LOAD segment.  Every half tile is issued three segments (~1.5k cycles) before its first reader, the wait is a
-// counted vmcnt(4) in steady state (never a drain), and LOAD (12 reads + 4 DMA) is about as long as MFMA (16 x 32
-// cycles).  64-byte rows are de-conflicted with chunk c of row r stored at c ^ ((r>>2)&3).
-// Hazards: half (t+1,h) overwrites half (t-1,h), last read by the lagging group in its LOAD(t-1,h), which closed two
-// barriers before any wave reaches LOAD(t,h); readers of (t+1,h) start after the barrier closing MFMA(t,h+1) /
-// LOAD(t+1,h-1), by which every wave has passed a vmcnt(4) issued after its (t+1,h) pieces.
-// ------------------------------------------------------------------------------------------------------------------
-LMI_DEV int gemm_lds_off64(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
-
-template <typename T, int EPI, int ACT, int AMODE>
-__global__ void __launch_bounds__(512) gemm_stagger2_kernel(GemmArgs p) {
-    typedef GemmCfg<256, 256, 2, 4, 2> C;
-    typedef typename vec_of<T>::x8 T8;
-    constexpr int HALF_BYTES = 256 * 64;                 // one operand, one k-half
-    constexpr int SLOT_BYTES = 4 * HALF_BYTES;           // A.h0 A.h1 W.h0 W.h1
-    LMI_DYN_SMEM(smem);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = wave_id();
-    const int grp = wave >> 2;
-    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
-    const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = (p.N + C::BN - 1) / C::BN;
-    int tm, tn;
-    gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, tm, tn);
-    const int m0 = tm * C::BM, n0 = tn * C::BN;
-
-    // ---- LDS-DMA sources: this wave owns pieces q = wave and wave+8 (16 rows each) of every operand half ---------
-    const int prow = lane >> 2, pchunk = lane & 3;
-    const char* a_src[2];
-    const char* w_src[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (wave + 8 * j) * 16 + prow;
-        const int lc = pchunk ^ ((r >> 2) & 3);
-        const int am = imin(m0 + r, p.M - 1);
-        long arow;
-        if (AMODE == AMODE_PIXSHUF) {
-            const int g = p.ps_grid, h = g >> 1, per = h * h;
-            const int tile = am / per, pp = am - tile * per;
-            const int ph = pp / h, pw = pp - ph * h;
-            arow = (long)tile * g * g + (long)(2 * ph) * g + 2 * pw;
-        } else {
-            arow = am;
-        }
-        a_src[j] = (const char*)p.A + (arow * p.lda + lc * 8) * 2;
-        w_src[j] = (const char*)p.W + ((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2;
-    }
-    const int ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;
-    auto issue_half = [&](int kt, int h) {                // 4 pieces: A q0, A q1, W q0, W q1 of half h of k-tile kt
-        char* base = smem + (kt & 1) * SLOT_BYTES + h * HALF_BYTES + wave * 1024;
-        const int k0 = kt * GEMM_BK + h * 32;
-        long a_off = (long)k0 * 2;
-        if (AMODE == AMODE_PIXSHUF) {
-            const int seg = k0 / ps_c;
-            a_off = ((long)((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            glds16(a_src[j] + a_off, base + j * 8192);
-            glds16(w_src[j] + (long)k0 * 2, base + 2 * HALF_BYTES + j * 8192);
-        }
-    };
-
-    f32x16 acc[C::NI][C::MI];
-#pragma unroll
-    for (int i = 0; i < C::NI; ++i)
-#pragma unroll
-        for (int j = 0; j < C::MI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int fr = lane & 31, fh = lane >> 5;
-    const int nt = p.K / GEMM_BK;
-    issue_half(0, 0);
-    issue_half(0, 1);
-    wait_vmcnt_barrier<0>();
-    if (grp == 1) raw_barrier();                          // waves 4-7 run one barrier behind
-
-    for (int t = 0; t < nt; ++t) {
-        const char* slot = smem + (t & 1) * SLOT_BYTES;
-        const bool do_issue = t + 1 < nt;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            // ---- LOAD segment ---------------------------------------------------------------------------------
-            const char* a_h = slot + h * HALF_BYTES;
-            const char* w_h = a_h + 2 * HALF_BYTES;
-            T8 af[2][C::MI], wf[2][C::NI];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int i = 0; i < C::MI; ++i) af[kk][i] = *(const T8*)(a_h + gemm_lds_off64(wm * C::WTM + i * 32 + fr, kk * 2 + fh));
-#pragma unroll
-                for (int i = 0; i < C::NI; ++i) wf[kk][i] = *(const T8*)(w_h + gemm_lds_off64(wn * C::WTN + i * 32 + fr, kk * 2 + fh));
-            }
-            if (do_issue) {
-                issue_half(t + 1, h);
-                wait_vmcnt_barrier<4>();                  // all older pieces landed; only the 4 just issued in flight
-            } else {
-                wait_vmcnt_barrier<0>();
-            }
-            // ---- MFMA segment ---------------------------------------------------------------------------------
-            sched_fence();
-            setprio_hi();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < C::MI; ++mi) acc[ni][mi] = mfma32(wf[kk][ni], af[kk][mi], acc[ni][mi]);
-            setprio_lo();
-            sched_fence();
-            raw_barrier();
-        }
-    }
-    if (grp == 0) raw_barrier();                          // balance the barrier count
     gemm_epilogue<T, EPI, ACT, C>(p, acc, m0, n0, wm, wn, fr, fh);
 }
 

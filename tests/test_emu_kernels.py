@@ -115,7 +115,7 @@ def test_gemm_pixel_shuffle_gather(ops, dtype):
     assert (out.float() - ref).abs().max() <= tol(dtype) * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_gemm_every_tile_geometry(ops, cfg):
     """All GemmCfg geometries (128x128 .. 256x256, 2- and 3-slot LDS rings) on ragged M, an N that is not a multiple
     of the tile width, and enough k-tiles to wrap the ring several times."""
@@ -296,22 +296,6 @@ def test_attention_decode_shape_bottom_right_causal(ops):
                       lq, H, KV, D, D ** -0.5, True, True)
         ref = attn_ref(q, k, v, [0, lq], [0, 70], H, KV, D, D ** -0.5, True)
         assert (out.float() - ref).abs().max() <= 4e-3
-
-
-def test_gemm_lds_swizzle64_is_conflict_free():
-    """Same check for the 64-byte-row half-tile images of gemm_stagger2_kernel (chunk c of row r at c ^ ((r>>2)&3))."""
-    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
-              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
-    groups += [[l + 32 for l in g] for g in groups]
-    for kk in range(2):
-        for base in range(0, 256, 32):
-            for g in groups:
-                slots = set()
-                for lane in g:
-                    r, c = base + (lane & 31), 2 * kk + (lane >> 5)
-                    off = r * 64 + ((c ^ ((r >> 2) & 3)) << 4)
-                    slots.add((off % 256) // 16)
-                assert len(slots) == 16
 
 
 def test_gemm_lds_swizzle_is_conflict_free():
