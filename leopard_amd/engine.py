@@ -96,14 +96,43 @@ class LeopardEngine:
         self.cfg, self.W = cfg, weights
         self.ops = ops if ops is not None else Ops()
         self.dtype = weights.dtype
-        self.device = device if device is not None else weights.embed.device
+        self.device = torch.device(device) if device is not None else weights.embed.device
         self.use_tr = use_tr
         tc = cfg.text_config
         self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
+        self._geom_cache: Dict[tuple, tuple] = {}      # seq_lens -> (cu, cos, sin, last_rows) device tensors
+        self._vit_cu_cache: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------
     def _empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    def _pinned_to_device(self, t: torch.Tensor) -> torch.Tensor:
+        """Host tensor -> device without blocking the host on the stream (pinned staging + async copy)."""
+        if self.device.type != "cuda":
+            return t.to(self.device)
+        staged = t.pin_memory()
+        out = staged.to(self.device, non_blocking=True)
+        out._lmi_staging = staged                       # keep the pinned source alive until the copy has run
+        return out
+
+    def sequence_geometry(self, seq_lens: Sequence[int]):
+        """cu_seqlens / RoPE tables / last-row indices for a tuple of packed sequence lengths (cached: the same
+        prompt geometry recurs, and rebuilding would cost a blocking host->device copy per call)."""
+        key = tuple(int(l) for l in seq_lens)
+        hit = self._geom_cache.get(key)
+        if hit is None:
+            cu_list = [0]
+            for l in key:
+                cu_list.append(cu_list[-1] + l)
+            cu = torch.tensor(cu_list, dtype=torch.int32, device=self.device)
+            pos = torch.cat([torch.arange(l) for l in key])
+            cos, sin = self.rope_tables(pos)
+            last_rows = torch.tensor([c - 1 for c in cu_list[1:]], device=self.device)
+            if len(self._geom_cache) > 64:
+                self._geom_cache.clear()
+            hit = self._geom_cache[key] = (cu, cos, sin, last_rows, cu_list)
+        return hit
 
     def rope_tables(self, positions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """cos/sin [S, head_dim/2] fp32 on device (tiny; torch used as plumbing for a table build)."""
@@ -128,7 +157,9 @@ class LeopardEngine:
         qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0]) if W.vit_layers else None
         att = self._empty(M, D)
         ff = self._empty(M, W.vit_ff)
-        cu = torch.arange(0, (n + 1) * T, T, dtype=torch.int32, device=self.device)
+        cu = self._vit_cu_cache.get(n)
+        if cu is None:
+            cu = self._vit_cu_cache[n] = torch.arange(0, (n + 1) * T, T, dtype=torch.int32, device=self.device)
         scale = hd ** -0.5
         for L in W.vit_layers:
             ops.layernorm(x, L.ln1_w, L.ln1_b, h, vc.layer_norm_eps)
@@ -165,11 +196,16 @@ class LeopardEngine:
     # ------------------------------------------------------------------------------------------------
     def embed_merge(self, input_ids: torch.Tensor, visual_tokens: Optional[torch.Tensor]) -> torch.Tensor:
         cfg = self.cfg
-        ids_host = input_ids.detach().reshape(-1).cpu().numpy()
+        # the index map is planned on the host from the token ids; ids that are already host-side (the tokenizer's
+        # output, EVAL:443) cost no device sync at all
+        ids_host_t = input_ids.detach().reshape(-1).to("cpu", torch.int64)
         n_rows = 0 if visual_tokens is None else visual_tokens.shape[0]
-        src = plan_merge(ids_host, cfg.image_token_index, n_rows, cfg.tokens_per_tile)
-        ids_dev = input_ids.reshape(-1).to(device=self.device, dtype=torch.int64).contiguous()
-        src_dev = torch.from_numpy(src).to(self.device)
+        src = plan_merge(ids_host_t.numpy(), cfg.image_token_index, n_rows, cfg.tokens_per_tile)
+        if input_ids.device == self.device:
+            ids_dev = input_ids.reshape(-1).to(torch.int64).contiguous()
+        else:
+            ids_dev = self._pinned_to_device(ids_host_t.contiguous())
+        src_dev = self._pinned_to_device(torch.from_numpy(src))
         x = self._empty(len(src), cfg.text_config.hidden_size, dtype=torch.float32)
         self.ops.embed_merge(ids_dev, src_dev, self.W.embed, visual_tokens, x)
         return x
@@ -185,13 +221,8 @@ class LeopardEngine:
         S, D = x.shape
         H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
         qw, kw = H * hd, KV * hd
-        cu_list = [0]
-        for l in seq_lens:
-            cu_list.append(cu_list[-1] + int(l))
+        cu, cos, sin, last_rows, cu_list = self.sequence_geometry(seq_lens)
         assert cu_list[-1] == S
-        cu = torch.tensor(cu_list, dtype=torch.int32, device=self.device)
-        pos = torch.cat([torch.arange(int(l)) for l in seq_lens])
-        cos, sin = self.rope_tables(pos)
         if cache is not None:
             assert len(seq_lens) == 1 and cache.length == 0 and cache.capacity >= S
         h = self._empty(S, D)
@@ -212,12 +243,11 @@ class LeopardEngine:
             ops.gemm(gu, L.down_w, x, epilogue=_lib.EPI_RESIDUAL)
         if cache is not None:
             cache.length = S
-        return self._lm_head(x, cu_list, all_logits)
+        return self._lm_head(x, last_rows, all_logits)
 
-    def _lm_head(self, x, cu_list, all_logits):
+    def _lm_head(self, x, last_rows, all_logits):
         ops, W, tc = self.ops, self.W, self.cfg.text_config
         V = tc.vocab_size
-        last_rows = torch.tensor([c - 1 for c in cu_list[1:]], device=self.device)
         xl = x.index_select(0, last_rows).contiguous()                   # [n_seq, D] fp32 (plumbing gather)
         hl = self._empty(xl.shape[0], xl.shape[1])
         ops.rmsnorm(xl, W.final_norm, hl, tc.rms_norm_eps)
