@@ -72,6 +72,7 @@ class TextConfig:
     rope_scaling: Optional[RopeScaling] = field(default_factory=RopeScaling)
     head_dim_override: Optional[int] = None
     pad_token_id: Optional[int] = None
+    sliding_window: Optional[int] = None          # Mistral (Leopard-Idefics2): 4096
 
     @property
     def head_dim(self) -> int:
@@ -163,4 +164,70 @@ def mid_config() -> LeopardConfig:
     cfg.text_config.num_hidden_layers = 2
     cfg.text_config.vocab_size = 8192
     cfg.image_token_index = 8000
+    return cfg
+
+
+# ==================================================================================================
+# Leopard-Idefics2 (evaluations/models/idefics2_multiimg.py; Idefics2-8B base: NaViT SigLIP + perceiver + Mistral-7B)
+# dimensions: Pai-Megatron-Patch/examples/idefics2/train_multiimg_idefics2.sh:80,93-102,190,234,239 and the public
+# idefics2-8b config (perceiver 64 latents x 3 layers, 16 heads x 96, 4 kv heads; vision 70x70 position grid)
+# ==================================================================================================
+@dataclass
+class PerceiverConfig:
+    n_latents: int = 64
+    depth: int = 3
+    n_heads: int = 16
+    head_dim: int = 96
+    num_key_value_heads: int = 4
+    rms_norm_eps: float = 1e-6
+
+
+@dataclass
+class Idefics2Config:
+    vision_config: VisionConfig = field(default_factory=lambda: VisionConfig(image_size=980))
+    text_config: TextConfig = field(default_factory=lambda: TextConfig(vocab_size=32003, rope_theta=10000.0,
+                                                                      rope_scaling=None, sliding_window=4096))
+    perceiver_config: PerceiverConfig = field(default_factory=PerceiverConfig)
+    image_token_id: int = 32001
+    longest_edge: int = 980                    # idefics2_multiimg.py:23-25 (do_image_splitting=False)
+
+    # the LLM core of LeopardEngine reads these two names
+    @property
+    def image_token_index(self) -> int:
+        return self.image_token_id
+
+    @property
+    def tokens_per_tile(self) -> int:
+        return 1                               # the prompt already carries n_latents <image> ids per image
+
+    def to_dict(self) -> dict:
+        d = dataclasses.asdict(self)
+        d["model_type"] = "idefics2"
+        return d
+
+
+def idefics2_full_config() -> Idefics2Config:
+    return Idefics2Config()
+
+
+def idefics2_tiny_config() -> Idefics2Config:
+    """Golden-fixture configuration (same op graph, tiny dims): 4x4 position grid, 4 latents."""
+    return Idefics2Config(
+        vision_config=VisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                   image_size=56, patch_size=14),
+        text_config=TextConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                               num_key_value_heads=2, vocab_size=512, rope_theta=10000.0, rope_scaling=None,
+                               sliding_window=4096, pad_token_id=0),
+        perceiver_config=PerceiverConfig(n_latents=4, depth=2, n_heads=4, head_dim=16, num_key_value_heads=2),
+        image_token_id=500, longest_edge=56)
+
+
+def idefics2_mid_config() -> Idefics2Config:
+    """Full-width layers (vision 1152 / 16x72, perceiver 16x96 over 4096, Mistral 32/8x128), reduced depth."""
+    cfg = Idefics2Config()
+    cfg.vision_config.num_hidden_layers = 2
+    cfg.text_config.num_hidden_layers = 2
+    cfg.text_config.vocab_size = 8192
+    cfg.perceiver_config.depth = 2
+    cfg.image_token_id = 8000
     return cfg

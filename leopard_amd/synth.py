@@ -162,3 +162,70 @@ def synth_prompt_ids(vit_inputs_per_image, cfg: LeopardConfig, n_question: int =
         ids += rnd(4) + ([128025] if big else rnd(1)) + [img] * k + ([128026] if big else rnd(1))
     ids += rnd(n_question) + rnd(16)
     return np.asarray(ids, dtype=np.int64)
+
+
+# --------------------------------------------------------------------------------------------------
+# Leopard-Idefics2 parameter inventory in the HF key layout (Idefics2ForConditionalGeneration; the reference's
+# converter: toolkits/model_checkpoints_convertor/idefics2/idefics2_hf2mg.py:1263-1662 — model.vision_model.*,
+# model.connector.*, model.text_model.*, lm_head.weight)
+# --------------------------------------------------------------------------------------------------
+def idefics2_param_specs(cfg) -> Iterator[Tuple[str, Tuple[int, ...], int]]:
+    vc, tc, pc = cfg.vision_config, cfg.text_config, cfg.perceiver_config
+    v = "model.vision_model."
+    yield v + "embeddings.patch_embedding.weight", (vc.hidden_size, vc.num_channels, vc.patch_size, vc.patch_size), KIND_WEIGHT
+    yield v + "embeddings.patch_embedding.bias", (vc.hidden_size,), KIND_BIAS
+    yield v + "embeddings.position_embedding.weight", (vc.num_patches, vc.hidden_size), KIND_WEIGHT
+    for i in range(vc.num_hidden_layers):
+        p = f"{v}encoder.layers.{i}."
+        for ln in ("layer_norm1", "layer_norm2"):
+            yield p + ln + ".weight", (vc.hidden_size,), KIND_NORM
+            yield p + ln + ".bias", (vc.hidden_size,), KIND_BIAS
+        for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            yield p + f"self_attn.{proj}.weight", (vc.hidden_size, vc.hidden_size), KIND_WEIGHT
+            yield p + f"self_attn.{proj}.bias", (vc.hidden_size,), KIND_BIAS
+        yield p + "mlp.fc1.weight", (vc.intermediate_size, vc.hidden_size), KIND_WEIGHT
+        yield p + "mlp.fc1.bias", (vc.intermediate_size,), KIND_BIAS
+        yield p + "mlp.fc2.weight", (vc.hidden_size, vc.intermediate_size), KIND_WEIGHT
+        yield p + "mlp.fc2.bias", (vc.hidden_size,), KIND_BIAS
+    yield v + "post_layernorm.weight", (vc.hidden_size,), KIND_NORM
+    yield v + "post_layernorm.bias", (vc.hidden_size,), KIND_BIAS
+
+    c = "model.connector."
+    yield c + "modality_projection.gate_proj.weight", (tc.intermediate_size, vc.hidden_size), KIND_WEIGHT
+    yield c + "modality_projection.up_proj.weight", (tc.intermediate_size, vc.hidden_size), KIND_WEIGHT
+    yield c + "modality_projection.down_proj.weight", (tc.hidden_size, tc.intermediate_size), KIND_WEIGHT
+    r = c + "perceiver_resampler."
+    yield r + "latents", (pc.n_latents, tc.hidden_size), KIND_WEIGHT
+    for i in range(pc.depth):
+        p = f"{r}layers.{i}."
+        for n in ("input_latents_norm", "input_context_norm", "post_attention_layernorm"):
+            yield p + n + ".weight", (tc.hidden_size,), KIND_NORM
+        yield p + "self_attn.q_proj.weight", (pc.n_heads * pc.head_dim, tc.hidden_size), KIND_WEIGHT
+        yield p + "self_attn.k_proj.weight", (pc.num_key_value_heads * pc.head_dim, tc.hidden_size), KIND_WEIGHT
+        yield p + "self_attn.v_proj.weight", (pc.num_key_value_heads * pc.head_dim, tc.hidden_size), KIND_WEIGHT
+        yield p + "self_attn.o_proj.weight", (tc.hidden_size, pc.n_heads * pc.head_dim), KIND_WEIGHT
+        yield p + "mlp.gate_proj.weight", (4 * tc.hidden_size, tc.hidden_size), KIND_WEIGHT
+        yield p + "mlp.up_proj.weight", (4 * tc.hidden_size, tc.hidden_size), KIND_WEIGHT
+        yield p + "mlp.down_proj.weight", (tc.hidden_size, 4 * tc.hidden_size), KIND_WEIGHT
+    yield r + "norm.weight", (tc.hidden_size,), KIND_NORM
+
+    l = "model.text_model."
+    hd = tc.head_dim
+    yield l + "embed_tokens.weight", (tc.vocab_size, tc.hidden_size), KIND_WEIGHT
+    for i in range(tc.num_hidden_layers):
+        p = f"{l}layers.{i}."
+        yield p + "input_layernorm.weight", (tc.hidden_size,), KIND_NORM
+        yield p + "self_attn.q_proj.weight", (tc.num_attention_heads * hd, tc.hidden_size), KIND_WEIGHT
+        yield p + "self_attn.k_proj.weight", (tc.num_key_value_heads * hd, tc.hidden_size), KIND_WEIGHT
+        yield p + "self_attn.v_proj.weight", (tc.num_key_value_heads * hd, tc.hidden_size), KIND_WEIGHT
+        yield p + "self_attn.o_proj.weight", (tc.hidden_size, tc.num_attention_heads * hd), KIND_WEIGHT
+        yield p + "post_attention_layernorm.weight", (tc.hidden_size,), KIND_NORM
+        yield p + "mlp.gate_proj.weight", (tc.intermediate_size, tc.hidden_size), KIND_WEIGHT
+        yield p + "mlp.up_proj.weight", (tc.intermediate_size, tc.hidden_size), KIND_WEIGHT
+        yield p + "mlp.down_proj.weight", (tc.hidden_size, tc.intermediate_size), KIND_WEIGHT
+    yield l + "norm.weight", (tc.hidden_size,), KIND_NORM
+    yield "lm_head.weight", (tc.vocab_size, tc.hidden_size), KIND_WEIGHT
+
+
+def idefics2_state_dict_numpy(cfg) -> Dict[str, np.ndarray]:
+    return {n: synth_array(n, s, k) for n, s, k in idefics2_param_specs(cfg)}

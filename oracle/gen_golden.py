@@ -461,6 +461,61 @@ def gen_harness_capture(L):
     print("harness_capture.json ok:", len(recs), "records x 3 settings")
 
 
+
+def gen_idefics2_tiny():
+    """Third-party Idefics2ForConditionalGeneration (the model class the reference's idefics2_multiimg.py loads, IDEF:27-29)
+    at a tiny configuration with the seeded synthetic weights, on two images of different sizes padded to a common
+    canvas with a pixel_attention_mask (what the reference's processor emits, IDEF:91-93)."""
+    from transformers import Idefics2Config, Idefics2ForConditionalGeneration
+    from leopard_amd.config import idefics2_tiny_config
+    from leopard_amd.synth import idefics2_state_dict_numpy
+    cfg = idefics2_tiny_config()
+    v, t, pc = cfg.vision_config, cfg.text_config, cfg.perceiver_config
+    hf_cfg = Idefics2Config(
+        vision_config=dict(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size, num_hidden_layers=v.num_hidden_layers,
+                           num_attention_heads=v.num_attention_heads, image_size=v.image_size, patch_size=v.patch_size,
+                           hidden_act=v.hidden_act, layer_norm_eps=v.layer_norm_eps),
+        perceiver_config=dict(hidden_act="silu", hidden_size=t.hidden_size, rms_norm_eps=pc.rms_norm_eps,
+                              resampler_n_latents=pc.n_latents, resampler_depth=pc.depth, resampler_n_heads=pc.n_heads,
+                              resampler_head_dim=pc.head_dim, num_key_value_heads=pc.num_key_value_heads),
+        text_config=dict(model_type="mistral", hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                         num_hidden_layers=t.num_hidden_layers, num_attention_heads=t.num_attention_heads,
+                         num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps,
+                         rope_theta=t.rope_theta, sliding_window=t.sliding_window, max_position_embeddings=32768,
+                         pad_token_id=0, head_dim=t.hidden_size // t.num_attention_heads),
+        image_token_id=cfg.image_token_id, tie_word_embeddings=False, attn_implementation="eager")
+    model = Idefics2ForConditionalGeneration(hf_cfg).eval()
+    sd = {k: torch.from_numpy(a) for k, a in idefics2_state_dict_numpy(cfg).items()}
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.missing_keys and not missing.unexpected_keys, missing
+    rng = np.random.default_rng(31)
+    img_a = rng.standard_normal((3, 42, 56)).astype(np.float32)         # 3 x 4 patches
+    img_b = rng.standard_normal((3, 58, 30)).astype(np.float32)         # 4 x 2 patches (+ remainder pixels)
+    Hm, Wm = 58, 56
+    pix = np.zeros((1, 2, 3, Hm, Wm), np.float32)
+    msk = np.zeros((1, 2, Hm, Wm), np.int64)
+    pix[0, 0, :, :42, :56] = img_a; msk[0, 0, :42, :56] = 1
+    pix[0, 1, :, :58, :30] = img_b; msk[0, 1, :58, :30] = 1
+    L = pc.n_latents
+    ids = [5, 7] + [cfg.image_token_id] * L + [9, 11, 13] + [cfg.image_token_id] * L + [17, 19]
+    ids_t = torch.tensor([ids])
+    with torch.no_grad():
+        out = model(input_ids=ids_t, attention_mask=torch.ones_like(ids_t), pixel_values=torch.from_numpy(pix),
+                    pixel_attention_mask=torch.from_numpy(msk))
+    np.savez_compressed(os.path.join(OUT, "idefics2_tiny.npz"), ids=np.array(ids), img_a=img_a, img_b=img_b,
+                        logits=out.logits.numpy(), image_hidden_states=out.image_hidden_states.numpy())
+    # processor size rule sweep (third-party get_resize_output_image_size)
+    from transformers.models.idefics2.image_processing_pil_idefics2 import get_resize_output_image_size
+    from transformers.image_utils import SizeDict
+    rows = []
+    for (w, h) in [(1344, 896), (896, 1344), (980, 980), (400, 300), (2000, 100), (981, 5), (3000, 3000), (979, 1200)]:
+        oh, ow = get_resize_output_image_size(np.zeros((3, h, w)), SizeDict(longest_edge=980, shortest_edge=0))
+        rows.append([w, h, int(ow), int(oh)])
+    with open(os.path.join(OUT, "idefics2_resize.json"), "w") as f:
+        json.dump(rows, f)
+    print("idefics2_tiny.npz ok; logits", out.logits.shape, "features", tuple(out.image_hidden_states.shape), rows[0])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     L = import_reference()
@@ -471,6 +526,7 @@ def main():
     gen_tiny_e2e(L)
     gen_fullwidth_layers()
     gen_harness_capture(L)
+    gen_idefics2_tiny()
 
 
 if __name__ == "__main__":

@@ -164,9 +164,9 @@ def siglip_embeddings(pixel_values: Tensor, W: Dict[str, Tensor], cfg) -> Tensor
     return x + W[p + "position_embedding.weight"].unsqueeze(0)
 
 
-def siglip_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg) -> Tensor:
+def siglip_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, prefix: str = "vision_tower.vision_model.") -> Tensor:
     vc = cfg.vision_config
-    p = f"vision_tower.vision_model.encoder.layers.{i}."
+    p = f"{prefix}encoder.layers.{i}."
     N, T, D = x.shape
     H, hd = vc.num_attention_heads, vc.head_dim
     r = x
@@ -304,9 +304,9 @@ def rms_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
 
 
 def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: Tensor,
-                kv_out: Optional[list] = None) -> Tensor:
+                kv_out: Optional[list] = None, prefix: str = "language_model.model.") -> Tensor:
     tc = cfg.text_config
-    p = f"language_model.model.layers.{i}."
+    p = f"{prefix}layers.{i}."
     B, S, D = x.shape
     H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     r = x
@@ -329,6 +329,8 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
         s1 = min(S, s0 + step)
         sc = torch.matmul(q[:, :, s0:s1], kk[:, :, :s1].transpose(-1, -2)) * scale
         causal = ar[s0:s1, None] >= ar[None, :s1]
+        if getattr(tc, "sliding_window", None):                 # Mistral: query i sees keys j with i - j < window
+            causal = causal & (ar[s0:s1, None] - ar[None, :s1] < tc.sliding_window)
         sc = sc.masked_fill(~causal, float("-inf"))
         o[:, :, s0:s1] = torch.matmul(torch.softmax(sc, dim=-1, dtype=torch.float32), vv[:, :, :s1])
     o = o.transpose(1, 2).reshape(B, S, H * hd)
@@ -341,7 +343,8 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
 
 
 def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tensor], cfg,
-                  last_only: bool = False, kv_out: Optional[list] = None) -> Tensor:
+                  last_only: bool = False, kv_out: Optional[list] = None, prefix: str = "language_model.model.",
+                  head: str = "language_model.lm_head.weight") -> Tensor:
     """``self.language_model(inputs_embeds=..., position_ids=...)`` -> logits (EVAL:322-333).
     ``last_only`` computes the head for the final position only (the algorithmic need of prefill);
     the reference computes all positions."""
@@ -349,11 +352,11 @@ def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tens
     cos, sin = rope_tables(position_ids, tc.head_dim, tc.rope_theta, tc.rope_scaling)
     x = inputs_embeds
     for i in range(tc.num_hidden_layers):
-        x = llama_layer(x, W, i, cfg, cos, sin, kv_out)
-    x = rms_norm(x, W["language_model.model.norm.weight"], tc.rms_norm_eps)
+        x = llama_layer(x, W, i, cfg, cos, sin, kv_out, prefix=prefix)
+    x = rms_norm(x, W[prefix + "norm.weight"], tc.rms_norm_eps)
     if last_only:
         x = x[:, -1:, :]
-    return F.linear(x, W["language_model.lm_head.weight"])
+    return F.linear(x, W[head])
 
 
 # ==================================================================================================
