@@ -59,6 +59,12 @@ int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dt
 int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, int image_size, int patch,
                          int ldo, int dtype, void* stream);
 
+/* Same for rectangular images (Leopard-Idefics2's NaViT tower, idefics2_multiimg.py:91-93; third-party
+ * Idefics2VisionEmbeddings; analogue idefics_vision_tower.py:118-150): n_images of height x width (u8 HWC or normalised
+ * fp32 CHW); the valid patch conv drops remainder pixels -> (height/patch)*(width/patch) rows per image. */
+int lmi_preprocess_images(const void* in, int from_u8, void* out, int n_images, int height, int width, int patch, int ldo,
+                          int dtype, void* stream);
+
 /* LayerNorm (SigLIP layer_norm1/2, post_layernorm; analogue idefics_vision_tower.py:77-81,176) and
  * RMSNorm (Llama input/post_attention/final norm; megatron/legacy/model/rms_norm.py:26-31):
  * x fp32 [M, ldx] -> out T [M, ldo]; w, b fp32 [D]. */
@@ -71,23 +77,26 @@ int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx
  * SigLIP patch-embed, q/k/v/out_proj, fc1 (+gelu_tanh), fc2; projector linear_1 (+gelu_erf, A gathered through
  * the 2x2 pixel shuffle of EVAL:165-176) and linear_2 (EVAL:187-192); Llama qkv / o_proj / gate+up (+SwiGLU,
  * megatron_patch/model/llava/transformer.py:136-139) / down_proj; all-position lm_head (EVAL:333).
- * Requires N % 128 == 0, K % 64 == 0.  A, W are T; bias/addmat fp32 (nullable); row_map (nullable) scatters
+ * Requires N % 128 == 0, K % 64 == 0.  A, W are T; bias/addmat fp32 (nullable); addmat row = add_rows[m] when add_rows is
+ * given (NaViT bucketised position ids), else m % add_period; row_map (nullable) scatters
  * output row m to row row_map[m].  For LMI_A_PIXEL_SHUFFLE, A is the ViT output [tiles*G*G, K/4] and M counts
  * shuffled rows (tiles*(G/2)^2). */
-int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* row_map,
-             int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
+int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
+             const int* row_map, int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
              int ps_grid, int dtype, void* stream);
 
 /* Variable-length FlashAttention-2 forward over packed sequences (SigLIP: non-causal, head_dim 72, one
- * sequence per tile; Llama: causal GQA, head_dim 128) — replaces the attention inside self.vision_tower(...)
+ * sequence per tile; Llama / Mistral: causal GQA, head_dim 128, optional sliding window; Idefics2 perceiver: head_dim 96,
+ * len_q != len_k) — replaces the attention inside self.vision_tower(...)
  * and self.language_model(...) (EVAL:268,322; analogue transformer.py:456-512 flash_attn_varlen_func).
  * q/k/v/out: T, head h of row r at base + r*ld + h*head_dim.  cu_seqlens: int32 [n_seq+1] on device.
- * Causal alignment is bottom-right (key j visible to query i iff j <= i + len_k - len_q).
+ * Causal alignment is bottom-right (key j visible to query i iff j <= i + len_k - len_q); window > 0 additionally hides
+ * keys with i + len_k - len_q - j >= window (Mistral sliding window), 0 = unlimited.
  * use_tr=1 uses ds_read_b64_tr_b16 for the V operand (production); 0 uses plain LDS gathers (cross-check). */
 int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,
                         const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads,
-                        int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, int causal, int use_tr,
-                        int dtype, void* stream);
+                        int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window,
+                        int use_tr, int dtype, void* stream);
 
 /* RoPE (rotate-half; cos/sin fp32 [S, head_dim/2] built from position_ids and the llama3-scaled inverse
  * frequencies, rotary_pos_embedding.py:48-83,197-239) applied in place to the q and k heads of packed qkv rows

@@ -25,10 +25,11 @@ SIGNATURES = {
     "lmi_set_option": [C.c_char_p, _I],
     "lmi_fill_synthetic": [_P, C.c_int64, C.c_uint32, _I, _I, _P],
     "lmi_preprocess_tiles": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "lmi_preprocess_images": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "lmi_layernorm": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "lmi_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
-    "lmi_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "lmi_attn_varlen_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
+    "lmi_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_attn_varlen_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
     "lmi_rope_qk": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     "lmi_embed_merge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lmi_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

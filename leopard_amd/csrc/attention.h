@@ -34,6 +34,7 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo;
     int n_heads, n_kv_heads;
     float scale;              // softmax scale (head_dim^-0.5)
+    int window;               // sliding window (Mistral): query i sees keys j with i - j < window; 0 = unlimited
 };
 
 constexpr int ATT_BQ = 128, ATT_BKV = 64, ATT_THREADS = 256;
@@ -165,15 +166,17 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
             }
         }
         // ---- mask -----------------------------------------------------------------------------------
-        const bool need_mask = (kv0 + ATT_BKV > len_k) || (CAUSAL && (kv0 + ATT_BKV - 1 > wave_q_lo + shift));
+        const bool need_mask = (kv0 + ATT_BKV > len_k) || (CAUSAL && (kv0 + ATT_BKV - 1 > wave_q_lo + shift)) ||
+                               (CAUSAL && p.window > 0 && kv0 <= wave_q_hi + shift - p.window);
         if (need_mask) {
             const int lim = CAUSAL ? imin(len_k - 1, my_q + shift) : len_k - 1;   // last visible key
+            const int lo = (CAUSAL && p.window > 0) ? my_q + shift - p.window + 1 : 0;   // first visible key
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    if (key > lim) s[b][r] = -INFINITY;
+                    if (key > lim || key < lo) s[b][r] = -INFINITY;
                 }
         }
         // ---- online softmax ---------------------------------------------------------------------------
@@ -373,15 +376,17 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
                 s[b] = mfma32(kf, qf[ks], s[b]);
             }
         }
-        const bool need_mask = (kv0 + ATT_BKV > len_k) || (CAUSAL && (kv0 + ATT_BKV - 1 > wave_q_lo + shift));
+        const bool need_mask = (kv0 + ATT_BKV > len_k) || (CAUSAL && (kv0 + ATT_BKV - 1 > wave_q_lo + shift)) ||
+                               (CAUSAL && p.window > 0 && kv0 <= wave_q_hi + shift - p.window);
         if (need_mask) {
-            const int lim = CAUSAL ? imin(len_k - 1, my_q + shift) : len_k - 1;
+            const int lim = CAUSAL ? imin(len_k - 1, my_q + shift) : len_k - 1;   // last visible key
+            const int lo = (CAUSAL && p.window > 0) ? my_q + shift - p.window + 1 : 0;   // first visible key
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    if (key > lim) s[b][r] = -INFINITY;
+                    if (key > lim || key < lo) s[b][r] = -INFINITY;
                 }
         }
         float mx = s[0][0];

@@ -192,9 +192,9 @@ int norm_impl(const float* x, const float* w, const float* b, void* out, int M, 
 }
 
 template <typename T>
-int im2col_impl(const void* in, int from_u8, void* out, int n_tiles, int S, int P, int ldo, int grid, void* stream) {
-    if (from_u8) LMI_LAUNCH((im2col_kernel<T, true>), dim3(grid), dim3(256), 0, stream, in, (T*)out, n_tiles, S, P, ldo);
-    else LMI_LAUNCH((im2col_kernel<T, false>), dim3(grid), dim3(256), 0, stream, in, (T*)out, n_tiles, S, P, ldo);
+int im2col_impl(const void* in, int from_u8, void* out, int n_tiles, int H, int W, int P, int ldo, int grid, void* stream) {
+    if (from_u8) LMI_LAUNCH((im2col_kernel<T, true>), dim3(grid), dim3(256), 0, stream, in, (T*)out, n_tiles, H, W, P, ldo);
+    else LMI_LAUNCH((im2col_kernel<T, false>), dim3(grid), dim3(256), 0, stream, in, (T*)out, n_tiles, H, W, P, ldo);
     return check_launch("lmi_preprocess_tiles");
 }
 template <typename T>
@@ -252,15 +252,21 @@ int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dt
     return check_launch("lmi_fill_synthetic");
 }
 
+int lmi_preprocess_images(const void* in, int from_u8, void* out, int n_images, int height, int width, int patch, int ldo,
+                          int dtype, void* stream) {
+    if (!in || !out || n_images < 0 || patch <= 0 || height < patch || width < patch || ldo < 3 * patch * patch || (ldo & 7))
+        return fail(LMI_EINVAL, "lmi_preprocess_images: bad shape (H=%d W=%d P=%d ldo=%d)", height, width, patch, ldo);
+    if (n_images == 0) return LMI_OK;
+    const int grid = grid_for((long)n_images * (height / patch) * (width / patch) * ldo, 256);
+    LMI_DISPATCH_T(dtype, (im2col_impl<f16_t>(in, from_u8, out, n_images, height, width, patch, ldo, grid, stream)),
+                   (im2col_impl<bf16_t>(in, from_u8, out, n_images, height, width, patch, ldo, grid, stream)));
+}
+
 int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, int image_size, int patch, int ldo,
                          int dtype, void* stream) {
-    if (!in || !out || n_tiles < 0 || patch <= 0 || image_size % patch || ldo < 3 * patch * patch || (ldo & 7))
+    if (image_size <= 0 || patch <= 0 || image_size % patch)
         return fail(LMI_EINVAL, "lmi_preprocess_tiles: bad shape (S=%d P=%d ldo=%d)", image_size, patch, ldo);
-    if (n_tiles == 0) return LMI_OK;
-    const int g = image_size / patch;
-    const int grid = grid_for((long)n_tiles * g * g * ldo, 256);
-    LMI_DISPATCH_T(dtype, (im2col_impl<f16_t>(in, from_u8, out, n_tiles, image_size, patch, ldo, grid, stream)),
-                   (im2col_impl<bf16_t>(in, from_u8, out, n_tiles, image_size, patch, ldo, grid, stream)));
+    return lmi_preprocess_images(in, from_u8, out, n_tiles, image_size, image_size, patch, ldo, dtype, stream);
 }
 
 int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps,
@@ -275,7 +281,8 @@ int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx
                    (norm_impl<bf16_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm")));
 }
 
-int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* row_map,
+int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
+             const int* row_map,
              int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
              int ps_grid, int dtype, void* stream) {
     if (!A || !W || !out) return fail(LMI_EINVAL, "lmi_gemm: null pointer");
@@ -284,7 +291,7 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
     if ((lda & 7) || (ldw & 7) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out) ||
         (bias && !aligned16(bias)) || (addmat && !aligned16(addmat)))
         return fail(LMI_EINVAL, "lmi_gemm: pointers must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
-    if (addmat && add_period <= 0) return fail(LMI_EINVAL, "lmi_gemm: addmat needs add_period > 0");
+    if (addmat && !add_rows && add_period <= 0) return fail(LMI_EINVAL, "lmi_gemm: addmat needs add_period > 0 or add_rows");
     if (a_mode == LMI_A_PIXEL_SHUFFLE) {
         if (ps_grid <= 0 || (ps_grid & 1) || (K & 3) || ((K / 4) % GEMM_BK) || (M % ((ps_grid / 2) * (ps_grid / 2))))
             return fail(LMI_EINVAL, "lmi_gemm: pixel-shuffle needs even grid, (K/4) %% 64 == 0, M %% (G/2)^2 == 0");
@@ -293,7 +300,7 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
     }
     if (M == 0) return LMI_OK;
     GemmArgs a;
-    a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.row_map = row_map;
+    a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.add_rows = add_rows; a.row_map = row_map;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m;
     LMI_DISPATCH_T(dtype, dispatch_gemm<f16_t>(a, epilogue, act, a_mode, stream),
                    dispatch_gemm<bf16_t>(a, epilogue, act, a_mode, stream));
@@ -301,20 +308,25 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
 
 int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,
                         const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
-                        int ldq, int ldk, int ldv, int ldo, float scale, int causal, int use_tr, int dtype, void* stream) {
+                        int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream) {
     if (!q || !k || !v || !out || !cu_seqlens_q || !cu_seqlens_k) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: null pointer");
     if (n_seq < 0 || max_seqlen_q < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads))
         return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: bad head counts (%d, %d)", n_heads, n_kv_heads);
-    if (head_dim != 128 && head_dim != 72) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: head_dim %d not in {72, 128}", head_dim);
+    if (head_dim != 128 && head_dim != 96 && head_dim != 72)
+        return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: head_dim %d not in {72, 96, 128}", head_dim);
+    if (window < 0) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: window must be >= 0");
     if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out))
         return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: alignment");
     if (n_seq == 0 || max_seqlen_q == 0) return LMI_OK;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
-    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
     if (head_dim == 128)
         LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
                        (dispatch_attn<bf16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
+    if (head_dim == 96)
+        LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 96>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
+                       (dispatch_attn<bf16_t, 96>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
     LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 72>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
                    (dispatch_attn<bf16_t, 72>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
 }

@@ -34,23 +34,23 @@ __global__ void fill_synth_kernel(OUT* out, long n, uint32_t seed, int kind) {
 //     value law = SiglipImageProcessor: x*(1/255) then (x-0.5)/0.5   (EVAL:403-404)
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool FROM_U8>
-__global__ void im2col_kernel(const void* in, T* out, int n_tiles, int S, int P, int ldo) {
-    const int G = S / P, KD = 3 * P * P;
-    const long total = (long)n_tiles * G * G * ldo;
+__global__ void im2col_kernel(const void* in, T* out, int n_tiles, int H, int W, int P, int ldo) {
+    const int GH = H / P, GW = W / P, KD = 3 * P * P;         // valid conv: remainder pixels are dropped
+    const long total = (long)n_tiles * GH * GW * ldo;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % ldo);
         const long row = i / ldo;
         float v = 0.f;
         if (col < KD) {
             const int c = col / (P * P), rem = col - c * P * P, ky = rem / P, kx = rem - ky * P;
-            const int px = (int)(row % G), py = (int)((row / G) % G);
-            const long n = row / ((long)G * G);
+            const int px = (int)(row % GW), py = (int)((row / GW) % GH);
+            const long n = row / ((long)GH * GW);
             const int y = py * P + ky, x = px * P + kx;
             if (FROM_U8) {
-                const float u = (float)((const uint8_t*)in)[((n * S + y) * S + x) * 3 + c];
+                const float u = (float)((const uint8_t*)in)[((n * H + y) * W + x) * 3 + c];
                 v = mul_rn(sub_rn(mul_rn(u, 1.0f / 255.0f), 0.5f), 2.0f);     // no FMA contraction: bit-exact vs the processor
             } else {
-                v = ((const float*)in)[((n * 3 + c) * S + y) * (long)S + x];
+                v = ((const float*)in)[((n * 3 + c) * H + y) * (long)W + x];
             }
         }
         out[i] = (T)v;

@@ -39,7 +39,8 @@ struct GemmArgs {
     const void* W;        // [N, K]
     void* out;            // T or fp32, leading dimension ldo
     const float* bias;    // [N] or null (for SwiGLU: unused)
-    const float* addmat;  // optional [add_period, N] fp32 matrix added row-periodically (SigLIP pos-emb)
+    const float* addmat;  // optional [add_period, N] fp32 matrix added row-periodically (SigLIP pos-emb) ...
+    const int* add_rows;  // ... or, when non-null, row add_rows[m] of addmat (NaViT bucketised position ids)
     const int* row_map;   // optional: output row of logical row m (scatter into the merged sequence)
     int M, N, K;
     int lda, ldw, ldo;
@@ -139,7 +140,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[C::NI][C::MI], int m
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][q * 4 + e];
                     if (p.bias) v += *(const f32x4*)(p.bias + n);
-                    if (p.addmat) v += *(const f32x4*)(p.addmat + (long)(m % p.add_period) * p.N + n);
+                    if (p.addmat) v += *(const f32x4*)(p.addmat + (long)(p.add_rows ? p.add_rows[m] : m % p.add_period) * p.N + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
                     if (EPI == EPI_STORE_T) {

@@ -236,7 +236,7 @@ class LeopardEngine:
             ops.gemm(h, L.qkv_w, qkv)
             ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
             ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
-                          True, self.use_tr)
+                          True, self.use_tr, window=tc.sliding_window or 0)
             ops.gemm(att, L.o_w, x, epilogue=_lib.EPI_RESIDUAL)
             ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
             ops.gemm(h, L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
@@ -312,7 +312,8 @@ class LeopardEngine:
             ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
             ops.gemv(L.qkv_w, h[0], qkv[0], epilogue=1)
             ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i], cache.v[i], pos)
-            ops.attention(qkv[:, :qw], cache.k[i], cache.v[i], att, cu_q, cu_k, 1, H, KV, hd, scale, True, self.use_tr)
+            ops.attention(qkv[:, :qw], cache.k[i], cache.v[i], att, cu_q, cu_k, 1, H, KV, hd, scale, True, self.use_tr,
+                          window=tc.sliding_window or 0)
             ops.gemv(L.o_w, att[0], x[0], epilogue=2)
             ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
             ops.gemv(L.gu_w, h[0], gu[0], epilogue=3)

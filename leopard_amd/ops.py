@@ -57,6 +57,15 @@ class Ops:
                                                   out.shape[1], _DT[out.dtype], self._stream(out)))
         return out
 
+    def preprocess_images(self, src: torch.Tensor, out: torch.Tensor, patch: int):
+        """src: u8 [n,H,W,3] or fp32 [n,3,H,W] (one size); out: T [n*(H//P)*(W//P), ldo]."""
+        from_u8 = src.dtype == torch.uint8
+        n, H, W = (src.shape[0], src.shape[1], src.shape[2]) if from_u8 else (src.shape[0], src.shape[2], src.shape[3])
+        assert src.is_contiguous() and out.is_contiguous()
+        self._check(self.lib.lmi_preprocess_images(_ptr(src), int(from_u8), _ptr(out), n, H, W, patch, out.shape[1],
+                                                   _DT[out.dtype], self._stream(out)))
+        return out
+
     def layernorm(self, x, w, b, out, eps):
         M, D = x.shape
         self._check(self.lib.lmi_layernorm(_ptr(x), _ptr(w), _ptr(b), _ptr(out), M, D, x.stride(0), out.stride(0),
@@ -70,25 +79,25 @@ class Ops:
         return out
 
     def gemm(self, a, w, out, bias=None, addmat=None, row_map=None, epilogue=EPI_STORE, act=ACT_NONE,
-             a_mode=A_PLAIN, ps_grid=0, M=None):
+             a_mode=A_PLAIN, ps_grid=0, M=None, add_rows=None):
         """out = epilogue(a @ w.T).  a: T [M,K] (or the ViT output for pixel-shuffle mode), w: T [N,K]."""
         N, K = w.shape
         if M is None:
             M = a.shape[0]
         add_period = 0 if addmat is None else addmat.shape[0]
-        self._check(self.lib.lmi_gemm(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(addmat), _ptr(row_map), M, N, K,
+        self._check(self.lib.lmi_gemm(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(addmat), _ptr(add_rows), _ptr(row_map), M, N, K,
                                       a.stride(0), w.stride(0), out.stride(0), add_period, epilogue, act, a_mode,
                                       ps_grid, _DT[w.dtype], self._stream(out)))
         return out
 
     def attention(self, q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, scale, causal,
-                  use_tr=True):
+                  use_tr=True, window=0):
         """q/k/v/out are 2-D row views [rows, >= heads*head_dim] (possibly column slices of a packed qkv buffer)."""
         n_seq = cu_q.numel() - 1
         self._check(self.lib.lmi_attn_varlen_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(cu_q), _ptr(cu_k), n_seq,
                                                  int(max_seqlen_q), n_heads, n_kv_heads, head_dim, q.stride(0),
                                                  k.stride(0), v.stride(0), out.stride(0), float(scale), int(causal),
-                                                 int(use_tr), _DT[q.dtype], self._stream(out)))
+                                                 int(window), int(use_tr), _DT[q.dtype], self._stream(out)))
         return out
 
     def rope_qk(self, qkv, n_q_heads, n_kv_heads, head_dim, cos, sin, k_cache=None, v_cache=None, cache_pos0=0):

@@ -313,3 +313,62 @@ def test_gemm_lds_swizzle_is_conflict_free():
                     off = r * 128 + ((lc ^ ((r >> 1) & 7)) << 4)
                     slots.add((off % 256) // 16)
                 assert len(slots) == 16
+
+
+def test_attention_sliding_window(ops):
+    """Mistral window: query i sees keys j with i - j < window (bottom-right aligned)."""
+    H, KV, D, S, Wn = 2, 1, 128, 150, 40
+    dtype = torch.float16
+    qkv = rnd((S, (H + 2 * KV) * D), dtype, 65)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    out = torch.empty(S, H * D, dtype=dtype)
+    cu = torch.tensor([0, S], dtype=torch.int32)
+    ops.attention(q, k, v, out, cu, cu, S, H, KV, D, D ** -0.5, True, True, window=Wn)
+    qs = q.float().view(S, H, D).transpose(0, 1)
+    ks = k.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H, 0)
+    vs = v.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H, 0)
+    i, j = torch.arange(S)[:, None], torch.arange(S)[None, :]
+    sc = (qs @ ks.transpose(-1, -2) * D ** -0.5).masked_fill(~((j <= i) & (i - j < Wn)), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(S, H * D)
+    assert (out.float() - ref).abs().max() <= 4e-3
+
+
+@pytest.mark.parametrize("use_tr", [True, False])
+def test_attention_perceiver_d96_cross(ops, use_tr):
+    """Idefics2 perceiver shape: 64 latent queries against [context; latents] keys, head_dim 96, GQA 4:1, non-causal."""
+    H, KV, D = 4, 1, 96
+    dtype = torch.float16
+    cu_q, cu_k = [0, 64, 128], [0, 64 + 75, 64 + 75 + 64 + 130]
+    q = rnd((128, H * D), dtype, 66)
+    kv = rnd((cu_k[-1], 2 * KV * D), dtype, 67)
+    out = torch.full((128, H * D), float("nan"), dtype=dtype)
+    ops.attention(q, kv[:, :KV * D], kv[:, KV * D:], out, torch.tensor(cu_q, dtype=torch.int32), torch.tensor(cu_k, dtype=torch.int32),
+                  64, H, KV, D, D ** -0.5, False, use_tr)
+    ref = attn_ref(q, kv[:, :KV * D], kv[:, KV * D:], cu_q, cu_k, H, KV, D, D ** -0.5, False)
+    assert (out.float() - ref).abs().max() <= 4e-3
+
+
+def test_gemm_addmat_row_index(ops):
+    """NaViT position ids: row m adds addmat[add_rows[m]]."""
+    M, N, K = 50, 128, 64
+    a, w = rnd((M, K), torch.float16, 90), rnd((N, K), torch.float16, 91, 0.1)
+    table = rnd((16, N), torch.float32, 92)
+    idx = torch.randint(0, 16, (M,), generator=torch.Generator().manual_seed(93)).to(torch.int32)
+    out = torch.empty(M, N)
+    ops.gemm(a, w, out, addmat=table, add_rows=idx, epilogue=_lib.EPI_STORE_F32)
+    assert (out - (a.float() @ w.float().T + table[idx.long()])).abs().max() <= 1e-4
+
+
+def test_preprocess_rectangular_image(ops):
+    n, H, W, P, ldo = 2, 45, 61, 14, 640                       # 3 x 4 patches, remainder pixels dropped
+    pix = rnd((n, 3, H, W), torch.float32, 94)
+    out = torch.full((n * 12, ldo), 7.0, dtype=torch.float16)
+    ops.preprocess_images(pix.contiguous(), out, P)
+    ref = torch.nn.functional.unfold(pix[:, :, :42, :56], kernel_size=P, stride=P).transpose(1, 2).reshape(n * 12, 588)
+    assert torch.equal(out[:, :588].float(), ref.to(torch.float16).float()) and out[:, 588:].abs().max() == 0
+    u8 = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (1, H, W, 3), dtype=np.uint8))
+    out2 = torch.empty(12, ldo, dtype=torch.float16)
+    ops.preprocess_images(u8, out2, P)
+    from leopard_amd.tiler import siglip_normalize
+    ref2 = torch.nn.functional.unfold(torch.from_numpy(siglip_normalize(u8.numpy()))[:, :, :42, :56], kernel_size=P, stride=P)
+    assert torch.equal(out2[:, :588].float(), ref2.transpose(1, 2).reshape(12, 588).to(torch.float16).float())

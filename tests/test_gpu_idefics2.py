@@ -1,0 +1,74 @@
+"""-m gpu: Leopard-Idefics2 (NaViT SigLIP + perceiver + Mistral) through the C ABI vs the Idefics2 CPU oracle, full-width
+layers at reduced depth, two images of different sizes (one is the BASELINE C4 image shape 1344x896 -> 980x653 ->
+3220 patches); plus new-kernel-feature checks at production shapes (sliding window, head_dim 96 cross attention)."""
+import numpy as np
+import pytest
+import torch
+
+from leopard_amd.config import idefics2_mid_config
+from leopard_amd.synth import idefics2_state_dict_numpy, synth_image_u8
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from leopard_amd.ops import Ops
+    return Ops()
+
+
+def test_window_and_d96_kernels(ops):
+    from tests.test_gpu_kernels import attn_ref, rnd
+    dtype = torch.float16
+    H, KV, D, S, Wn = 32, 8, 128, 700, 256
+    qkv = rnd((S, (H + 2 * KV) * D), dtype, 65)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    out = torch.empty(S, H * D, dtype=dtype, device=DEV)
+    cu = torch.tensor([0, S], dtype=torch.int32, device=DEV)
+    ops.attention(q, k, v, out, cu, cu, S, H, KV, D, D ** -0.5, True, True, window=Wn)
+    qs = q.float().view(S, H, D).transpose(0, 1)
+    ks = k.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+    vs = v.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+    i, j = torch.arange(S, device=DEV)[:, None], torch.arange(S, device=DEV)[None, :]
+    sc = (qs @ ks.transpose(-1, -2) * D ** -0.5).masked_fill(~((j <= i) & (i - j < Wn)), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(S, H * D)
+    assert (out.float() - ref).abs().max() <= 3e-3
+    # perceiver cross attention: 64 latent queries x (3220 + 64) keys, 16 q / 4 kv heads x 96
+    H, KV, D = 16, 4, 96
+    cu_q, cu_k = [0, 64, 128], [0, 3284, 3284 + 1000 + 64]
+    qq = rnd((128, H * D), dtype, 66)
+    kv = rnd((cu_k[-1], 2 * KV * D), dtype, 67)
+    for use_tr in (True, False):
+        o = torch.full((128, H * D), float("nan"), dtype=dtype, device=DEV)
+        ops.attention(qq, kv[:, :KV * D], kv[:, KV * D:], o, torch.tensor(cu_q, dtype=torch.int32, device=DEV),
+                      torch.tensor(cu_k, dtype=torch.int32, device=DEV), 64, H, KV, D, D ** -0.5, False, use_tr)
+        ref = attn_ref(qq, kv[:, :KV * D], kv[:, KV * D:], cu_q, cu_k, H, KV, D, D ** -0.5, False)
+        assert (o.float() - ref).abs().max() <= 3e-3, use_tr
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2.5e-3), (torch.bfloat16, 2.0e-2)])
+def test_idefics2_mid_prefill_vs_oracle(ops, dtype, tol):
+    from PIL import Image
+    from leopard_amd.idefics2 import Idefics2Engine, Idefics2SynthSource, Idefics2Weights, preprocess_image_u8
+    from oracle import idefics2_oracle as IO
+    cfg = idefics2_mid_config()
+    ims = [Image.fromarray(synth_image_u8(0, 1344, 896)), Image.fromarray(synth_image_u8(1, 500, 700))]
+    u8 = [preprocess_image_u8(im, cfg.longest_edge) for im in ims]
+    assert u8[0].shape == (653, 980, 3) and u8[1].shape == (700, 500, 3)
+    L = cfg.perceiver_config.n_latents
+    rng = np.random.default_rng(2)
+    text = lambda n: rng.integers(3, 7000, n).tolist()
+    ids = torch.tensor([text(6) + [cfg.image_token_id] * L + text(5) + [cfg.image_token_id] * L + text(20)])
+    W = Idefics2Weights.build(cfg, Idefics2SynthSource(cfg, ops, torch.device(DEV), dtype), dtype)
+    eng = Idefics2Engine(cfg, W, ops=ops, device=torch.device(DEV))
+    res = eng.prefill(ids, [torch.from_numpy(a.copy()) for a in u8], all_logits=True, keep_parts=True)
+    Wt = IO.weights_from_numpy(idefics2_state_dict_numpy(cfg))
+    pix = [IO.image_processor(im, cfg.longest_edge) for im in ims]
+    logits, parts = IO.prefill_logits(ids, pix, Wt, cfg, return_parts=True)
+    f = (res.parts["image_features"].cpu() - parts["image_features"]).abs().max().item() / parts["image_features"].abs().max().item()
+    a = (res.logits_all.cpu() - logits[0]).abs().max().item() / logits.abs().max().item()
+    print(f"[idefics2 mid {dtype}] normalised-max error: image features {f:.2e}, logits {a:.2e} (|logit| max {logits.abs().max():.2f})")
+    assert res.n_tiles == 2 and res.seq_len == ids.shape[1]
+    assert f <= tol and a <= tol
+    assert int(res.logits_last.argmax()) == int(logits[0, -1].argmax())
