@@ -132,6 +132,70 @@ def cpu_baseline(cfg):
     return tflops, t
 
 
+def bench_idefics2(args, dev, dtype, rank, world, D):
+    """BASELINE config 4: Leopard-Idefics2, 4 images of 1344x896 (-> 980x653, 3220 patches, 64 visual tokens each)
+    interleaved in a ~312-token prompt; NaViT SigLIP (27L) + modality projection + perceiver (3L) + Mistral-7B (32L)."""
+    from PIL import Image
+    from leopard_amd.config import idefics2_full_config
+    from leopard_amd.engine import KVCache
+    from leopard_amd.idefics2 import Idefics2Engine, Idefics2SynthSource, Idefics2Weights, preprocess_image_u8
+    from leopard_amd.ops import Ops
+    cfg = idefics2_full_config()
+    ops = Ops()
+    W = Idefics2Weights.build(cfg, Idefics2SynthSource(cfg, ops, dev, dtype), dtype)
+    eng = Idefics2Engine(cfg, W, ops=ops, device=dev)
+    n_img = 4
+    imgs = [torch.from_numpy(preprocess_image_u8(Image.fromarray(synth_image_u8(rank * 16 + i, 1344, 896)), cfg.longest_edge).copy()).to(dev)
+            for i in range(n_img)]
+    L = cfg.perceiver_config.n_latents
+    rng = np.random.default_rng(rank)
+    ids = []
+    for _ in range(n_img):
+        ids += rng.integers(3, 32000, 6).tolist() + [cfg.image_token_id] * L
+    ids += rng.integers(3, 32000, 32).tolist()
+    ids = torch.tensor([ids])
+    S = ids.shape[1]
+    cache = KVCache(cfg, S, dtype, dev)
+
+    def step():
+        cache.length = 0
+        return eng.prefill(ids, imgs, cache=cache)
+
+    def barrier():
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(res.logits_last).all()
+    v, t, pc = cfg.vision_config, cfg.text_config, cfg.perceiver_config
+    P, d, ff, Dt = 3220, v.hidden_size, v.intermediate_size, t.hidden_size
+    vit = 2 * P * v.patch_dim * d + v.num_hidden_layers * (2 * P * (4 * d * d + 2 * d * ff) + 4 * P * P * d)
+    mp = 2 * P * (2 * d * t.intermediate_size + t.intermediate_size * Dt)
+    qd, kd = pc.n_heads * pc.head_dim, pc.num_key_value_heads * pc.head_dim
+    perc = pc.depth * (2 * L * Dt * qd + 2 * (P + L) * Dt * 2 * kd + 4 * L * (P + L) * qd + 2 * L * qd * Dt + 2 * L * 3 * Dt * 4 * Dt)
+    qkv = Dt * (t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim
+    llm = t.num_hidden_layers * (2 * S * (qkv + Dt * Dt + 3 * Dt * t.intermediate_size) + 2 * t.num_attention_heads * t.head_dim * S * (S + 1)) + 2 * Dt * t.vocab_size
+    total = n_img * (vit + mp + perc) + llm
+    out = {"metric": "multi-image prefill images/sec (Leopard-Idefics2, 4x1344x896 per sample)",
+           "value": round(world * n_img * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"C4: 4x(1344x896) -> 980x653, 3220 patches each, 64 visual tokens each, S={S}; NaViT SigLIP (27L) + "
+                                  "perceiver (3L) + Mistral-7B (32L) prefill to last-token logits; synthetic seeded weights",
+                      "parallelism": f"sample-sharded x{world}"},
+           "algorithmic_tflop_per_step": round(total / 1e12, 2),
+           "prefill_mfma_frac": round(total / 1e12 / (elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +205,8 @@ def main():
     ap.add_argument("--images", type=int, default=6)
     ap.add_argument("--width", type=int, default=1344)
     ap.add_argument("--height", type=int, default=896)
+    ap.add_argument("--workload", default="llava-c3", choices=["llava-c3", "idefics2-c4"],
+                    help="llava-c3 = the BASELINE metric's configuration (default); idefics2-c4 = Leopard-Idefics2, 4 x 1344x896")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent samples in flight per GPU, each on its own HIP stream (1 = the reference's one-sample-at-a-time loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,6 +228,8 @@ def main():
     from leopard_amd.ops import Ops
     from leopard_amd.weights import EngineWeights, SynthSource
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if args.workload == "idefics2-c4":
+        return bench_idefics2(args, dev, dtype, rank, world, D)
     cfg = full_config()
     ops = Ops()
     t0 = time.perf_counter()

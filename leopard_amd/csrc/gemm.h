@@ -106,19 +106,23 @@ LMI_DEV void gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, in
 }
 
 // ---- epilogue shared by every geometry: lane owns row m = .. + fr and 4 consecutive n per accumulator quad -----
+// Written so that hipcc can batch the memory operations: the per-lane bias quads are loaded once, and for each output
+// row all residual / position-table loads are issued back to back before the first use (a per-quad load -> wait -> store
+// chain costs a full memory round trip per quad: 32 serialized round trips per lane on a 128x64 wave tile).
 template <typename T, int EPI, int ACT, typename C>
 LMI_DEV void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[C::NI][C::MI], int m0, int n0, int wm, int wn, int fr, int fh) {
     typedef typename vec_of<T>::x4 T4;
+    const int nw0 = n0 + wn * C::WTN;                                   // first column of this wave
+    if (EPI == EPI_SWIGLU_T) {
+        // W rows are interleaved in 32-row blocks [gate | up]: accumulator ni = 2j holds gate, 2j+1 holds up
 #pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi) {
-        const int m = m0 + wm * C::WTM + mi * 32 + fr;
-        if (m >= p.M) continue;
-        const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
-        if (EPI == EPI_SWIGLU_T) {
-            // W rows are interleaved in 32-row blocks [gate | up]: accumulator ni = 2j holds gate, 2j+1 holds up
+        for (int mi = 0; mi < C::MI; ++mi) {
+            const int m = m0 + wm * C::WTM + mi * 32 + fr;
+            if (m >= p.M) continue;
+            const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
 #pragma unroll
             for (int nj = 0; nj < C::NI / 2; ++nj) {
-                const int nb = n0 + wn * C::WTN + nj * 64;
+                const int nb = nw0 + nj * 64;
                 if (nb >= p.N) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -128,34 +132,85 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[C::NI][C::MI], int m
                     *(T4*)((T*)p.out + orow * p.ldo + (nb >> 1) + q * 8 + fh * 4) = v;
                 }
             }
-        } else {
+        }
+        return;
+    }
+    // columns of this lane: n(ni, q) = nw0 + ni*32 + q*8 + fh*4 ; valid while the 32-column block starts below N
+    f32x4 bias[C::NI][4];
 #pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni) {
-                const int nb = n0 + wn * C::WTN + ni * 32;
-                if (nb >= p.N) continue;
+    for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = nb + q * 8 + fh * 4;
-                    f32x4 v;
+        for (int q = 0; q < 4; ++q) {
+            const int n = nw0 + ni * 32 + q * 8 + fh * 4;
+            bias[ni][q] = (p.bias && nw0 + ni * 32 < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][q * 4 + e];
-                    if (p.bias) v += *(const f32x4*)(p.bias + n);
-                    if (p.addmat) v += *(const f32x4*)(p.addmat + (long)(p.add_rows ? p.add_rows[m] : m % p.add_period) * p.N + n);
+    for (int mi = 0; mi < C::MI; ++mi) {
+        const int m = m0 + wm * C::WTM + mi * 32 + fr;
+        if (m >= p.M) continue;
+        const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
+        f32x4 v[C::NI][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
-                    if (EPI == EPI_STORE_T) {
+        for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[ni][q][e] = acc[ni][mi][q * 4 + e];
+                v[ni][q] += bias[ni][q];
+            }
+        if (p.addmat) {                                                  // SigLIP position table (patch-embed GEMM only)
+            const float* arow = p.addmat + (long)(p.add_rows ? p.add_rows[m] : m % p.add_period) * p.N;
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)
+                if (nw0 + ni * 32 < p.N) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[ni][q] += *(const f32x4*)(arow + nw0 + ni * 32 + q * 8 + fh * 4);
+                }
+        }
+        if (ACT != ACT_NONE) {
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[ni][q][e] = act_apply(v[ni][q][e], ACT);
+        }
+        if (EPI == EPI_RESID_F32) {
+            float* drow = (float*)p.out + orow * p.ldo;
+            f32x4 old[C::NI][4];
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)                            // all residual loads first ...
+                if (nw0 + ni * 32 < p.N) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) old[ni][q] = *(const f32x4*)(drow + nw0 + ni * 32 + q * 8 + fh * 4);
+                }
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)                            // ... then the adds and stores
+                if (nw0 + ni * 32 < p.N) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(f32x4*)(drow + nw0 + ni * 32 + q * 8 + fh * 4) = old[ni][q] + v[ni][q];
+                }
+        } else if (EPI == EPI_STORE_T) {
+            T* drow = (T*)p.out + orow * p.ldo;
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)
+                if (nw0 + ni * 32 < p.N) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
                         T4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
-                        *(T4*)((T*)p.out + orow * p.ldo + n) = o;
-                    } else if (EPI == EPI_RESID_F32) {
-                        f32x4* dst = (f32x4*)((float*)p.out + orow * p.ldo + n);
-                        *dst = *dst + v;
-                    } else {
-                        *(f32x4*)((float*)p.out + orow * p.ldo + n) = v;
+                        for (int e = 0; e < 4; ++e) o[e] = (T)v[ni][q][e];
+                        *(T4*)(drow + nw0 + ni * 32 + q * 8 + fh * 4) = o;
                     }
                 }
-            }
+        } else {
+            float* drow = (float*)p.out + orow * p.ldo;
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)
+                if (nw0 + ni * 32 < p.N) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(f32x4*)(drow + nw0 + ni * 32 + q * 8 + fh * 4) = v[ni][q];
+                }
         }
     }
 }
