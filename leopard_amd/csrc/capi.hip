@@ -57,10 +57,12 @@ typedef GemmCfg<128, 256, 2, 4, 3> Cfg4;   // 144 KiB LDS, wave tile 64x64, 3-sl
 constexpr int kNumGemmCfg = 8;              // 0-4 ring geometries; 5-7 staggered 256x256 schedules
 int g_gemm_cfg = -1;                        // -1 = choose per shape
 int g_gemm_group_m = GEMM_GROUP_M;
+int g_gemm_order = 0;
 
 template <typename T, int EPI, int ACT, int AMODE, typename C>
 int launch_gemm_cfg(const GemmArgs& a, void* stream) {
-    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    if (a.order == 1) tiles = (tiles + 255) / 256 * 256;
     static bool attr_set = false;
     if (!attr_set) { allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE, C>, C::SMEM); attr_set = true; }
     LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
@@ -69,7 +71,8 @@ int launch_gemm_cfg(const GemmArgs& a, void* stream) {
 
 template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR>
 int launch_gemm_stagger(const GemmArgs& a, void* stream) {
-    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    if (a.order == 1) tiles = (tiles + 255) / 256 * 256;
     static bool attr_set = false;
     if (!attr_set) { allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>, C::SMEM); attr_set = true; }
     LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
@@ -237,6 +240,7 @@ int lmi_set_option(const char* key, int value) {
         g_gemm_group_m = value;
         return LMI_OK;
     }
+    if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
     return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);
 }
@@ -301,7 +305,7 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
     if (M == 0) return LMI_OK;
     GemmArgs a;
     a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.add_rows = add_rows; a.row_map = row_map;
-    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
     LMI_DISPATCH_T(dtype, dispatch_gemm<f16_t>(a, epilogue, act, a_mode, stream),
                    dispatch_gemm<bf16_t>(a, epilogue, act, a_mode, stream));
 }

@@ -47,6 +47,7 @@ struct GemmArgs {
     int add_period;
     int ps_grid;          // pixel-shuffle: G (26); output tokens per tile = (G/2)^2; C = K/4
     int group_m;          // row-tiles per L2 group in the XCD-aware tile order
+    int order;            // 0 = each XCD owns a contiguous slab of the grouped order; 1 = XCDs take 32-tile chunks round-robin
 };
 
 constexpr int GEMM_BK = 64;
@@ -90,12 +91,23 @@ LMI_DEV float act_apply(float x, int act) {
 // byte offset of logical 16-byte chunk `lc` of row `r` inside a [rows][64] 16-bit tile (128-byte rows)
 LMI_DEV int gemm_lds_off(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); }
 
-// XCD-aware, grouped tile order (bijective for any tile count)
-LMI_DEV void gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+// XCD-aware, grouped tile order.  Tiles are linearised in groups of `group_m` row-tiles, row-tile fastest, so that 32
+// consecutive ids form an (8 x 4)-tile patch whose A / W panels one XCD's 4 MiB L2 can hold.  Workgroup b runs on XCD
+// b % 8 (observed dispatch; speed only).  order 0: XCD x owns the x-th contiguous eighth of the linear order (bijective
+// for any tile count).  order 1: the XCDs take 32-tile patches round-robin, so at any time all eight work on
+// neighbouring patches of the SAME row-tile group and share its A panel through the Infinity Cache; the grid is rounded
+// up to a multiple of 256 workgroups and surplus workgroups exit.  Returns false for a surplus workgroup.
+LMI_DEV bool gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, int order, int& tm, int& tn) {
     const int nwg = tiles_m * tiles_n;
-    const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int swz;
+    if (order == 1) {
+        swz = ((idx >> 5) * 8 + xcd) * 32 + (idx & 31);
+        if (swz >= nwg) return false;
+    } else {
+        const int q = nwg >> 3, r = nwg & 7;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int per_group = group_m * tiles_n;
     const int g = swz / per_group;
     const int first_m = g * group_m;
@@ -103,6 +115,7 @@ LMI_DEV void gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, in
     const int in_g = swz - g * per_group;
     tm = first_m + in_g % gsize;
     tn = in_g / gsize;
+    return true;
 }
 
 // ---- epilogue shared by every geometry: lane owns row m = .. + fr and 4 consecutive n per accumulator quad -----
@@ -225,7 +238,7 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = (p.N + C::BN - 1) / C::BN;
     int tm, tn;
-    gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, tm, tn);
+    if (!gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn)) return;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
     // ---- per-thread staging sources: one row per pass; the 16-byte chunk position is fixed per thread ----------
@@ -347,7 +360,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = (p.N + C::BN - 1) / C::BN;
     int tm, tn;
-    gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, tm, tn);
+    if (!gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn)) return;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
     const int srow = tid >> 3, pc = tid & 7;
@@ -407,6 +420,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     wait_vmcnt_barrier<0>();
     if (grp == 1) raw_barrier();                                   // waves 4-7 run one barrier behind
 
+    constexpr bool DMA_IN_MFMA = (VAR == 2);
     for (int t = 0; t < nt; ++t) {
         const char* a_t = smem + (t & 1) * C::STAGE_BYTES;
         const char* w_t = a_t + C::A_BYTES;
@@ -432,9 +446,9 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
 #pragma unroll
                 for (int mi = 0; mi < C::MI; ++mi) {
                     acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
-                    // VAR 2: the LDS-DMA pieces of tile t+1 ride in the issue slots between the MFMAs of k-steps 0, 1
+                    // the LDS-DMA pieces of tile t+1 ride in the issue slots between the MFMAs of k-steps 0, 1
                     const int idx = ni * C::MI + mi, g = ks * (C::G / 2) + (idx >> 1);    // compile-time after unrolling
-                    if (VAR == 2 && ks < 2 && (idx & 1) && (idx >> 1) < C::G / 2 && do_issue) issue_piece(g, t + 1, (t + 1) & 1);
+                    if (DMA_IN_MFMA && ks < 2 && (idx & 1) && (idx >> 1) < C::G / 2 && do_issue) issue_piece(g, t + 1, (t + 1) & 1);
                 }
             if (VAR == 0) setprio_lo();
             sched_fence();

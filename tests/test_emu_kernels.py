@@ -372,3 +372,20 @@ def test_preprocess_rectangular_image(ops):
     from leopard_amd.tiler import siglip_normalize
     ref2 = torch.nn.functional.unfold(torch.from_numpy(siglip_normalize(u8.numpy()))[:, :, :42, :56], kernel_size=P, stride=P)
     assert torch.equal(out2[:, :588].float(), ref2.transpose(1, 2).reshape(12, 588).to(torch.float16).float())
+
+
+def test_gemm_tile_order_round_robin(ops):
+    """gemm.order = 1 (XCDs take 32-tile patches round-robin; surplus workgroups of the rounded-up grid exit)."""
+    ops.set_option("gemm.order", 1)
+    try:
+        for cfg in (0, 7):
+            ops.set_option("gemm.config", cfg)
+            M, N, K = 700, 640, 128
+            a, w = rnd((M, K), torch.float16, 95), rnd((N, K), torch.float16, 96, 0.1)
+            out = torch.full((M, N), float("nan"), dtype=torch.float16)
+            ops.gemm(a, w, out)
+            ref = a.float() @ w.float().T
+            assert (out.float() - ref).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item())
+    finally:
+        ops.set_option("gemm.order", 0)
+        ops.set_option("gemm.config", -1)

@@ -47,6 +47,7 @@ def bench_gemm(args):
     total = {c: 0.0 for c in cfgs}
     if args.group_m:
         ops.set_option("gemm.group_m", args.group_m)
+    ops.set_option("gemm.order", args.order)
     shapes = GEMM_SHAPES if args.only < 0 else [GEMM_SHAPES[args.only]]
     for name, M, N, K, epi, act in shapes:
         a = (torch.randn(M, K, generator=g)).to(dtype).to(DEV)
@@ -117,6 +118,7 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--group-m", type=int, default=0)
+    ap.add_argument("--order", type=int, default=0)
     ap.add_argument("--only", type=int, default=-1, help="index of a single GEMM shape")
     a = ap.parse_args()
     bench_gemm(a) if a.what == "gemm" else bench_attn(a)
