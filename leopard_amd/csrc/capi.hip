@@ -54,7 +54,9 @@ typedef GemmCfg<256, 256, 2, 4, 2> Cfg1;   // 128 KiB LDS, 512 threads, wave til
 typedef GemmCfg<256, 128, 4, 2, 3> Cfg2;   // 144 KiB LDS, 512 threads, wave tile 64x64, 3-slot ring
 typedef GemmCfg<256, 128, 4, 2, 2> Cfg3;   //  96 KiB LDS
 typedef GemmCfg<128, 256, 2, 4, 3> Cfg4;   // 144 KiB LDS, wave tile 64x64, 3-slot ring
-constexpr int kNumGemmCfg = 8;              // 0-4 ring geometries; 5-7 staggered 256x256 schedules
+typedef GemmCfg<64, 128, 2, 2, 3> CfgS;    //  72 KiB LDS, 256 threads, wave tile 32x64: small-M problems
+typedef GemmCfg<64, 128, 2, 2, 6> CfgS6;   // 144 KiB LDS: 5 k-tiles in flight for latency-bound weight streaming at small M
+constexpr int kNumGemmCfg = 10;             // 0-4 ring geometries; 5-7 staggered 256x256 schedules
 int g_gemm_cfg = -1;                        // -1 = choose per shape
 int g_gemm_group_m = GEMM_GROUP_M;
 int g_gemm_order = 0;
@@ -83,7 +85,7 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
 // staggered 256x256 schedule; narrow-N / deep-K (SigLIP fc2) the 256x128 3-slot ring; small problems 128x128.
 int choose_gemm_cfg(const GemmArgs& a) {
     if (g_gemm_cfg >= 0) return g_gemm_cfg;
-    if (a.M < 512) return 0;
+    if (a.M < 512) return 8;
     if (a.N >= 2048) return 7;
     if (a.K >= 2048) return 2;
     return 0;
@@ -99,6 +101,8 @@ int launch_gemm(const GemmArgs& a, void* stream) {
         case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 0>(a, stream);   // setprio, DMA in LOAD segments
         case 6: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 1>(a, stream);   // DMA in LOAD segments
         case 7: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 2>(a, stream);   // DMA between MFMAs (production)
+        case 8: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgS>(a, stream);
+        case 9: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgS6>(a, stream);
         default: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg0>(a, stream);
     }
 }
@@ -138,20 +142,38 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
                AttnGeom<D>::SMEM, stream, a);
     return check_launch("lmi_attn_varlen_fwd");
 }
-int g_attn_dma = 1;                          // 1 = LDS-DMA kernel (production), 0 = register-staged kernel
+int g_attn_lds_pad = 0;                      // experiment knob: extra dynamic LDS per workgroup (lowers residency)
+int g_attn_dma = 1;                          // 2 = software-pipelined LDS-DMA kernel (production), 1 = plain LDS-DMA kernel,
+                                             // 0 = register-staged kernel (cross-checks)
 
 template <typename T, int D, bool CAUSAL>
 int launch_attn_dma(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     const int qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
     static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(attn_fwd_dma_kernel<T, D, CAUSAL>, AttnDmaGeom<D>::SMEM); attr_set = true; }
-    LMI_LAUNCH((attn_fwd_dma_kernel<T, D, CAUSAL>), dim3(qblocks, a.n_heads, n_seq), dim3(ATT_THREADS),
-               AttnDmaGeom<D>::SMEM, stream, a);
+    if (!attr_set) { allow_big_lds(attn_fwd_dma_kernel<T, D, CAUSAL>, 160 * 1024); attr_set = true; }
+    AttnArgs b = a;
+    b.n_qblocks = qblocks;
+    LMI_LAUNCH((attn_fwd_dma_kernel<T, D, CAUSAL>), dim3(qblocks * a.n_heads * n_seq), dim3(ATT_THREADS),
+               AttnDmaGeom<D>::SMEM + g_attn_lds_pad, stream, b);
+    return check_launch("lmi_attn_varlen_fwd");
+}
+
+template <typename T, int D, bool CAUSAL>
+int launch_attn_pipe(const AttnArgs& a, int n_seq, int max_q, void* stream) {
+    const int qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
+    static bool attr_set = false;
+    if (!attr_set) { allow_big_lds(attn_fwd_pipe_kernel<T, D, CAUSAL>, 160 * 1024); attr_set = true; }
+    AttnArgs b = a;
+    b.n_qblocks = qblocks;
+    LMI_LAUNCH((attn_fwd_pipe_kernel<T, D, CAUSAL>), dim3(qblocks * a.n_heads * n_seq), dim3(ATT_THREADS),
+               AttnDmaGeom<D>::SMEM + g_attn_lds_pad, stream, b);
     return check_launch("lmi_attn_varlen_fwd");
 }
 
 template <typename T, int D>
 int dispatch_attn(const AttnArgs& a, int n_seq, int max_q, int causal, int use_tr, void* stream) {
+    if (use_tr && g_attn_dma == 2)
+        return causal ? launch_attn_pipe<T, D, true>(a, n_seq, max_q, stream) : launch_attn_pipe<T, D, false>(a, n_seq, max_q, stream);
     if (use_tr && g_attn_dma)
         return causal ? launch_attn_dma<T, D, true>(a, n_seq, max_q, stream) : launch_attn_dma<T, D, false>(a, n_seq, max_q, stream);
     if (causal) return use_tr ? launch_attn<T, D, true, true>(a, n_seq, max_q, stream)
@@ -241,7 +263,8 @@ int lmi_set_option(const char* key, int value) {
         return LMI_OK;
     }
     if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
-    if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "attn.dma")) { g_attn_dma = value < 0 ? 0 : (value > 2 ? 2 : value); return LMI_OK; }
+    if (!strcmp(key, "attn.lds_pad")) { g_attn_lds_pad = value < 0 ? 0 : (value > 90 * 1024 ? 90 * 1024 : value); return LMI_OK; }
     return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);
 }
 
@@ -324,7 +347,7 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
     if (n_seq == 0 || max_seqlen_q == 0) return LMI_OK;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
-    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
     if (head_dim == 128)
         LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
                        (dispatch_attn<bf16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));

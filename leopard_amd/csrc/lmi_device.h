@@ -78,6 +78,20 @@ LMI_DEV u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
+// compiler-tracked form (no wait inside): hipcc counts it in lgkmcnt like any other LDS load, so a batch issued early
+// is waited for only where its result is first used
+LMI_DEV u32x2 ds_read_tr16_b64_async(const void* lds_ptr) {
+    typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
+    const s16x4v r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)lds_ptr);
+    return __builtin_bit_cast(u32x2, r);
+}
+// keep a value materialised at this point of the program (stops hipcc from sinking its computation into a later block)
+template <typename V> LMI_DEV void pin_here(V& v) { asm volatile("" : "+v"(v)); }
+// scheduling-group hints (LLVM igrouplp): one group of `n` instructions of a class, in program order of the hints
+#define LMI_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define LMI_SCHED_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+#define LMI_SCHED_DSREAD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+
 // Batched form used by attention: for d-block i = 0..N-1 read the 4-key groups at byte offsets i*64 and
 // i*64 + ROW8 from one base address, one wait for all 2N reads.  out[i] = {lo.x, lo.y, hi.x, hi.y}.
 template <int N, int ROW8>
@@ -163,9 +177,17 @@ LMI_DEV void ds_read_tr16_gather(const void* base, const int (&off)[N], int imm,
 LMI_DEV float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 LMI_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 LMI_DEV float shfl(float v, int l) { return __shfl(v, l, 64); }
+// v_permlane32_swap_b32: lanes 32..63 of `a` trade places with lanes 0..31 of `b` (no LDS round trip)
+LMI_DEV void swap_hi_lo(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+LMI_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 LMI_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 LMI_DEV void setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 LMI_DEV void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
+// HW_ID[3:0]: this wave's slot on its SIMD (co-resident waves of a SIMD have distinct slots)
+LMI_DEV int hw_wave_slot() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); }
 LMI_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 LMI_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 LMI_DEV float fexp(float x) { return __expf(x); }
@@ -246,6 +268,12 @@ inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
+inline u32x2 ds_read_tr16_b64_async(const void* lds_ptr) { return ds_read_tr16_b64(lds_ptr); }
+template <typename V> inline void pin_here(V&) {}
+#define LMI_SCHED_MFMA(n) ((void)0)
+#define LMI_SCHED_VALU(n) ((void)0)
+#define LMI_SCHED_DSREAD(n) ((void)0)
+
 template <int N, int ROW8>
 inline void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
     for (int i = 0; i < N; ++i) {
@@ -276,9 +304,19 @@ inline S emu_shfl_idx(S v, int src) {
 inline float shfl_xor(float v, int m) { return emu_shfl_idx(v, lane_id() ^ m); }
 inline int shfl_xor(int v, int m) { return emu_shfl_idx(v, lane_id() ^ m); }
 inline float shfl(float v, int l) { return emu_shfl_idx(v, l); }
+inline void swap_hi_lo(unsigned& a, unsigned& b) {
+    const unsigned ta = (unsigned)emu_shfl_idx((int)a, lane_id() ^ 32), tb = (unsigned)emu_shfl_idx((int)b, lane_id() ^ 32);
+    if (lane_id() < 32) b = ta; else a = tb;
+}
+inline bool wave_any(bool p) {
+    int v = p ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v |= emu_shfl_idx(v, lane_id() ^ m);
+    return v != 0;
+}
 inline void sched_fence() {}
 inline void setprio_hi() {}
 inline void setprio_lo() {}
+inline int hw_wave_slot() { return 0; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fexp(float x) { return expf(x); }
@@ -297,6 +335,23 @@ LMI_DEV int imin(int a, int b) { return a < b ? a : b; }
 LMI_DEV int imax(int a, int b) { return a > b ? a : b; }
 template <typename T> LMI_DEV float to_f32(T v) { return (float)v; }
 template <typename T> LMI_DEV T from_f32(float v) { return (T)v; }
+// two fp32 -> one dword of two T (x in the low half)
+template <typename T> LMI_DEV unsigned pack2(float x, float y) {
+    typename vec_of<T>::x2 v;
+    v[0] = (T)x; v[1] = (T)y;
+    return __builtin_bit_cast(unsigned, v);
+}
+// reductions across the two half-wave partners (lane, lane ^ 32): both lanes get the result
+LMI_DEV float xhalf_max(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    swap_hi_lo(a, b);
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+LMI_DEV float xhalf_sum(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    swap_hi_lo(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
 
 LMI_DEV float wave_sum(float v) {
 #pragma unroll

@@ -17,16 +17,35 @@ import torch.distributed as dist
 
 
 def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
-    """Initialise the default process group from the torchrun environment.  Returns (rank, world)."""
+    """Initialise the default process group from the torchrun environment.  Returns (rank, world).
+    backend None = RCCL ("nccl") when a GPU is present, with gloo as the fallback if RCCL cannot come up: the data path has
+    no collective (sample sharding), so the group only carries the barrier and the max-over-ranks timing reduce."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        want = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if want == "nccl":
+            try:
+                kw = {"device_id": device} if device is not None else {}
+                dist.init_process_group("nccl", rank=rank, world_size=world, **kw)
+                probe = torch.zeros(1, device=device if device is not None else "cuda")
+                dist.all_reduce(probe)                              # force communicator creation now, not in the timed region
+                torch.cuda.synchronize()
+            except Exception as e:                                  # pragma: no cover  (needs a multi-GPU node)
+                print(f"[leopard_amd.dist] RCCL init failed on rank {rank} ({e!r}); falling back to gloo", flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(want, rank=rank, world_size=world)
     return rank, world
+
+
+def _reduce_device(device):
+    """gloo reduces host tensors; RCCL reduces device tensors."""
+    return "cpu" if dist.get_backend() == "gloo" else device
 
 
 def world_size() -> int:
@@ -41,7 +60,7 @@ def barrier() -> None:
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized():
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -80,6 +99,11 @@ def encode_images_sharded(engine, tiles: torch.Tensor) -> torch.Tensor:
     if hi > lo:
         mine[:(hi - lo) * tpt] = engine.encode_images(tiles[lo:hi].contiguous())
     gathered = torch.empty(world * max_rows, D, dtype=torch.float32, device=tiles.device)
-    dist.all_gather_into_tensor(gathered, mine)                  # equal-size padded shards, one collective
+    if dist.get_backend() == "gloo" and tiles.device.type == "cuda":            # fallback group: stage through the host
+        host = torch.empty(world * max_rows, D, dtype=torch.float32)
+        dist.all_gather_into_tensor(host, mine.cpu())
+        gathered.copy_(host)
+    else:
+        dist.all_gather_into_tensor(gathered, mine)              # equal-size padded shards, one collective
     parts = [gathered[r * max_rows:r * max_rows + (b - a) * tpt] for r, (a, b) in enumerate(slices)]
     return torch.cat(parts, dim=0)

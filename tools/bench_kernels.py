@@ -28,6 +28,14 @@ GEMM_SHAPES = [
 ]
 
 
+SMALL_SHAPES = [
+    ("m312 gate/up swiglu", 312, 28672, 4096, _lib.EPI_SWIGLU, 0),
+    ("m312 down  resid", 312, 4096, 14336, _lib.EPI_RESIDUAL, 0),
+    ("m312 qkv   store", 312, 6144, 4096, _lib.EPI_STORE, 0),
+    ("m312 o     resid", 312, 4096, 4096, _lib.EPI_RESIDUAL, 0),
+]
+
+
 def time_fn(fn, iters):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -39,7 +47,7 @@ def time_fn(fn, iters):
 
 
 def bench_gemm(args):
-    ops = Ops()
+    ops = Ops(_lib.bind(args.lib)) if args.lib else Ops()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     cfgs = [int(c) for c in args.cfgs.split(",")]
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -48,7 +56,8 @@ def bench_gemm(args):
     if args.group_m:
         ops.set_option("gemm.group_m", args.group_m)
     ops.set_option("gemm.order", args.order)
-    shapes = GEMM_SHAPES if args.only < 0 else [GEMM_SHAPES[args.only]]
+    base = SMALL_SHAPES if args.small else GEMM_SHAPES
+    shapes = base if args.only < 0 else [base[args.only]]
     for name, M, N, K, epi, act in shapes:
         a = (torch.randn(M, K, generator=g)).to(dtype).to(DEV)
         w = (torch.randn(N, K, generator=g) * 0.02).to(dtype).to(DEV)
@@ -89,8 +98,10 @@ def bench_gemm(args):
 
 
 def bench_attn(args):
-    ops = Ops()
+    ops = Ops(_lib.bind(args.lib)) if args.lib else Ops()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if args.lds_pad:
+        ops.set_option("attn.lds_pad", args.lds_pad)
     g = torch.Generator(device="cpu").manual_seed(0)
     S, H, KV, D = 7187, 32, 8, 128
     qkv = torch.randn(S, (H + 2 * KV) * D, generator=g).to(dtype).to(DEV)
@@ -119,6 +130,9 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--group-m", type=int, default=0)
     ap.add_argument("--order", type=int, default=0)
+    ap.add_argument("--small", action="store_true")
+    ap.add_argument("--lds-pad", type=int, default=0)
+    ap.add_argument("--lib", default="", help="A/B: path of another build of libleopard_amd.so")
     ap.add_argument("--only", type=int, default=-1, help="index of a single GEMM shape")
     a = ap.parse_args()
     bench_gemm(a) if a.what == "gemm" else bench_attn(a)
