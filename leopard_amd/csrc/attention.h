@@ -20,8 +20,14 @@
 //                   row-major V image; O^T's column is q, so the online-softmax rescale is a per-lane scalar.
 // Softmax statistics and accumulators are fp32; P is rounded to the 16-bit compute type for the PV MFMA.
 #pragma once
-#include <type_traits>
 #include "lmi_device.h"
+
+// timing-only ablations of the production attention kernel (tools/_ab builds with -DLMI_ATTN_ABLATE=n; results are wrong)
+#ifdef LMI_ATTN_ABLATE
+#define LMI_ABL(n) (LMI_ATTN_ABLATE == (n))
+#else
+#define LMI_ABL(n) false
+#endif
 
 namespace lmi {
 
@@ -40,6 +46,7 @@ struct AttnArgs {
 };
 
 constexpr int ATT_BQ = 128, ATT_BKV = 64, ATT_THREADS = 256;
+constexpr float ATT_DEFER_LOG2 = 8.0f;        // LDS-DMA kernels: the softmax reference may lag the row maximum by 2^8
 
 template <int D> struct AttnGeom {
     static constexpr int DK = (D + 15) / 16 * 16;            // QK^T contraction length (zero padded)
@@ -281,6 +288,7 @@ template <int D> struct AttnDmaGeom {
 
 template <typename T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p) {
+    constexpr int NW = ATT_THREADS / 64, BQ = ATT_BQ, PPW = AttnDmaGeom<D>::PPW;
     typedef AttnDmaGeom<D> G;
     constexpr int NKS = G::NKS, NDB = G::NDB;
     typedef typename vec_of<T>::x8 T8;
@@ -297,11 +305,11 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     const int kvh = h_idx % p.n_kv_heads, head = kvh * (p.n_heads / p.n_kv_heads) + h_idx / p.n_kv_heads;
     const int q_beg = p.cu_q[seq], len_q = p.cu_q[seq + 1] - q_beg;
     const int k_beg = p.cu_k[seq], len_k = p.cu_k[seq + 1] - k_beg;
-    const int q0 = qb * ATT_BQ;
+    const int q0 = qb * BQ;
     if (q0 >= len_q) return;
     const int shift = len_k - len_q;
     int kv_end = len_k;
-    if (CAUSAL) kv_end = imin(len_k, q0 + ATT_BQ + shift);
+    if (CAUSAL) kv_end = imin(len_k, q0 + BQ + shift);
     const int n_tiles = (kv_end + ATT_BKV - 1) / ATT_BKV;
     const int wave_q_lo = q0 + wave * 32, wave_q_hi = wave_q_lo + 31;
     // tiles this wave computes: the later ones are fully masked for its 32 rows (it still issues its DMA pieces and
@@ -322,27 +330,31 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         }
     }
 
-    // ---- LDS-DMA sources: wave w owns pieces w, w+4, ...; lane l of piece q is chunk q*64+l of the tile image ------
+    // ---- LDS-DMA sources: wave w owns pieces w, w+4, ...; lane l of piece q is chunk q*64+l of the tile image.  K and V of
+    // this (sequence, kv head) are addressed through buffer resources: per-lane byte offsets are loop invariant, the tile
+    // advances a scalar offset, and rows past len_k read as zeros (no address clamp in the loop).
     const T* k_base = (const T*)p.k + (long)k_beg * p.ldk + kvh * D;
     const T* v_base = (const T*)p.v + (long)k_beg * p.ldv + kvh * D;
-    int p_row[G::PPW], p_kc[G::PPW], p_vc[G::PPW];
+    const BufRsrc k_buf = make_buf(k_base, len_k > 0 ? (unsigned)(((long)(len_k - 1) * p.ldk + D) * 2) : 0u);
+    const BufRsrc v_buf = make_buf(v_base, len_k > 0 ? (unsigned)(((long)(len_k - 1) * p.ldv + D) * 2) : 0u);
+    unsigned p_ko[PPW], p_vo[PPW];
 #pragma unroll
-    for (int i = 0; i < G::PPW; ++i) {
-        const int ci = (wave + 4 * i) * 64 + lane;
+    for (int i = 0; i < PPW; ++i) {
+        const int ci = (wave + NW * i) * 64 + lane;
         const int r = ci / G::CH, c = ci - r * G::CH;
-        p_row[i] = r;
-        p_kc[i] = G::SWZ ? (c ^ (r & 15)) : c;
-        p_vc[i] = G::SWZ ? (c ^ ((r & 3) << 2)) : c;
+        p_ko[i] = (unsigned)(r * p.ldk + ((G::SWZ ? (c ^ (r & 15)) : c) << 3)) * 2u;
+        p_vo[i] = (unsigned)(r * p.ldv + ((G::SWZ ? (c ^ ((r & 3) << 2)) : c) << 3)) * 2u;
     }
     auto issue_tile = [&](int t, int slot) {
         char* kdst = smem + slot * 2 * G::TILE_BYTES;
         char* vdst = kdst + G::TILE_BYTES;
+        const unsigned k_so = (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldk;
+        const unsigned v_so = (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldv;
 #pragma unroll
-        for (int i = 0; i < G::PPW; ++i) {
-            if (wave + 4 * i < G::PIECES) {                       // wave-uniform
-                const int key = imin(t * ATT_BKV + p_row[i], len_k - 1);
-                glds16(k_base + (long)key * p.ldk + (p_kc[i] << 3), kdst + (wave + 4 * i) * 1024);
-                glds16(v_base + (long)key * p.ldv + (p_vc[i] << 3), vdst + (wave + 4 * i) * 1024);
+        for (int i = 0; i < PPW; ++i) {
+            if (wave + NW * i < G::PIECES) {                      // wave-uniform
+                if (!LMI_ABL(4) || t < 2) glds16_buf(k_buf, p_ko[i], k_so, kdst + (wave + NW * i) * 1024);
+                if (!LMI_ABL(4) || t < 2) glds16_buf(v_buf, p_vo[i], v_so, vdst + (wave + NW * i) * 1024);
             }
         }
     };
@@ -370,15 +382,15 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     for (int db = 0; db < NDB; ++db)
         v_off[db] = (4 * fh + tr_j) * G::ROWB + ((G::SWZ ? (db ^ tr_j) : db) << 6) + tr_half * 32 + tr_g * 8;
 
-    // The two workgroups that share a CU run the same loop at the same pace; with equal priority their waves on a SIMD
-    // stay phase-locked (both in the MFMA segment, then both in softmax).  A static priority by hardware wave slot parity
-    // lets one of them run unimpeded and pushes the other into the complementary phase.
-    if (hw_wave_slot() & 1) setprio_hi();
     issue_tile(0, 0);
     int t = 0;
+    LMI_PROF_DECL();
     for (; t < my_tiles; ++t) {
+        LMI_PROF_MARK(0);
         wait_vmcnt_barrier<0>();                                   // tile t landed; slot of tile t-1 is free
+        LMI_PROF_MARK(1);
         if (t + 1 < n_tiles) issue_tile(t + 1, (t + 1) & 1);
+        LMI_PROF_MARK(2);
         const int kv0 = t * ATT_BKV;
         const char* k_lds = smem + (t & 1) * 2 * G::TILE_BYTES;
         const char* v_lds = k_lds + G::TILE_BYTES;
@@ -388,14 +400,23 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+        sched_fence();
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const T8 kf = *(const T8*)(k_lds + b * 32 * G::ROWB + k_off[ks]);
-                s[b] = mfma32(kf, qf[ks], s[b]);
+                if (!LMI_ABL(2)) s[b] = mfma32(kf, qf[ks], s[b]); else s[b][ks] += (float)kf[0];
             }
         }
+        // K fragment reads run three MFMA pairs ahead of their use
+        LMI_SCHED_DSREAD(6);
+#pragma unroll
+        for (int i = 0; i < NKS - 3; ++i) { LMI_SCHED_MFMA(2); LMI_SCHED_DSREAD(2); }
+        LMI_SCHED_MFMA(6);
+        sched_fence();
+        LMI_PROF_TOUCH(s[0][15]); LMI_PROF_TOUCH(s[1][15]);
+        LMI_PROF_MARK(3);
         const bool need_mask = (kv0 + ATT_BKV > len_k) || (CAUSAL && (kv0 + ATT_BKV - 1 > wave_q_lo + shift)) ||
                                (CAUSAL && p.window > 0 && kv0 <= wave_q_hi + shift - p.window);
         if (need_mask) {
@@ -415,41 +436,60 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][r]);
         mx = xhalf_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        // rescale only when some row of this wave moved its maximum (wave-uniform branch: rows that did not get alpha = 1)
-        if (wave_any(m_new != m_run)) {
-            const float alpha = fast_exp2((m_run - m_use) * c2);
+        // Deferred rescale: m_run is the reference the exponentials are taken against, not necessarily the true running
+        // maximum.  It moves (and O, l are rescaled, wave-uniformly) only when some row of the wave outgrew it by more
+        // than 2^ATT_DEFER_LOG2, so P stays <= 2^ATT_DEFER_LOG2 (exact in the 16-bit P and the fp32 sums) and the 64
+        // multiplies per tile disappear from all but the first few tiles of a row block.
+        const float m_cand = fmaxf(m_run, mx);
+        if (wave_any((m_cand - m_run) * c2 > ATT_DEFER_LOG2)) {     // -inf - -inf = NaN compares false: nothing seen yet
+            const float alpha = fast_exp2((m_run - ((m_cand == -INFINITY) ? 0.f : m_cand)) * c2);
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < NDB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+            m_run = m_cand;
         }
-        m_run = m_new;
-        const float mc = m_use * c2;
+        const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * c2;
+        LMI_PROF_TOUCH(o_acc[0][0]);
+        LMI_PROF_MARK(4);
+        // V^T fragments, one 16-key group at a time, double buffered; group 0 is requested before the exponentials
+        u32x2 vlo[2][NDB], vhi[2][NDB];
+        tr16_issue<NDB, 8 * G::ROWB>(v_lds, v_off, 0, vlo[0], vhi[0]);
         float psum = 0.f;
         T8 pf[2][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(s[b][r] * c2 - mc);
+                const float pv = LMI_ABL(1) ? s[b][r] : fast_exp2(s[b][r] * c2 - mc);
                 psum += pv;
                 pf[b][r >> 3][r & 7] = (T)pv;
             }
         l_run += psum;
+        LMI_PROF_TOUCH(psum);
+        LMI_PROF_MARK(5);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                u32x4 vraw[NDB];
-                ds_read_tr16_gather<NDB, 8 * G::ROWB>(v_lds, v_off, (b * 32 + 16 * u) * G::ROWB, vraw);
-#pragma unroll
-                for (int db = 0; db < NDB; ++db)
-                    o_acc[db] = mfma32(__builtin_bit_cast(T8, vraw[db]), pf[b][u], o_acc[db]);
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+                tr16_issue<NDB, 8 * G::ROWB>(v_lds, v_off, (g + 1) * 16 * G::ROWB, vlo[(g + 1) & 1], vhi[(g + 1) & 1]);
+                lgkm_fence<2 * NDB>(vlo[g & 1], vhi[g & 1]);
+            } else {
+                lgkm_fence<0>(vlo[g & 1], vhi[g & 1]);
             }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const u32x4 a = u32x4{vlo[g & 1][db][0], vlo[g & 1][db][1], vhi[g & 1][db][0], vhi[g & 1][db][1]};
+                if (!LMI_ABL(3)) o_acc[db] = mfma32(__builtin_bit_cast(T8, a), pf[g >> 1][g & 1], o_acc[db]); else o_acc[db][g] += (float)__builtin_bit_cast(T8, a)[0] * (float)pf[g >> 1][g & 1][0];
+            }
+        }
+#ifdef LMI_ATTN_PROF
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) LMI_PROF_TOUCH(o_acc[db][15]);
+#endif
+        LMI_PROF_MARK(6);
     }
+    LMI_PROF_DUMP();
     for (; t < n_tiles; ++t) {                                     // drain: keep feeding / syncing for the waves below the diagonal
         wait_vmcnt_barrier<0>();
         if (t + 1 < n_tiles) issue_tile(t + 1, (t + 1) & 1);
@@ -465,249 +505,6 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         for (int qp = 0; qp < 2; ++qp) {
             // this lane holds d = db*32 + 8*qd + 4*fh + e for qd = 2qp (a) and 2qp+1 (b); after the exchange the low
             // half-wave lane owns d = db*32 + 16qp + 0..7 and the high one d = db*32 + 16qp + 8..15
-            unsigned a[2], b[2];
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                a[w] = pack2<T>(o_acc[db][8 * qp + 2 * w] * inv, o_acc[db][8 * qp + 2 * w + 1] * inv);
-                b[w] = pack2<T>(o_acc[db][8 * qp + 4 + 2 * w] * inv, o_acc[db][8 * qp + 4 + 2 * w + 1] * inv);
-                swap_hi_lo(a[w], b[w]);
-            }
-            const int d = db * 32 + 16 * qp + 8 * fh;
-            if (my_q < len_q && d < D) *(u32x4*)(o_row + d) = u32x4{a[0], a[1], b[0], b[1]};
-        }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// attn_fwd_pipe_kernel — software-pipelined variant of the LDS-DMA kernel (same tiles, swizzles, register layouts and
-// epilogue).  The 64-key tile is processed as two 32-key blocks j, and the loop is skewed by two blocks so that every
-// phase has 16 MFMAs on independent accumulators with one block's softmax issued between them:
-//     M_j:   S(j+2) = K(j+2) . Q^T  (8 MFMAs, one chain)  interleaved with  O^T += V(j)^T . P(j)^T  (8 MFMAs, 4 chains)
-//            ||  mask + row max + exp2 + row sum + 16-bit pack of S(j+1) -> P(j+1)                     (~76 VALU)
-//            ||  K(j+2) fragment reads and V(j) transpose reads, just in time
-// (a chain of MFMAs on ONE accumulator only runs at the issue rate when another MFMA sits between its links, which is why
-// the QK^T chain is braided with the PV MFMAs).  The wave-uniform, rare rescale of O for the maximum found in M_j runs
-// between M_j and M_j+1.  One barrier per tile in front of M_2t: every wave is then done with K(t) and V(t-1), so the DMA
-// group {K(t+2), V(t+1)} goes out into those two slots and has a whole tile period to land (2 K + 2 V slots).
-// ------------------------------------------------------------------------------------------------------------------
-template <typename T, int D, bool CAUSAL>
-__global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_pipe_kernel(AttnArgs p) {
-    typedef AttnDmaGeom<D> G;
-    constexpr int NKS = G::NKS, NDB = G::NDB;
-    typedef typename vec_of<T>::x8 T8;
-    LMI_DYN_SMEM(smem);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-    const int fr = lane & 31, fh = lane >> 5;
-    const int bid = (int)blockIdx.x;                              // grid decode: see attn_fwd_dma_kernel
-    const int h_idx = bid % p.n_heads, rest = bid / p.n_heads;
-    const int qb = p.n_qblocks - 1 - rest % p.n_qblocks, seq = rest / p.n_qblocks;
-    const int kvh = h_idx % p.n_kv_heads, head = kvh * (p.n_heads / p.n_kv_heads) + h_idx / p.n_kv_heads;
-    const int q_beg = p.cu_q[seq], len_q = p.cu_q[seq + 1] - q_beg;
-    const int k_beg = p.cu_k[seq], len_k = p.cu_k[seq + 1] - k_beg;
-    const int q0 = qb * ATT_BQ;
-    if (q0 >= len_q) return;
-    const int shift = len_k - len_q;
-    int kv_end = len_k;
-    if (CAUSAL) kv_end = imin(len_k, q0 + ATT_BQ + shift);
-    const int n_tiles = imax(0, (kv_end + ATT_BKV - 1) / ATT_BKV);
-    const int wave_q_lo = q0 + wave * 32, wave_q_hi = wave_q_lo + 31;
-    int my_tiles = n_tiles;
-    if (CAUSAL) my_tiles = imax(0, imin(n_tiles, (wave_q_hi + shift) / ATT_BKV + 1));
-
-    const int my_q = q0 + wave * 32 + fr;
-    const T* q_row = (const T*)p.q + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldq + head * D;
-    T8 qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int c = 2 * ks + fh;
-        if (c < G::CH) qf[ks] = *(const T8*)(q_row + c * 8);
-        else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[ks][e] = (T)0.0f;
-        }
-    }
-
-    const T* k_base = (const T*)p.k + (long)k_beg * p.ldk + kvh * D;
-    const T* v_base = (const T*)p.v + (long)k_beg * p.ldv + kvh * D;
-    int p_row[G::PPW], p_kc[G::PPW], p_vc[G::PPW];
-#pragma unroll
-    for (int i = 0; i < G::PPW; ++i) {
-        const int ci = (wave + 4 * i) * 64 + lane;
-        const int r = ci / G::CH, c = ci - r * G::CH;
-        p_row[i] = r;
-        p_kc[i] = G::SWZ ? (c ^ (r & 15)) : c;
-        p_vc[i] = G::SWZ ? (c ^ ((r & 3) << 2)) : c;
-    }
-    // LDS: [K slot 0 | V slot 0 | K slot 1 | V slot 1]
-    auto issue_k = [&](int t) {
-        char* dst = smem + (t & 1) * 2 * G::TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < G::PPW; ++i)
-            if (wave + 4 * i < G::PIECES) {
-                const int key = imin(t * ATT_BKV + p_row[i], len_k - 1);
-                glds16(k_base + (long)key * p.ldk + (p_kc[i] << 3), dst + (wave + 4 * i) * 1024);
-            }
-    };
-    auto issue_v = [&](int t) {
-        char* dst = smem + (t & 1) * 2 * G::TILE_BYTES + G::TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < G::PPW; ++i)
-            if (wave + 4 * i < G::PIECES) {
-                const int key = imin(t * ATT_BKV + p_row[i], len_k - 1);
-                glds16(v_base + (long)key * p.ldv + (p_vc[i] << 3), dst + (wave + 4 * i) * 1024);
-            }
-    };
-
-    f32x16 o_acc[NDB];
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float c2 = p.scale * 1.4426950408889634f;
-
-    int k_off[NKS];                                               // chunks past D hold zeros in Q: point them at chunk 0
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int c = (2 * ks + fh < G::CH) ? 2 * ks + fh : 0;
-        k_off[ks] = fr * G::ROWB + ((G::SWZ ? (c ^ (fr & 15)) : c) << 4);
-    }
-    const int tr_j = (lane & 15) >> 2, tr_g = lane & 3, tr_half = (lane >> 4) & 1;
-    int v_off[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-        v_off[db] = (4 * fh + tr_j) * G::ROWB + ((G::SWZ ? (db ^ tr_j) : db) << 6) + tr_half * 32 + tr_g * 8;
-
-    // ---- pipeline pieces (all inlined) ----------------------------------------------------------------------------
-    auto k_frag = [&](int t, int h, int ks) -> T8 {                 // K fragment ks of 32-key block h of tile t
-        return *(const T8*)(smem + (t & 1) * 2 * G::TILE_BYTES + h * 32 * G::ROWB + k_off[ks]);
-    };
-    auto v_frag = [&](int t, int h, int u, int db) -> T8 {          // V^T fragment (keys 16u.., d-block db) of block h of tile t
-        const char* base = smem + (t & 1) * 2 * G::TILE_BYTES + G::TILE_BYTES + (h * 32 + 16 * u) * G::ROWB + v_off[db];
-        const u32x2 lo = ds_read_tr16_b64_async(base);
-        const u32x2 hi = ds_read_tr16_b64_async(base + 8 * G::ROWB);
-        return __builtin_bit_cast(T8, u32x4{lo[0], lo[1], hi[0], hi[1]});
-    };
-    auto zero = [&](f32x16& s) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    };
-    auto apply_mask = [&](f32x16& s, int jb) {                      // wave-uniform early-out: only diagonal / ragged blocks
-        const int kb0 = jb * 32;
-        const bool need_mask = (kb0 + 32 > len_k) || (CAUSAL && (kb0 + 31 > wave_q_lo + shift)) ||
-                               (CAUSAL && p.window > 0 && kb0 <= wave_q_hi + shift - p.window);
-        if (need_mask) {
-            const int lim = CAUSAL ? imin(len_k - 1, my_q + shift) : len_k - 1;
-            const int lo = (CAUSAL && p.window > 0) ? my_q + shift - p.window + 1 : 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (key > lim || key < lo) s[r] = -INFINITY;
-            }
-        }
-    };
-    // row max of one block, running-max update, P = exp2(S c2 - m c2), row sum, 16-bit pack.  Returns whether any row of
-    // the wave moved its maximum; `alpha` is the factor O and l then have to be scaled by (the caller does it once the PV
-    // MFMAs of the phase are issued; l is scaled here, before the new row sum is added).
-    float alpha = 1.f;
-    auto softmax = [&](const f32x16& s, T8 (&pf)[2]) -> bool {
-        float mx = s[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = xhalf_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const bool moved = wave_any(m_new != m_run);
-        alpha = fast_exp2((m_run - m_use) * c2);
-        m_run = m_new;
-        const float mc = m_use * c2;
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = fast_exp2(s[r] * c2 - mc);
-            psum += e;
-            pf[r >> 3][r & 7] = (T)e;
-        }
-        l_run = l_run * alpha + psum;
-        return moved;
-    };
-    auto rescale = [&]() {
-#pragma unroll
-        for (int i = 0; i < NDB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-    };
-    auto dma_turn = [&](int t) {                                    // barrier beta_{t+1} and the DMA group behind it
-        wait_vmcnt_barrier<0>();
-        if (t + 2 < n_tiles) issue_k(t + 2);
-        if (t + 1 < n_tiles) issue_v(t + 1);
-    };
-    // phase M_j: QK^T of block (tq, hq) into s_next (if WITH_QK) braided with PV of block (tv, hv) using p_cur, and the
-    // softmax of s_mid -> p_next (if WITH_SM) between them
-    auto phase = [&](auto with_qk, auto with_sm, int tq, int hq, f32x16& s_next, int tv, int hv, const T8 (&p_cur)[2],
-                     f32x16& s_mid, int jb_mid, T8 (&p_next)[2]) {
-        constexpr bool WITH_QK = decltype(with_qk)::value, WITH_SM = decltype(with_sm)::value;
-        if constexpr (WITH_SM) apply_mask(s_mid, jb_mid);
-        bool moved = false;
-        if constexpr (WITH_QK) zero(s_next);
-        if constexpr (WITH_SM) moved = softmax(s_mid, p_next);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if constexpr (WITH_QK) {
-                if (i < NKS) s_next = mfma32(k_frag(tq, hq, i), qf[i], s_next);
-            }
-            if (i < 2 * NDB) o_acc[i % NDB] = mfma32(v_frag(tv, hv, i / NDB, i % NDB), p_cur[i / NDB], o_acc[i % NDB]);
-        }
-        if constexpr (WITH_SM) { pin_here(p_next[0]); pin_here(p_next[1]); }
-        if constexpr (WITH_QK) pin_here(s_next);
-        if constexpr (WITH_SM) {
-            constexpr int NM = (WITH_QK ? NKS : 0) + 2 * NDB;       // MFMAs of this phase; ~80 VALU of softmax between them
-#pragma unroll
-            for (int i = 0; i < NM; ++i) { LMI_SCHED_MFMA(1); LMI_SCHED_VALU(80 / NM); }
-        }
-        sched_fence();
-        if (moved) rescale();
-    };
-    const std::true_type yes{};
-    const std::false_type no{};
-
-    if (n_tiles > 0) issue_k(0);
-    wait_vmcnt_barrier<0>();                                        // beta_0: K(0) landed
-    if (1 < n_tiles) issue_k(1);
-    if (0 < n_tiles) issue_v(0);
-    int t = 0;
-    if (my_tiles > 0) {
-        f32x16 s0, s1;
-        T8 p0[2], p1[2];
-        // prologue: S(0), S(1) (two chains braided), P(0)
-        zero(s0); zero(s1);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            s0 = mfma32(k_frag(0, 0, ks), qf[ks], s0);
-            s1 = mfma32(k_frag(0, 1, ks), qf[ks], s1);
-        }
-        apply_mask(s0, 0);
-        (void)softmax(s0, p0);                                      // O and l are still zero: nothing to rescale
-        // tile t: on entry S(2t+1) is in s1 and P(2t) in p0
-        for (; t + 1 < my_tiles; ++t) {
-            dma_turn(t);                                            // K(t+1), V(t) landed
-            phase(yes, yes, t + 1, 0, s0, t, 0, p0, s1, 2 * t + 1, p1);      // M_2t
-            phase(yes, yes, t + 1, 1, s1, t, 1, p1, s0, 2 * t + 2, p0);      // M_2t+1
-        }
-        dma_turn(t);
-        phase(no, yes, 0, 0, s0, t, 0, p0, s1, 2 * t + 1, p1);
-        phase(no, no, 0, 0, s1, t, 1, p1, s0, 0, p0);
-        ++t;
-    }
-    for (; t < n_tiles; ++t) dma_turn(t);                           // drain: keep feeding / syncing for the other waves
-
-    const float l_tot = xhalf_sum(l_run);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    T* o_row = (T*)p.out + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldo + head * D;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
             unsigned a[2], b[2];
 #pragma unroll
             for (int w = 0; w < 2; ++w) {

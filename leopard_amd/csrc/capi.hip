@@ -12,6 +12,12 @@
 
 using namespace lmi;
 
+#ifdef LMI_ATTN_PROF
+namespace lmi { __device__ unsigned long long* g_prof_buf = nullptr; }
+extern "C" int lmi_debug_set_prof_buffer(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(lmi::g_prof_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 namespace {
 thread_local char g_err[512] = "";
 
@@ -143,8 +149,7 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     return check_launch("lmi_attn_varlen_fwd");
 }
 int g_attn_lds_pad = 0;                      // experiment knob: extra dynamic LDS per workgroup (lowers residency)
-int g_attn_dma = 1;                          // 2 = software-pipelined LDS-DMA kernel (production), 1 = plain LDS-DMA kernel,
-                                             // 0 = register-staged kernel (cross-checks)
+int g_attn_dma = 1;                          // 1 = LDS-DMA kernel (production), 0 = register-staged kernel (cross-checks)
 
 template <typename T, int D, bool CAUSAL>
 int launch_attn_dma(const AttnArgs& a, int n_seq, int max_q, void* stream) {
@@ -158,22 +163,8 @@ int launch_attn_dma(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     return check_launch("lmi_attn_varlen_fwd");
 }
 
-template <typename T, int D, bool CAUSAL>
-int launch_attn_pipe(const AttnArgs& a, int n_seq, int max_q, void* stream) {
-    const int qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
-    static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(attn_fwd_pipe_kernel<T, D, CAUSAL>, 160 * 1024); attr_set = true; }
-    AttnArgs b = a;
-    b.n_qblocks = qblocks;
-    LMI_LAUNCH((attn_fwd_pipe_kernel<T, D, CAUSAL>), dim3(qblocks * a.n_heads * n_seq), dim3(ATT_THREADS),
-               AttnDmaGeom<D>::SMEM + g_attn_lds_pad, stream, b);
-    return check_launch("lmi_attn_varlen_fwd");
-}
-
 template <typename T, int D>
 int dispatch_attn(const AttnArgs& a, int n_seq, int max_q, int causal, int use_tr, void* stream) {
-    if (use_tr && g_attn_dma == 2)
-        return causal ? launch_attn_pipe<T, D, true>(a, n_seq, max_q, stream) : launch_attn_pipe<T, D, false>(a, n_seq, max_q, stream);
     if (use_tr && g_attn_dma)
         return causal ? launch_attn_dma<T, D, true>(a, n_seq, max_q, stream) : launch_attn_dma<T, D, false>(a, n_seq, max_q, stream);
     if (causal) return use_tr ? launch_attn<T, D, true, true>(a, n_seq, max_q, stream)
@@ -263,7 +254,7 @@ int lmi_set_option(const char* key, int value) {
         return LMI_OK;
     }
     if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
-    if (!strcmp(key, "attn.dma")) { g_attn_dma = value < 0 ? 0 : (value > 2 ? 2 : value); return LMI_OK; }
+    if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.lds_pad")) { g_attn_lds_pad = value < 0 ? 0 : (value > 90 * 1024 ? 90 * 1024 : value); return LMI_OK; }
     return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);
 }

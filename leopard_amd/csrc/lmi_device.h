@@ -69,6 +69,19 @@ LMI_DEV void glds16(const void* gptr, void* lds_wave_base) {
 
 // LDS transpose read: within each 16-lane group, lane i = 4*j+g supplies the address of 4 consecutive
 // 16-bit elements (row j, column group g); lane c receives {row0[c], row1[c], row2[c], row3[c]}.
+// Same through a buffer resource: source byte = base + voffset (per lane) + soffset (wave-uniform), both 32-bit; bytes at
+// or beyond num_records read as zero (raw-buffer range check), so ragged tile tails need no address clamp.
+struct BufRsrc {
+    __amdgpu_buffer_rsrc_t r;
+};
+LMI_DEV BufRsrc make_buf(const void* base, unsigned num_records) {
+    return BufRsrc{__builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)num_records, 0x00020000)};
+}
+LMI_DEV void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset,
+                                             (int)soffset, 0, 0);
+}
+
 LMI_DEV void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 LMI_DEV u32x2 ds_read_tr16_b64(const void* lds_ptr) {
@@ -78,15 +91,6 @@ LMI_DEV u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
-// compiler-tracked form (no wait inside): hipcc counts it in lgkmcnt like any other LDS load, so a batch issued early
-// is waited for only where its result is first used
-LMI_DEV u32x2 ds_read_tr16_b64_async(const void* lds_ptr) {
-    typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
-    const s16x4v r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)lds_ptr);
-    return __builtin_bit_cast(u32x2, r);
-}
-// keep a value materialised at this point of the program (stops hipcc from sinking its computation into a later block)
-template <typename V> LMI_DEV void pin_here(V& v) { asm volatile("" : "+v"(v)); }
 // scheduling-group hints (LLVM igrouplp): one group of `n` instructions of a class, in program order of the hints
 #define LMI_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 #define LMI_SCHED_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
@@ -132,46 +136,30 @@ LMI_DEV void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
     out[2] = u32x4{a2[0], a2[1], b2[0], b2[1]};
 }
 
-// Attention V operand: 2*N transpose reads (N d-blocks x {keys +0..3, keys +8..11}) from per-lane addresses
-// base + imm + off[db] (+ HI for the second key group), one wait.  out[db] = {lo.x, lo.y, hi.x, hi.y}.
+// Split form for software pipelining: tr16_issue() starts the 2N transpose reads of one 16-key group (d-block db at
+// base + off[db] + imm, second key quad HI bytes further) and returns immediately; the registers may only be consumed
+// after lgkm_fence<CNT>() on them, CNT = number of LDS operations issued after the group that may still be in flight
+// (LDS returns in order).  Inline asm on purpose: hipcc orders every LDS-reading *intrinsic* behind all outstanding
+// LDS-DMA with s_waitcnt vmcnt(0), which would serialise the next tile's DMA with this tile's reads.
 template <int N, int HI>
-LMI_DEV void ds_read_tr16_gather(const void* base, const int (&off)[N], int imm, u32x4* out) {
-    static_assert(N == 3 || N == 4, "d-block count");
+LMI_DEV void tr16_issue(const void* base, const int (&off)[N], int imm, u32x2 (&lo)[N], u32x2 (&hi)[N]) {
     const unsigned b = (unsigned)(size_t)base + (unsigned)imm;
-    u32x2 l0, l1, l2, l3, h0, h1, h2, h3;
-    if constexpr (N == 4) {
-        const unsigned a0 = b + off[0], a1 = b + off[1], a2 = b + off[2], a3 = b + off[3];
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %8\n\t"
-            "ds_read_b64_tr_b16 %1, %8 offset:%c12\n\t"
-            "ds_read_b64_tr_b16 %2, %9\n\t"
-            "ds_read_b64_tr_b16 %3, %9 offset:%c12\n\t"
-            "ds_read_b64_tr_b16 %4, %10\n\t"
-            "ds_read_b64_tr_b16 %5, %10 offset:%c12\n\t"
-            "ds_read_b64_tr_b16 %6, %11\n\t"
-            "ds_read_b64_tr_b16 %7, %11 offset:%c12\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
-            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "i"(HI)
-            : "memory");
-        out[3] = u32x4{l3[0], l3[1], h3[0], h3[1]};
-    } else {
-        const unsigned a0 = b + off[0], a1 = b + off[1], a2 = b + off[2];
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %6\n\t"
-            "ds_read_b64_tr_b16 %1, %6 offset:%c9\n\t"
-            "ds_read_b64_tr_b16 %2, %7\n\t"
-            "ds_read_b64_tr_b16 %3, %7 offset:%c9\n\t"
-            "ds_read_b64_tr_b16 %4, %8\n\t"
-            "ds_read_b64_tr_b16 %5, %8 offset:%c9\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2)
-            : "v"(a0), "v"(a1), "v"(a2), "i"(HI)
-            : "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const unsigned a = b + off[i];
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%c3"
+                     : "=&v"(lo[i]), "=&v"(hi[i]) : "v"(a), "i"(HI) : "memory");
     }
-    out[0] = u32x4{l0[0], l0[1], h0[0], h0[1]};
-    out[1] = u32x4{l1[0], l1[1], h1[0], h1[1]};
-    out[2] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+template <int CNT, int N>
+LMI_DEV void lgkm_fence(u32x2 (&lo)[N], u32x2 (&hi)[N]) {
+    static_assert(N == 3 || N == 4, "d-block count");
+    if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(%c8)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]),
+                     "+v"(lo[3]), "+v"(hi[3]) : "i"(CNT));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%c6)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2])
+                     : "i"(CNT));
 }
 
 LMI_DEV float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
@@ -186,8 +174,6 @@ LMI_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 LMI_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 LMI_DEV void setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 LMI_DEV void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
-// HW_ID[3:0]: this wave's slot on its SIMD (co-resident waves of a SIMD have distinct slots)
-LMI_DEV int hw_wave_slot() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); }
 LMI_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 LMI_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 LMI_DEV float fexp(float x) { return __expf(x); }
@@ -252,6 +238,18 @@ inline void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_memcpy((char*)lds_wave_base + lane_id() * 16, gptr, 16);
 }
 
+struct BufRsrc {
+    const char* base;
+    unsigned num_records;
+};
+inline BufRsrc make_buf(const void* base, unsigned num_records) { return BufRsrc{(const char*)base, num_records}; }
+inline void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
+    char* dst = (char*)lds_wave_base + lane_id() * 16;
+    const unsigned long off = (unsigned long)voffset + soffset;
+    if (off + 16 <= b.num_records) __builtin_memcpy(dst, b.base + off, 16);
+    else __builtin_memset(dst, 0, 16);
+}
+
 inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     struct Slot { uint16_t e[4]; };
     Slot* s = (Slot*)hipemu::wave_buf();
@@ -268,8 +266,6 @@ inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
-inline u32x2 ds_read_tr16_b64_async(const void* lds_ptr) { return ds_read_tr16_b64(lds_ptr); }
-template <typename V> inline void pin_here(V&) {}
 #define LMI_SCHED_MFMA(n) ((void)0)
 #define LMI_SCHED_VALU(n) ((void)0)
 #define LMI_SCHED_DSREAD(n) ((void)0)
@@ -284,13 +280,14 @@ inline void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
 }
 
 template <int N, int HI>
-inline void ds_read_tr16_gather(const void* base, const int (&off)[N], int imm, u32x4* out) {
+inline void tr16_issue(const void* base, const int (&off)[N], int imm, u32x2 (&lo)[N], u32x2 (&hi)[N]) {
     for (int i = 0; i < N; ++i) {
-        const u32x2 lo = ds_read_tr16_b64((const char*)base + imm + off[i]);
-        const u32x2 hi = ds_read_tr16_b64((const char*)base + imm + off[i] + HI);
-        out[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        lo[i] = ds_read_tr16_b64((const char*)base + imm + off[i]);
+        hi[i] = ds_read_tr16_b64((const char*)base + imm + off[i] + HI);
     }
 }
+template <int CNT, int N>
+inline void lgkm_fence(u32x2 (&)[N], u32x2 (&)[N]) {}
 
 template <typename S>
 inline S emu_shfl_idx(S v, int src) {
@@ -316,7 +313,6 @@ inline bool wave_any(bool p) {
 inline void sched_fence() {}
 inline void setprio_hi() {}
 inline void setprio_lo() {}
-inline int hw_wave_slot() { return 0; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fexp(float x) { return expf(x); }
@@ -365,3 +361,19 @@ LMI_DEV float wave_max(float v) {
 }
 
 }  // namespace lmi
+
+// ---- optional in-kernel cycle accounting (builds with -DLMI_ATTN_PROF only; tools/attn_prof.py) -----------------------
+#if defined(LMI_ATTN_PROF) && !defined(LMI_EMU)
+namespace lmi { extern __device__ unsigned long long* g_prof_buf; }
+#define LMI_PROF_DECL() unsigned long long prof_t[7] = {0, 0, 0, 0, 0, 0, 0}, prof_last = 0, prof_now = 0; int prof_sink = 0
+#define LMI_PROF_MARK(i) do { prof_now = __builtin_amdgcn_s_memtime(); if ((i) != 0) prof_t[i] += prof_now - prof_last; prof_last = prof_now; } while (0)
+#define LMI_PROF_TOUCH(x) (prof_sink += __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)(x))))
+#define LMI_PROF_DUMP() do { if ((threadIdx.x & 63) == 0 && lmi::g_prof_buf) { \
+        unsigned long long* d = lmi::g_prof_buf + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
+        for (int i = 0; i < 7; ++i) d[i] = prof_t[i]; d[7] = (unsigned long long)(unsigned)prof_sink; } } while (0)
+#else
+#define LMI_PROF_DECL() ((void)0)
+#define LMI_PROF_MARK(i) ((void)0)
+#define LMI_PROF_TOUCH(x) ((void)0)
+#define LMI_PROF_DUMP() ((void)0)
+#endif

@@ -389,3 +389,33 @@ def test_gemm_tile_order_round_robin(ops):
     finally:
         ops.set_option("gemm.order", 0)
         ops.set_option("gemm.config", -1)
+
+
+@pytest.mark.parametrize("dma", [1, 0])
+def test_attention_kernel_variants(ops, dma):
+    """Both attention kernels behind lmi_attn_varlen_fwd (LDS-DMA = production, register-staged = cross-check) on a causal
+    GQA case with ragged blocks and on the 72-wide SigLIP head."""
+    ops.set_option("attn.dma", dma)
+    try:
+        H, KV, D = 2, 1, 128
+        cu = [0, 300, 341]
+        T = cu[-1]
+        qkv = rnd((T, (H + 2 * KV) * D), torch.float16, 70)
+        q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+        out = torch.full((T, H * D), float("nan"), dtype=torch.float16)
+        cu_t = torch.tensor(cu, dtype=torch.int32)
+        ops.attention(q, k, v, out, cu_t, cu_t, 300, H, KV, D, D ** -0.5, True, True)
+        ref = attn_ref(q, k, v, cu, cu, H, KV, D, D ** -0.5, True)
+        assert (out.float() - ref).abs().max() <= 4e-3
+        H, D = 2, 72
+        cu = [0, 270]
+        qkv = rnd((270, 3 * H * D), torch.float16, 71)
+        q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+        out = torch.full((270, H * D), float("nan"), dtype=torch.float16)
+        cu_t = torch.tensor(cu, dtype=torch.int32)
+        ops.attention(q, k, v, out, cu_t, cu_t, 270, H, H, D, D ** -0.5, False, True)
+        ref = attn_ref(q, k, v, cu, cu, H, H, D, D ** -0.5, False)
+        assert (out.float() - ref).abs().max() <= 4e-3
+    finally:
+        ops.set_option("attn.dma", 1)
+
