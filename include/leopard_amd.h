@@ -59,6 +59,15 @@ int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dt
 int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, int image_size, int patch,
                          int ldo, int dtype, void* stream);
 
+/* a3 / a5 (next row f3: the tiler on the GPU) — one pass of Pillow's antialiased 8-bit RGB resampling, the arithmetic
+ * behind `image.resize(...)` in resize_and_pad_image (EVAL:102-140) and behind SiglipImageProcessor's bicubic resize of
+ * the thumbnail (EVAL:403-404).  Bit-identical to libImaging for the taps it is given: bounds[o] = {first source index,
+ * tap count}, taps[o][ksize] = 22-bit fixed-point weights (leopard_amd/tiler.py pil_resample_coeffs).
+ * axis 0: src [out_rows, in, 3] -> dst [out_rows, out_cols, 3] (along rows); axis 1: src [in, out_cols, 3] ->
+ * dst [out_rows, out_cols, 3] (down columns).  Pitches in bytes, so dst may be a window of a larger canvas (the paste). */
+int lmi_resample_u8(const void* src, void* dst, int axis, int out_rows, int out_cols, int src_pitch, int dst_pitch,
+                    const int* bounds, const int* taps, int ksize, void* stream);
+
 /* Same for rectangular images (Leopard-Idefics2's NaViT tower, idefics2_multiimg.py:91-93; third-party
  * Idefics2VisionEmbeddings; analogue idefics_vision_tower.py:118-150): n_images of height x width (u8 HWC or normalised
  * fp32 CHW); the valid patch conv drops remainder pixels -> (height/patch)*(width/patch) rows per image. */

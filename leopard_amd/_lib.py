@@ -26,6 +26,7 @@ SIGNATURES = {
     "lmi_fill_synthetic": [_P, C.c_int64, C.c_uint32, _I, _I, _P],
     "lmi_preprocess_tiles": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "lmi_preprocess_images": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_resample_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "lmi_layernorm": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "lmi_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "lmi_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

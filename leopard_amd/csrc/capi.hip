@@ -270,6 +270,22 @@ int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dt
     return check_launch("lmi_fill_synthetic");
 }
 
+int lmi_resample_u8(const void* src, void* dst, int axis, int out_rows, int out_cols, int src_pitch, int dst_pitch,
+                    const int* bounds, const int* taps, int ksize, void* stream) {
+    if (!src || !dst || !bounds || !taps) return fail(LMI_EINVAL, "lmi_resample_u8: null pointer");
+    if ((axis != 0 && axis != 1) || out_rows < 0 || out_cols < 0 || ksize <= 0 || src_pitch <= 0 || dst_pitch < out_cols * 3)
+        return fail(LMI_EINVAL, "lmi_resample_u8: bad arguments (axis=%d rows=%d cols=%d ksize=%d)", axis, out_rows, out_cols, ksize);
+    if (out_rows == 0 || out_cols == 0) return LMI_OK;
+    const int grid = grid_for((long)out_rows * out_cols, 256);
+    if (axis == 0)
+        LMI_LAUNCH((resample_u8_kernel<0>), dim3(grid), dim3(256), 0, stream, (const uint8_t*)src, (uint8_t*)dst, out_rows, out_cols,
+                   src_pitch, dst_pitch, bounds, taps, ksize);
+    else
+        LMI_LAUNCH((resample_u8_kernel<1>), dim3(grid), dim3(256), 0, stream, (const uint8_t*)src, (uint8_t*)dst, out_rows, out_cols,
+                   src_pitch, dst_pitch, bounds, taps, ksize);
+    return check_launch("lmi_resample_u8");
+}
+
 int lmi_preprocess_images(const void* in, int from_u8, void* out, int n_images, int height, int width, int patch, int ldo,
                           int dtype, void* stream) {
     if (!in || !out || n_images < 0 || patch <= 0 || height < patch || width < patch || ldo < 3 * patch * patch || (ldo & 7))

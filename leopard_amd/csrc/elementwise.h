@@ -58,6 +58,39 @@ __global__ void im2col_kernel(const void* in, T* out, int n_tiles, int H, int W,
 }
 
 // ------------------------------------------------------------------------------------------------
+// One pass of Pillow's antialiased resampling for 8-bit RGB (a3 / a5: Image.resize inside resize_and_pad_image,
+// EVAL:102-140, and the thumbnail squash of SiglipImageProcessor, EVAL:403-404).  Bit-identical to libImaging
+// ImagingResampleHorizontal_8bpc / Vertical_8bpc: 22-bit fixed-point taps from the host (leopard_amd/tiler.py
+// pil_resample_coeffs, a restatement of precompute_coeffs + normalize_coeffs_8bpc), int32 accumulation from 2^21,
+// arithmetic shift, clamp to [0, 255].  AXIS 0: along a row (src [rows, in, 3] -> dst [rows, out, 3]); AXIS 1: down a
+// column (src [in, cols, 3] -> dst [out, cols, 3]).  HBM-bound byte work; one thread per output pixel.
+// ------------------------------------------------------------------------------------------------
+template <int AXIS>
+__global__ void resample_u8_kernel(const uint8_t* src, uint8_t* dst, int rows, int cols, int src_pitch, int dst_pitch,
+                                   const int* bounds, const int* kk, int ksize) {
+    // rows x cols = extent of the OUTPUT image
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / cols), x = (int)(i - (long)y * cols);
+        const int o = AXIS == 0 ? x : y;
+        const int lo = bounds[2 * o], n = bounds[2 * o + 1];
+        const int* k = kk + (long)o * ksize;
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        const uint8_t* p = AXIS == 0 ? src + (long)y * src_pitch + (long)lo * 3 : src + (long)lo * src_pitch + (long)x * 3;
+        const long step = AXIS == 0 ? 3 : src_pitch;
+        for (int t = 0; t < n; ++t) {
+            const int w = k[t];
+            s0 += (int)p[0] * w; s1 += (int)p[1] * w; s2 += (int)p[2] * w;
+            p += step;
+        }
+        uint8_t* d = dst + (long)y * dst_pitch + (long)x * 3;
+        d[0] = (uint8_t)imin(imax(s0 >> 22, 0), 255);
+        d[1] = (uint8_t)imin(imax(s1 >> 22, 0), 255);
+        d[2] = (uint8_t)imin(imax(s2 >> 22, 0), 255);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm (SigLIP, eps 1e-6) / RMSNorm (Llama, eps 1e-5): fp32 stream row -> 16-bit GEMM operand row.
 // One wave per row, row kept in registers, statistics in fp32 with two passes (mean, then centred variance).
 // ------------------------------------------------------------------------------------------------

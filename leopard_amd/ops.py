@@ -66,6 +66,16 @@ class Ops:
                                                    _DT[out.dtype], self._stream(out)))
         return out
 
+    def resample_u8(self, src: torch.Tensor, dst: torch.Tensor, axis: int, bounds: torch.Tensor, taps: torch.Tensor):
+        """One pass of Pillow's 8-bit RGB resampling.  src/dst: u8 [rows, cols, 3] views whose last two dims are dense
+        (dst may be a window of a larger canvas); bounds int32 [out, 2], taps int32 [out, ksize]."""
+        assert src.dtype == torch.uint8 and dst.dtype == torch.uint8 and src.stride(2) == 1 and src.stride(1) == 3
+        assert dst.stride(2) == 1 and dst.stride(1) == 3 and bounds.dtype == torch.int32 and taps.dtype == torch.int32
+        assert bounds.is_contiguous() and taps.is_contiguous() and bounds.shape[0] == dst.shape[1 if axis == 0 else 0]
+        self._check(self.lib.lmi_resample_u8(_ptr(src), _ptr(dst), axis, dst.shape[0], dst.shape[1], src.stride(0), dst.stride(0),
+                                             _ptr(bounds), _ptr(taps), taps.shape[1], self._stream(dst)))
+        return dst
+
     def layernorm(self, x, w, b, out, eps):
         M, D = x.shape
         self._check(self.lib.lmi_layernorm(_ptr(x), _ptr(w), _ptr(b), _ptr(out), M, D, x.stride(0), out.stride(0),

@@ -20,6 +20,7 @@ resize uses PIL so that the u8 tiles are bit-identical to what the reference fee
 """
 from __future__ import annotations
 
+import functools
 import math
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -119,15 +120,9 @@ def letterbox(image, canvas: Optional[Tuple[int, int]]):
     if canvas is None:
         return None
     from PIL import Image
-    w0, h0 = image.size
-    cw, ch = canvas
-    sw, sh = cw / w0, ch / h0
-    if sw < sh:
-        nw, nh = cw, min(math.ceil(h0 * sw), ch)
-    else:
-        nw, nh = min(math.ceil(w0 * sh), cw), ch
-    out = Image.new("RGB", (cw, ch), (0, 0, 0))
-    out.paste(image.resize((nw, nh)), ((cw - nw) // 2, (ch - nh) // 2))
+    nw, nh, px, py = letterbox_geometry(image.size, canvas)
+    out = Image.new("RGB", canvas, (0, 0, 0))
+    out.paste(image.resize((nw, nh)), (px, py))
     return out
 
 
@@ -172,3 +167,61 @@ def siglip_normalize(u8_tiles: np.ndarray) -> np.ndarray:
 def siglip_preprocess(vit_inputs: Sequence, size: int = TILE) -> np.ndarray:
     """[N,3,size,size] fp32 pixel_values, the tensor the reference passes to ``generate``."""
     return siglip_normalize(to_u8_tiles(vit_inputs, size))
+
+
+# --------------------------------------------------------------------------------------------------
+# Pillow's resampling taps (for the GPU tiler: leopard_amd/gpu_tiler.py + lmi_resample_u8)
+# --------------------------------------------------------------------------------------------------
+_PRECISION_BITS = 32 - 8 - 2          # libImaging Resample.c: taps are 22-bit fixed point for 8-bit channels
+
+
+def _bicubic(x: np.ndarray) -> np.ndarray:
+    """libImaging bicubic_filter (a = -0.5), same operation order in float64."""
+    a = -0.5
+    x = np.abs(x)
+    near = ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    far = (((x - 5) * x + 8) * x - 4) * a
+    return np.where(x < 1.0, near, np.where(x < 2.0, far, 0.0))
+
+
+@functools.lru_cache(maxsize=256)
+def pil_resample_coeffs(in_size: int, out_size: int):
+    """(bounds int32 [out, 2], taps int32 [out, ksize]) of ``Image.resize`` with BICUBIC along one axis from ``in_size``
+    to ``out_size`` samples: a restatement of libImaging's precompute_coeffs + normalize_coeffs_8bpc (Pillow
+    src/libImaging/Resample.c; third-party, absent from /root/reference — pinned by comparing the GPU tiler's output with
+    PIL's own, bit for bit, in tests/test_gpu_tiler.py).  The arithmetic is float64 in the same order as the C code."""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale                              # bicubic support = 2
+    ksize = int(math.ceil(support)) * 2 + 1
+    xx = np.arange(out_size, dtype=np.float64)
+    center = 0.0 + (xx + 0.5) * scale
+    ss = 1.0 / filterscale
+    xmin = (center - support + 0.5).astype(np.int64)        # C (int) cast: truncation toward zero
+    xmin = np.maximum(xmin, 0)
+    xmax = (center + support + 0.5).astype(np.int64)
+    xmax = np.minimum(xmax, in_size) - xmin
+    k = np.zeros((out_size, ksize), dtype=np.float64)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for x in range(ksize):                                   # sequential accumulation order of the C loop
+        w = _bicubic((x + xmin - center + 0.5) * ss)
+        w = np.where(x < xmax, w, 0.0)
+        k[:, x] = w
+        ww = ww + w
+    nz = ww != 0.0
+    k[nz] = k[nz] / ww[nz, None]
+    fixed = np.where(k < 0, -0.5 + k * (1 << _PRECISION_BITS), 0.5 + k * (1 << _PRECISION_BITS)).astype(np.int64)   # (int) truncation
+    bounds = np.stack([xmin, xmax], axis=1).astype(np.int32)
+    return bounds, fixed.astype(np.int32)
+
+
+def letterbox_geometry(size: Tuple[int, int], canvas: Tuple[int, int]) -> Tuple[int, int, int, int]:
+    """(new_w, new_h, paste_x, paste_y) of resize_and_pad_image for an image of PIL size ``size`` (EVAL:102-140)."""
+    w0, h0 = size
+    cw, ch = canvas
+    sw, sh = cw / w0, ch / h0
+    if sw < sh:
+        nw, nh = cw, min(math.ceil(h0 * sw), ch)
+    else:
+        nw, nh = min(math.ceil(w0 * sh), cw), ch
+    return nw, nh, (cw - nw) // 2, (ch - nh) // 2
