@@ -107,12 +107,30 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
                         int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window,
                         int use_tr, int dtype, void* stream);
 
+/* a12 (next row f2: the decode loop) — the same attention for a few query rows against a long KV cache: the key range is
+ * split over workgroups (512 keys each, at most 64 splits), partial (O, max, sum) go to `workspace` and are merged.
+ * Replaces the attention inside the decode branch of the reference forward (EVAL:291-333).  Causal (bottom-right), GQA,
+ * head_dim 128.  q_rows = rows of q / out (>= cu_seqlens_q[n_seq]); max_seqlen_k is a host upper bound that fixes the
+ * launch geometry (pass the cache capacity to keep it constant under a captured HIP graph); cu_seqlens on device.
+ * workspace: lmi_attn_decode_workspace_bytes(q_rows, n_heads, head_dim, max_seqlen_k) bytes, 16-byte aligned. */
+int64_t lmi_attn_decode_workspace_bytes(int q_rows, int n_heads, int head_dim, int max_seqlen_k);
+int lmi_attn_decode_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
+                        int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                        int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                        int dtype, void* stream);
+
 /* RoPE (rotate-half; cos/sin fp32 [S, head_dim/2] built from position_ids and the llama3-scaled inverse
  * frequencies, rotary_pos_embedding.py:48-83,197-239) applied in place to the q and k heads of packed qkv rows
  * [S, ld]; when k_cache/v_cache are non-null also appends rotated K and V to the cache rows cache_pos0.. */
 int lmi_rope_qk(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_table,
                 const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int dtype,
                 void* stream);
+
+/* Same with the position of row 0 read from device memory (*pos_dev): cos_all/sin_all are tables for every position of the
+ * cache ([capacity, head_dim/2]) and the K/V rows go to cache row *pos_dev + s.  Lets a decode step be captured in a HIP graph
+ * and replayed while a device counter advances (EVAL:291-320: position_ids = mask.sum - 1). */
+int lmi_rope_qk_at(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all,
+                   const float* sin_all, void* k_cache, void* v_cache, int ld_cache, const int* pos_dev, int dtype, void* stream);
 
 /* a10 — get_input_embeddings()(input_ids) + _merge_input_ids_with_image_features (EVAL:263,284-287; analogue
  * megatron_patch/model/llava/vlm_model.py:526-533): out fp32 [S, D]; src[s] >= 0 -> embed_table[ids[src[s]]],
@@ -124,6 +142,12 @@ int lmi_embed_merge(const int64_t* ids, const int64_t* src, const void* embed_ta
  * and the decode step (EVAL:291-320).  epilogue: 0 store fp32, 1 store T, 2 fp32 +=, 3 SwiGLU (N/2 outputs). */
 int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, int epilogue,
              int dtype, void* stream);
+
+/* Same with the RMSNorm of the decode step folded in: x is the fp32 residual row [K], norm_weight fp32 [K], and the row
+ * fed to the product is T(norm_weight * (x * rsqrt(mean(x^2) + eps))) — the arithmetic of lmi_rmsnorm, without its launch.
+ * K = 4096 (the hidden size of Llama-3.1-8B / Mistral-7B). */
+int lmi_gemv_rmsnorm(const void* W, const float* x, const float* norm_weight, float eps, void* out, int N, int K, int ldw,
+                     int epilogue, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -32,8 +32,11 @@ SIGNATURES = {
     "lmi_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_attn_varlen_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
     "lmi_rope_qk": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P],
+    "lmi_rope_qk_at": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],
+    "lmi_attn_decode_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, C.c_int64, _I, _P],
     "lmi_embed_merge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lmi_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lmi_gemv_rmsnorm": [_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
 }
 
 
@@ -44,6 +47,8 @@ def bind(path: str) -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = the library does not export the ABI
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.lmi_attn_decode_workspace_bytes.argtypes = [_I, _I, _I, _I]
+    lib.lmi_attn_decode_workspace_bytes.restype = C.c_int64
     lib.lmi_last_error.argtypes = []
     lib.lmi_last_error.restype = C.c_char_p
     return lib

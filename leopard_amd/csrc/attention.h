@@ -43,6 +43,12 @@ struct AttnArgs {
     float scale;              // softmax scale (head_dim^-0.5)
     int window;               // sliding window (Mistral): query i sees keys j with i - j < window; 0 = unlimited
     int n_qblocks;            // ceil(max_seqlen_q / ATT_BQ) (1-D grid decode of the LDS-DMA kernel)
+    // split-KV (decode: few query rows against a long cache): the key range is cut into n_splits chunks of split_tiles
+    // 64-key tiles, each workgroup writes an unnormalised partial (O fp32, reference max, row sum) and
+    // attn_combine_kernel merges them.  n_splits <= 1: single pass, normalised output straight to `out`.
+    int n_splits, split_tiles, part_rows;
+    float* part_o;            // [n_splits, part_rows, n_heads, D]
+    float* part_ml;           // [n_splits, part_rows, n_heads, 2]  (m, l)
 };
 
 constexpr int ATT_BQ = 128, ATT_BKV = 64, ATT_THREADS = 256;
@@ -300,7 +306,9 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     // heads are dispatched first and the light ones fill the tail, and (b) workgroup b runs on XCD b % 8 and takes kv head
     // b % n_kv_heads: with 8 kv heads each XCD's L2 serves one kv head's K/V stream to every query head that shares it.
     const int bid = (int)blockIdx.x;
-    const int h_idx = bid % p.n_heads, rest = bid / p.n_heads;
+    const int h_idx = bid % p.n_heads;
+    int rest = bid / p.n_heads, split = 0;
+    if (p.n_splits > 1) { split = rest % p.n_splits; rest /= p.n_splits; }
     const int qb = p.n_qblocks - 1 - rest % p.n_qblocks, seq = rest / p.n_qblocks;
     const int kvh = h_idx % p.n_kv_heads, head = kvh * (p.n_heads / p.n_kv_heads) + h_idx / p.n_kv_heads;
     const int q_beg = p.cu_q[seq], len_q = p.cu_q[seq + 1] - q_beg;
@@ -316,6 +324,10 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     // joins the barriers for the other waves in the drain loop below)
     int my_tiles = n_tiles;
     if (CAUSAL) my_tiles = imax(0, imin(n_tiles, (wave_q_hi + shift) / ATT_BKV + 1));
+    // split-KV: this workgroup only walks tiles [t_begin, t_end)
+    const int t_begin = p.n_splits > 1 ? imin(n_tiles, split * p.split_tiles) : 0;
+    const int t_end = p.n_splits > 1 ? imin(n_tiles, t_begin + p.split_tiles) : n_tiles;
+    my_tiles = imin(my_tiles, t_end);
 
     const int my_q = q0 + wave * 32 + fr;
     const T* q_row = (const T*)p.q + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldq + head * D;
@@ -382,17 +394,17 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     for (int db = 0; db < NDB; ++db)
         v_off[db] = (4 * fh + tr_j) * G::ROWB + ((G::SWZ ? (db ^ tr_j) : db) << 6) + tr_half * 32 + tr_g * 8;
 
-    issue_tile(0, 0);
-    int t = 0;
+    if (t_begin < t_end) issue_tile(t_begin, 0);
+    int t = t_begin;
     LMI_PROF_DECL();
     for (; t < my_tiles; ++t) {
         LMI_PROF_MARK(0);
         wait_vmcnt_barrier<0>();                                   // tile t landed; slot of tile t-1 is free
         LMI_PROF_MARK(1);
-        if (t + 1 < n_tiles) issue_tile(t + 1, (t + 1) & 1);
+        if (t + 1 < t_end) issue_tile(t + 1, (t + 1 - t_begin) & 1);
         LMI_PROF_MARK(2);
         const int kv0 = t * ATT_BKV;
-        const char* k_lds = smem + (t & 1) * 2 * G::TILE_BYTES;
+        const char* k_lds = smem + ((t - t_begin) & 1) * 2 * G::TILE_BYTES;
         const char* v_lds = k_lds + G::TILE_BYTES;
 
         f32x16 s[2];
@@ -490,13 +502,28 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         LMI_PROF_MARK(6);
     }
     LMI_PROF_DUMP();
-    for (; t < n_tiles; ++t) {                                     // drain: keep feeding / syncing for the waves below the diagonal
+    for (; t < t_end; ++t) {                                       // drain: keep feeding / syncing for the waves below the diagonal
         wait_vmcnt_barrier<0>();
-        if (t + 1 < n_tiles) issue_tile(t + 1, (t + 1) & 1);
+        if (t + 1 < t_end) issue_tile(t + 1, (t + 1 - t_begin) & 1);
     }
 
     // ---- finish: O / l; the two half-wave lanes of a row trade 4-element groups so each stores 16 contiguous bytes ------
     const float l_tot = xhalf_sum(l_run);
+    if (p.n_splits > 1) {                                          // unnormalised partial for attn_combine_kernel
+        if (my_q < len_q) {
+            const long base = ((long)split * p.part_rows + (q_beg + my_q)) * p.n_heads + head;
+            float* po = p.part_o + base * D;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int d = db * 32 + 8 * qd + 4 * fh;
+                    if (d < D) *(f32x4*)(po + d) = f32x4{o_acc[db][4 * qd], o_acc[db][4 * qd + 1], o_acc[db][4 * qd + 2], o_acc[db][4 * qd + 3]};
+                }
+            if (fh == 0) { p.part_ml[base * 2] = m_run; p.part_ml[base * 2 + 1] = l_tot; }
+        }
+        return;
+    }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     T* o_row = (T*)p.out + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldo + head * D;
 #pragma unroll
@@ -515,6 +542,42 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
             const int d = db * 32 + 16 * qp + 8 * fh;
             if (my_q < len_q && d < D) *(u32x4*)(o_row + d) = u32x4{a[0], a[1], b[0], b[1]};
         }
+}
+
+// Merge of the split-KV partials: out[row, head, :] = sum_s w_s O_s / sum_s w_s l_s with w_s = 2^((m_s - max m) c2).
+// One wave per (row, head); a split that saw no visible key has m = -inf and is skipped.
+template <typename T, int D>
+__global__ void __launch_bounds__(256) attn_combine_kernel(const float* part_o, const float* part_ml, T* out, const int* cu_q,
+                                                           int n_seq, int n_heads, int n_splits, int part_rows, int ldo, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total_q = cu_q[n_seq];
+    if (item >= (long)total_q * n_heads) return;
+    const int row = (int)(item / n_heads), head = (int)(item - (long)row * n_heads);
+    const float c2 = scale * 1.4426950408889634f;
+    float M = -INFINITY;
+    for (int s = 0; s < n_splits; ++s) M = fmaxf(M, part_ml[(((long)s * part_rows + row) * n_heads + head) * 2]);
+    float l = 0.f, acc[(D + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (D + 63) / 64; ++j) acc[j] = 0.f;
+    for (int s = 0; s < n_splits; ++s) {
+        const long base = ((long)s * part_rows + row) * n_heads + head;
+        const float m = part_ml[base * 2];
+        if (m == -INFINITY) continue;
+        const float w = fast_exp2((m - M) * c2);
+        l += w * part_ml[base * 2 + 1];
+#pragma unroll
+        for (int j = 0; j < (D + 63) / 64; ++j) {
+            const int d = j * 64 + lane;
+            if (d < D) acc[j] += w * part_o[base * D + d];
+        }
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+    for (int j = 0; j < (D + 63) / 64; ++j) {
+        const int d = j * 64 + lane;
+        if (d < D) out[(long)row * ldo + head * D + d] = (T)(acc[j] * inv);
+    }
 }
 
 }  // namespace lmi

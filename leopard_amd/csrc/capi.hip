@@ -173,9 +173,31 @@ int dispatch_attn(const AttnArgs& a, int n_seq, int max_q, int causal, int use_t
                   : launch_attn<T, D, false, false>(a, n_seq, max_q, stream);
 }
 
-template <typename T, int EPI>
-int launch_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, void* stream) {
+// units per workgroup of the K-split kernel: a multiple of the R/RW outputs handled per pass, sized for about a thousand
+// workgroups, at most 128 partial slots per wave
+static int gemv_upb(int units, int per_pass, int max_units) {
+    int upb = per_pass;
+    while ((units + upb - 1) / upb > 1024 && upb * 2 <= max_units) upb *= 2;
+    return upb;
+}
+template <typename T, int EPI, bool NORM>
+int launch_gemv(const void* W, const void* x, const float* gamma, float eps, const float* bias, void* out, int N, int K, int ldw,
+                void* stream) {
     const int rows = (EPI == GEMV_SWIGLU_T) ? N / 2 : N;
+    constexpr int RW = (EPI == GEMV_SWIGLU_T) ? 2 : 1;
+    if (K == 4096) {
+        const int upb = gemv_upb(rows, 8 / RW, 128 / RW);
+        LMI_LAUNCH((gemv_split_kernel<T, EPI, 2, 8, NORM>), dim3((rows + upb - 1) / upb), dim3(256), 0, stream, (const T*)W, x, gamma, eps,
+                   bias, out, N, K, ldw, upb);
+        return check_launch("lmi_gemv");
+    }
+    if (K == 14336 && !NORM) {
+        const int upb = gemv_upb(rows, 4 / RW, 128 / RW);
+        LMI_LAUNCH((gemv_split_kernel<T, EPI, 7, 4, false>), dim3((rows + upb - 1) / upb), dim3(256), 0, stream, (const T*)W, x, gamma, eps,
+                   bias, out, N, K, ldw, upb);
+        return check_launch("lmi_gemv");
+    }
+    if (NORM) return fail(LMI_EINVAL, "lmi_gemv_rmsnorm: K = %d is not a supported hidden size (4096)", K);
     const int grid = grid_for(rows, 4);
     if (K <= 4096) {
         LMI_LAUNCH((gemv_kernel<T, EPI, 8>), dim3(grid), dim3(256), 0, stream, (const T*)W, (const T*)x, bias, out, N, K, ldw);
@@ -184,13 +206,14 @@ int launch_gemv(const void* W, const void* x, const float* bias, void* out, int 
     }
     return check_launch("lmi_gemv");
 }
-template <typename T>
-int dispatch_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, int epi, void* stream) {
+template <typename T, bool NORM>
+int dispatch_gemv(const void* W, const void* x, const float* gamma, float eps, const float* bias, void* out, int N, int K, int ldw,
+                  int epi, void* stream) {
     switch (epi) {
-        case 0: return launch_gemv<T, GEMV_STORE_F32>(W, x, bias, out, N, K, ldw, stream);
-        case 1: return launch_gemv<T, GEMV_STORE_T>(W, x, bias, out, N, K, ldw, stream);
-        case 2: return launch_gemv<T, GEMV_RESID_F32>(W, x, bias, out, N, K, ldw, stream);
-        case 3: return launch_gemv<T, GEMV_SWIGLU_T>(W, x, bias, out, N, K, ldw, stream);
+        case 0: return launch_gemv<T, GEMV_STORE_F32, NORM>(W, x, gamma, eps, bias, out, N, K, ldw, stream);
+        case 1: return launch_gemv<T, GEMV_STORE_T, NORM>(W, x, gamma, eps, bias, out, N, K, ldw, stream);
+        case 2: return launch_gemv<T, GEMV_RESID_F32, NORM>(W, x, gamma, eps, bias, out, N, K, ldw, stream);
+        case 3: return launch_gemv<T, GEMV_SWIGLU_T, NORM>(W, x, gamma, eps, bias, out, N, K, ldw, stream);
     }
     return fail(LMI_EINVAL, "lmi_gemv: bad epilogue %d", epi);
 }
@@ -215,8 +238,8 @@ int im2col_impl(const void* in, int from_u8, void* out, int n_tiles, int H, int 
 }
 template <typename T>
 int rope_impl(void* qkv, int S, int ld, int nq, int nkv, int D, const float* c, const float* s, void* kc, void* vc,
-              int ldc, int pos0, int grid, void* stream) {
-    LMI_LAUNCH((rope_kernel<T>), dim3(grid), dim3(256), 0, stream, (T*)qkv, S, ld, nq, nkv, D, c, s, (T*)kc, (T*)vc, ldc, pos0);
+              int ldc, int pos0, const int* pos_dev, int grid, void* stream) {
+    LMI_LAUNCH((rope_kernel<T>), dim3(grid), dim3(256), 0, stream, (T*)qkv, S, ld, nq, nkv, D, c, s, (T*)kc, (T*)vc, ldc, pos0, pos_dev);
     return check_launch("lmi_rope_qk");
 }
 template <typename T>
@@ -235,6 +258,44 @@ int merge_impl(const int64_t* ids, const int64_t* src, const void* table, const 
         if ((dtype) == LMI_BF16) return CALL_BF16;                                    \
         return fail(LMI_EINVAL, "%s: dtype must be LMI_F16 or LMI_BF16", __func__);   \
     } while (0)
+
+// ---- decode attention: split-KV LDS-DMA kernel + merge ------------------------------------------------------------------
+static int decode_splits(int max_seqlen_k, int* split_tiles) {
+    const int tiles = (max_seqlen_k + ATT_BKV - 1) / ATT_BKV;
+    int st = 8;                                                  // 512 keys per workgroup ...
+    while ((tiles + st - 1) / st > 64) st *= 2;                  // ... unless that needs more than 64 splits
+    *split_tiles = st;
+    const int n = (tiles + st - 1) / st;
+    return n < 2 ? 2 : n;      // a single chunk also goes through the partial + merge pair: one code path, and the grid
+                               // never depends on device data (graph capture)
+}
+
+template <typename T>
+int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, int ldo, void* stream) {
+    static bool attr_set = false;
+    if (!attr_set) { allow_big_lds(attn_fwd_dma_kernel<T, 128, true>, 160 * 1024); attr_set = true; }
+    a.n_qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
+    LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true>), dim3(a.n_qblocks * a.n_heads * n_seq * a.n_splits), dim3(ATT_THREADS),
+               AttnDmaGeom<128>::SMEM, stream, a);
+    const long items = (long)q_rows * a.n_heads;
+    LMI_LAUNCH((attn_combine_kernel<T, 128>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, (const float*)a.part_o,
+               (const float*)a.part_ml, (T*)out, a.cu_q, n_seq, a.n_heads, a.n_splits, a.part_rows, ldo, a.scale);
+    return check_launch("lmi_attn_decode_fwd");
+}
+
+int rope_entry(const char* who, void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_table,
+                      const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, const int* pos_dev,
+                      int dtype, void* stream) {
+    if (!qkv || !cos_table || !sin_table || S < 0 || (head_dim & 15) || (ld & 7) || ((k_cache || v_cache) && (ld_cache & 7)) ||
+        ((k_cache != nullptr) != (v_cache != nullptr)))
+        return fail(LMI_EINVAL, "%s: bad argument", who);
+    if (S == 0) return LMI_OK;
+    const long work = (long)S * ((n_q_heads + n_kv_heads) * (head_dim / 16) + (v_cache ? n_kv_heads * head_dim / 8 : 0));
+    const int grid = grid_for(work, 256);
+    LMI_DISPATCH_T(dtype, (rope_impl<f16_t>(qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, k_cache, v_cache, ld_cache, cache_pos0, pos_dev, grid, stream)),
+                   (rope_impl<bf16_t>(qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, k_cache, v_cache, ld_cache, cache_pos0, pos_dev, grid, stream)));
+}
+
 
 extern "C" {
 
@@ -355,6 +416,7 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
+    a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr;
     if (head_dim == 128)
         LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
                        (dispatch_attn<bf16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
@@ -365,16 +427,50 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
                    (dispatch_attn<bf16_t, 72>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
 }
 
+int64_t lmi_attn_decode_workspace_bytes(int q_rows, int n_heads, int head_dim, int max_seqlen_k) {
+    if (q_rows < 0 || n_heads <= 0 || head_dim <= 0 || max_seqlen_k < 0) return -1;
+    int st;
+    const int n = decode_splits(max_seqlen_k, &st);
+    return (int64_t)n * q_rows * n_heads * (head_dim + 2) * 4;
+}
+
+int lmi_attn_decode_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
+                        int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                        int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                        int dtype, void* stream) {
+    if (!q || !k || !v || !out || !cu_seqlens_q || !cu_seqlens_k || !workspace) return fail(LMI_EINVAL, "lmi_attn_decode_fwd: null pointer");
+    if (n_seq < 0 || max_seqlen_q < 0 || max_seqlen_k < 0 || q_rows < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads))
+        return fail(LMI_EINVAL, "lmi_attn_decode_fwd: bad sizes");
+    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_attn_decode_fwd: head_dim %d (only 128)", head_dim);
+    if (window < 0) return fail(LMI_EINVAL, "lmi_attn_decode_fwd: window must be >= 0");
+    if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) ||
+        !aligned16(workspace))
+        return fail(LMI_EINVAL, "lmi_attn_decode_fwd: alignment");
+    const int64_t need = lmi_attn_decode_workspace_bytes(q_rows, n_heads, head_dim, max_seqlen_k);
+    if (workspace_bytes < need) return fail(LMI_EINVAL, "lmi_attn_decode_fwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    if (n_seq == 0 || max_seqlen_q == 0 || q_rows == 0) return LMI_OK;
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
+    a.n_splits = decode_splits(max_seqlen_k, &a.split_tiles);
+    a.part_rows = q_rows;
+    a.part_o = (float*)workspace;
+    a.part_ml = a.part_o + (size_t)a.n_splits * q_rows * n_heads * head_dim;
+    LMI_DISPATCH_T(dtype, (attn_decode_impl<f16_t>(a, n_seq, max_seqlen_q, q_rows, out, ldo, stream)),
+                   (attn_decode_impl<bf16_t>(a, n_seq, max_seqlen_q, q_rows, out, ldo, stream)));
+}
+
 int lmi_rope_qk(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_table,
                 const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int dtype, void* stream) {
-    if (!qkv || !cos_table || !sin_table || S < 0 || (head_dim & 15) || (ld & 7) || ((k_cache || v_cache) && (ld_cache & 7)) ||
-        ((k_cache != nullptr) != (v_cache != nullptr)))
-        return fail(LMI_EINVAL, "lmi_rope_qk: bad argument");
-    if (S == 0) return LMI_OK;
-    const long work = (long)S * ((n_q_heads + n_kv_heads) * (head_dim / 16) + (v_cache ? n_kv_heads * head_dim / 8 : 0));
-    const int grid = grid_for(work, 256);
-    LMI_DISPATCH_T(dtype, (rope_impl<f16_t>(qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, k_cache, v_cache, ld_cache, cache_pos0, grid, stream)),
-                   (rope_impl<bf16_t>(qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, k_cache, v_cache, ld_cache, cache_pos0, grid, stream)));
+    return rope_entry("lmi_rope_qk", qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, k_cache, v_cache, ld_cache,
+                      cache_pos0, nullptr, dtype, stream);
+}
+
+int lmi_rope_qk_at(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all,
+                   const float* sin_all, void* k_cache, void* v_cache, int ld_cache, const int* pos_dev, int dtype, void* stream) {
+    if (!pos_dev) return fail(LMI_EINVAL, "lmi_rope_qk_at: null position pointer");
+    return rope_entry("lmi_rope_qk_at", qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, ld_cache, 0,
+                      pos_dev, dtype, stream);
 }
 
 int lmi_embed_merge(const int64_t* ids, const int64_t* src, const void* embed_table, const float* visual_tokens, float* out,
@@ -389,8 +485,17 @@ int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, 
              void* stream) {
     if (!W || !x || !out || N <= 0 || K <= 0 || (K & 7) || (ldw & 7) || K > 28 * 512 || (epilogue == 3 && (N & 63)))
         return fail(LMI_EINVAL, "lmi_gemv: bad argument (N=%d K=%d)", N, K);
-    LMI_DISPATCH_T(dtype, dispatch_gemv<f16_t>(W, x, bias, out, N, K, ldw, epilogue, stream),
-                   dispatch_gemv<bf16_t>(W, x, bias, out, N, K, ldw, epilogue, stream));
+    LMI_DISPATCH_T(dtype, (dispatch_gemv<f16_t, false>(W, x, nullptr, 0.f, bias, out, N, K, ldw, epilogue, stream)),
+                   (dispatch_gemv<bf16_t, false>(W, x, nullptr, 0.f, bias, out, N, K, ldw, epilogue, stream)));
+}
+
+int lmi_gemv_rmsnorm(const void* W, const float* x, const float* norm_weight, float eps, void* out, int N, int K, int ldw,
+                     int epilogue, int dtype, void* stream) {
+    if (!W || !x || !norm_weight || !out || N <= 0 || K <= 0 || (ldw & 7) || (epilogue == 3 && (N & 63)) || !aligned16(x) ||
+        !aligned16(norm_weight))
+        return fail(LMI_EINVAL, "lmi_gemv_rmsnorm: bad argument (N=%d K=%d)", N, K);
+    LMI_DISPATCH_T(dtype, (dispatch_gemv<f16_t, true>(W, x, norm_weight, eps, nullptr, out, N, K, ldw, epilogue, stream)),
+                   (dispatch_gemv<bf16_t, true>(W, x, norm_weight, eps, nullptr, out, N, K, ldw, epilogue, stream)));
 }
 
 }  // extern "C"

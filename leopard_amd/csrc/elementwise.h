@@ -160,7 +160,11 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void rope_kernel(T* qkv, int S, int ld, int n_q, int n_kv, int D, const float* cosT, const float* sinT,
-                            T* k_cache, T* v_cache, int ld_cache, int cache_pos0) {
+                            T* k_cache, T* v_cache, int ld_cache, int cache_pos0, const int* pos_dev) {
+    // pos_dev (decode under a captured graph): the position of row 0 lives in device memory; it indexes the cos/sin
+    // tables (built for every position of the cache) and the cache row alike
+    const int table0 = pos_dev ? *pos_dev : 0;
+    if (pos_dev) cache_pos0 = table0;
     typedef typename vec_of<T>::x8 T8;
     const int half = D >> 1, cpr = half >> 3;                 // chunks per half row
     const int rot_heads = n_q + n_kv;
@@ -175,8 +179,8 @@ __global__ void rope_kernel(T* qkv, int S, int ld, int n_q, int n_kv, int D, con
             T* p1 = row + h * D + c * 8;
             T* p2 = p1 + half;
             const T8 a = *(const T8*)p1, b = *(const T8*)p2;
-            const float* cs = cosT + (long)s * half + c * 8;
-            const float* sn = sinT + (long)s * half + c * 8;
+            const float* cs = cosT + (long)(table0 + s) * half + c * 8;
+            const float* sn = sinT + (long)(table0 + s) * half + c * 8;
             T8 oa, ob;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -278,6 +282,102 @@ __global__ void __launch_bounds__(256) gemv_kernel(const T* W, const T* x, const
                 else if (EPI == GEMV_STORE_T) ((T*)out)[n] = (T)v;
                 else ((float*)out)[n] += v;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode GEMV, K split across the 4 waves of a workgroup (hidden sizes K = CPW*2048: 4096, 14336).
+//   * each wave keeps only its quarter of x in registers (read once per workgroup, not once per output row) and streams
+//     the matching quarter of R weight rows at a time (R*CPW 16-byte loads in flight per lane);
+//   * NORM: x arrives as the fp32 residual row and the RMSNorm (same arithmetic as norm_kernel) is applied while it is
+//     loaded, so the decode step needs no separate norm launch;
+//   * per-row partial sums of the 4 waves meet in LDS once per workgroup, then the epilogue runs.
+// Epilogues as gemv_kernel.  `units` = outputs (row pairs for SwiGLU); workgroup b owns units [b*UPB, (b+1)*UPB).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int EPI, int CPW, int R, bool NORM>
+__global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void* xin, const float* gamma, float eps, const float* bias,
+                                                         void* out, int N, int K, int ldw, int UPB) {
+    typedef typename vec_of<T>::x8 T8;
+    constexpr int RW = (EPI == GEMV_SWIGLU_T) ? 2 : 1;            // weight rows per output
+    __shared__ float part[4][128];
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int units = (EPI == GEMV_SWIGLU_T) ? N >> 1 : N;
+    const int u0 = blockIdx.x * UPB, u1 = imin(units, u0 + UPB);
+    // ---- this wave's slice of x ---------------------------------------------------------------------------------
+    T8 xv[CPW];
+    if (NORM) {
+        const float* xf = (const float*)xin;
+        f32x4 lo[CPW], hi[CPW];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int e = ((wave * CPW + i) * 64 + lane) * 8;
+            lo[i] = *(const f32x4*)(xf + e);
+            hi[i] = *(const f32x4*)(xf + e + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss += lo[i][j] * lo[i][j] + hi[i][j] * hi[i][j];
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int e = ((wave * CPW + i) * 64 + lane) * 8;
+            const f32x4 g0 = *(const f32x4*)(gamma + e), g1 = *(const f32x4*)(gamma + e + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xv[i][j] = (T)(g0[j] * (lo[i][j] * rstd));
+                xv[i][j + 4] = (T)(g1[j] * (hi[i][j] * rstd));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) xv[i] = *(const T8*)((const T*)xin + ((wave * CPW + i) * 64 + lane) * 8);
+    }
+    // ---- stream the weight rows, R at a time -------------------------------------------------------------------
+    auto row_of = [&](int u, int half) -> int {                    // weight row of output u (SwiGLU: gate / up interleaved by 32)
+        if (EPI == GEMV_SWIGLU_T) return ((u >> 5) << 6) + (u & 31) + 32 * half;
+        return u;
+    };
+    for (int ub = u0; ub < u1; ub += R / RW) {
+        T8 wv[R][CPW];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int u = imin(ub + r / RW, units - 1);
+            const T* wrow = W + (long)row_of(u, r % RW) * ldw;
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) wv[r][i] = *(const T8*)(wrow + ((wave * CPW + i) * 64 + lane) * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPW; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float)wv[r][i][e] * (float)xv[i][e];
+            acc = wave_sum(acc);
+            const int slot = (ub - u0) * RW + r;
+            if (lane == 0 && slot < 128) part[wave][slot] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: one thread per output of the workgroup ----------------------------------------------------
+    const int t = threadIdx.x;
+    if (t < u1 - u0) {
+        const int u = u0 + t;
+        if (EPI == GEMV_SWIGLU_T) {
+            const float g = part[0][2 * t] + part[1][2 * t] + part[2][2 * t] + part[3][2 * t];
+            const float up = part[0][2 * t + 1] + part[1][2 * t + 1] + part[2][2 * t + 1] + part[3][2 * t + 1];
+            ((T*)out)[u] = (T)(g / (1.0f + lmi::fexp(-g)) * up);
+        } else {
+            float v = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+            if (bias) v += bias[u];
+            if (EPI == GEMV_STORE_F32) ((float*)out)[u] = v;
+            else if (EPI == GEMV_STORE_T) ((T*)out)[u] = (T)v;
+            else ((float*)out)[u] += v;
         }
     }
 }

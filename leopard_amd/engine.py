@@ -98,6 +98,7 @@ class LeopardEngine:
         self.dtype = weights.dtype
         self.device = torch.device(device) if device is not None else weights.embed.device
         self.use_tr = use_tr
+        self.use_graphs = True         # capture the decode step in a HIP graph (cuda devices only)
         tc = cfg.text_config
         self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
         self._geom_cache: Dict[tuple, tuple] = {}      # seq_lens -> (cu, cos, sin, last_rows) device tensors
@@ -293,36 +294,105 @@ class LeopardEngine:
     # a12: one greedy decode step with the KV cache (EVAL:291-320 semantics: position = number of cached tokens)
     # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def decode_step(self, token_id: int, cache: KVCache) -> torch.Tensor:
+    # ------------------------------------------------------------------------------------------------
+    # a12: decode.  One step = ~290 launches of memory-bound kernels, so the step is captured once per KV cache into a
+    # HIP graph over static buffers; the token id and the position live in device memory (lmi_rope_qk_at, device
+    # cu_seqlens), the graph itself takes the argmax and advances the position, and the host only reads the new token.
+    # ------------------------------------------------------------------------------------------------
+    def _decode_state(self, cache: KVCache):
+        st = getattr(cache, "_decode_state", None)
+        if st is not None:
+            return st
+        W, tc = self.W, self.cfg.text_config
+        H, KV, hd, D = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim, tc.hidden_size
+        dev = self.device
+
+        class St:
+            pass
+        st = St()
+        st.tok = torch.zeros(1, dtype=torch.int64, device=dev)
+        st.src0 = torch.zeros(1, dtype=torch.int64, device=dev)
+        st.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        st.cu_q = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+        st.cu_k = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+        st.x = self._empty(1, D, dtype=torch.float32)
+        st.h, st.qkv, st.att = self._empty(1, D), self._empty(1, (H + 2 * KV) * hd), self._empty(1, H * hd)
+        st.gu = self._empty(1, W.llm_ff)
+        st.logits = self._empty(W.lm_head.shape[0], dtype=torch.float32)
+        st.cos, st.sin = self.rope_tables(torch.arange(cache.capacity))
+        st.ws = torch.empty(self.ops.decode_workspace_elems(1, H, hd, cache.capacity), dtype=torch.float32, device=dev)
+        st.graph = None
+        cache._decode_state = st
+        return st
+
+    def _decode_body(self, st, cache: KVCache):
+        """Everything of one decode step that does not depend on host values."""
         ops, W, tc = self.ops, self.W, self.cfg.text_config
         H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
-        qw, kw, D = H * hd, KV * hd, tc.hidden_size
-        pos = cache.length
-        if pos >= cache.capacity:
-            raise RuntimeError("KV cache is full")
-        ids = torch.tensor([token_id], dtype=torch.int64, device=self.device)
-        x = self._empty(1, D, dtype=torch.float32)
-        ops.embed_merge(ids, torch.zeros(1, dtype=torch.int64, device=self.device), W.embed, None, x)
-        cos, sin = self.rope_tables(torch.tensor([pos]))
-        h, qkv, att, gu = self._empty(1, D), self._empty(1, qw + 2 * kw), self._empty(1, qw), self._empty(1, W.llm_ff)
-        cu_q = torch.tensor([0, 1], dtype=torch.int32, device=self.device)
-        cu_k = torch.tensor([0, pos + 1], dtype=torch.int32, device=self.device)
-        scale = hd ** -0.5
+        qw = H * hd
+        ops.embed_merge(st.tok, st.src0, W.embed, None, st.x)
+        fuse = tc.hidden_size == 4096                 # lmi_gemv_rmsnorm: the norm rides in the projection's launch
         for i, L in enumerate(W.llm_layers):
-            ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
-            ops.gemv(L.qkv_w, h[0], qkv[0], epilogue=1)
-            ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i], cache.v[i], pos)
-            ops.attention(qkv[:, :qw], cache.k[i], cache.v[i], att, cu_q, cu_k, 1, H, KV, hd, scale, True, self.use_tr,
-                          window=tc.sliding_window or 0)
-            ops.gemv(L.o_w, att[0], x[0], epilogue=2)
-            ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
-            ops.gemv(L.gu_w, h[0], gu[0], epilogue=3)
-            ops.gemv(L.down_w, gu[0], x[0], epilogue=2)
-        cache.length = pos + 1
-        ops.rmsnorm(x, W.final_norm, h, tc.rms_norm_eps)
-        logits = self._empty(W.lm_head.shape[0], dtype=torch.float32)
-        ops.gemv(W.lm_head, h[0], logits)
-        return logits[:tc.vocab_size]
+            if fuse:
+                ops.gemv_rmsnorm(L.qkv_w, st.x[0], L.in_norm, tc.rms_norm_eps, st.qkv[0], epilogue=1)
+            else:
+                ops.rmsnorm(st.x, L.in_norm, st.h, tc.rms_norm_eps)
+                ops.gemv(L.qkv_w, st.h[0], st.qkv[0], epilogue=1)
+            ops.rope_qk_at(st.qkv, H, KV, hd, st.cos, st.sin, cache.k[i], cache.v[i], st.pos)
+            ops.attention_decode(st.qkv[:, :qw], cache.k[i], cache.v[i], st.att, st.cu_q, st.cu_k, 1, cache.capacity, H, KV, hd,
+                                 hd ** -0.5, st.ws, window=tc.sliding_window or 0)
+            ops.gemv(L.o_w, st.att[0], st.x[0], epilogue=2)
+            if fuse:
+                ops.gemv_rmsnorm(L.gu_w, st.x[0], L.post_norm, tc.rms_norm_eps, st.gu[0], epilogue=3)
+            else:
+                ops.rmsnorm(st.x, L.post_norm, st.h, tc.rms_norm_eps)
+                ops.gemv(L.gu_w, st.h[0], st.gu[0], epilogue=3)
+            ops.gemv(L.down_w, st.gu[0], st.x[0], epilogue=2)
+        if fuse:
+            ops.gemv_rmsnorm(W.lm_head, st.x[0], W.final_norm, tc.rms_norm_eps, st.logits, epilogue=0)
+        else:
+            ops.rmsnorm(st.x, W.final_norm, st.h, tc.rms_norm_eps)
+            ops.gemv(W.lm_head, st.h[0], st.logits)
+        # greedy choice and position advance stay on the device (torch ops as plumbing; all capturable)
+        torch.argmax(st.logits[:tc.vocab_size], dim=0, keepdim=True, out=st.tok)
+        st.pos.add_(1)
+        st.cu_k[1:].add_(1)
+
+    def _decode_run(self, st, cache: KVCache):
+        if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs:
+            self._decode_body(st, cache)
+            return
+        if st.graph is None:
+            # warm-up outside capture (first-use attribute calls, allocator), on copies of the device counters
+            keep = (st.tok.clone(), st.pos.clone(), st.cu_k.clone())
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self._decode_body(st, cache)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.cu_k.copy_(keep[2])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_body(st, cache)
+            st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.cu_k.copy_(keep[2])      # capture does not execute
+            st.graph = g
+        st.graph.replay()
+
+    def _decode_seed(self, st, cache: KVCache, token_id: int):
+        if cache.length >= cache.capacity:
+            raise RuntimeError("KV cache is full")
+        st.tok.fill_(int(token_id))
+        st.pos.fill_(cache.length)
+        st.cu_k[1:].fill_(cache.length + 1)
+
+    @torch.no_grad()
+    def decode_step(self, token_id: int, cache: KVCache) -> torch.Tensor:
+        """Append one token: returns its logits [vocab] (fp32, a view of a static buffer) and advances the cache."""
+        st = self._decode_state(cache)
+        self._decode_seed(st, cache, token_id)
+        self._decode_run(st, cache)
+        cache.length += 1
+        return st.logits[:self.cfg.text_config.vocab_size]
 
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, tiles: Optional[torch.Tensor], max_new_tokens: int = 128,
@@ -336,9 +406,13 @@ class LeopardEngine:
         out = [int(t) for t in ids.reshape(-1).tolist()]
         nxt = int(res.logits_last.argmax())
         eos = set(int(e) for e in eos_token_id)
+        st = self._decode_state(cache)
+        self._decode_seed(st, cache, nxt)
         for step in range(max_new_tokens):
             out.append(nxt)
             if nxt in eos or step == max_new_tokens - 1:
                 break
-            nxt = int(self.decode_step(nxt, cache).argmax())
+            self._decode_run(st, cache)              # consumes st.tok at st.pos, leaves the next token / position on the device
+            cache.length += 1
+            nxt = int(st.tok.item())
         return torch.tensor([out], dtype=torch.long, device=input_ids.device)

@@ -110,6 +110,29 @@ class Ops:
                                                  int(window), int(use_tr), _DT[q.dtype], self._stream(out)))
         return out
 
+    def attention_decode(self, q, k, v, out, cu_q, cu_k, max_seqlen_q, max_seqlen_k, n_heads, n_kv_heads, head_dim, scale,
+                         workspace: torch.Tensor, window=0):
+        """Split-KV attention for a few query rows against a long cache (decode).  workspace: fp32, decode_workspace_elems()."""
+        n_seq = cu_q.numel() - 1
+        self._check(self.lib.lmi_attn_decode_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(cu_q), _ptr(cu_k), n_seq, int(max_seqlen_q),
+                                                 int(max_seqlen_k), q.shape[0], n_heads, n_kv_heads, head_dim, q.stride(0), k.stride(0),
+                                                 v.stride(0), out.stride(0), float(scale), int(window), _ptr(workspace),
+                                                 workspace.numel() * workspace.element_size(), _DT[q.dtype], self._stream(out)))
+        return out
+
+    def decode_workspace_elems(self, q_rows, n_heads, head_dim, max_seqlen_k) -> int:
+        n = int(self.lib.lmi_attn_decode_workspace_bytes(q_rows, n_heads, head_dim, max_seqlen_k))
+        if n < 0:
+            raise RuntimeError("lmi_attn_decode_workspace_bytes: bad arguments")
+        return n // 4
+
+    def rope_qk_at(self, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, pos_dev):
+        """rope_qk with the position of row 0 taken from the device int32 ``pos_dev`` (graph-capturable decode step)."""
+        self._check(self.lib.lmi_rope_qk_at(_ptr(qkv), qkv.shape[0], qkv.stride(0), n_q_heads, n_kv_heads, head_dim, _ptr(cos_all),
+                                            _ptr(sin_all), _ptr(k_cache), _ptr(v_cache), k_cache.stride(0), _ptr(pos_dev),
+                                            _DT[qkv.dtype], self._stream(qkv)))
+        return qkv
+
     def rope_qk(self, qkv, n_q_heads, n_kv_heads, head_dim, cos, sin, k_cache=None, v_cache=None, cache_pos0=0):
         S = qkv.shape[0]
         ldc = 0 if k_cache is None else k_cache.stride(0)
@@ -129,4 +152,11 @@ class Ops:
         N, K = w.shape
         self._check(self.lib.lmi_gemv(_ptr(w), _ptr(x), _ptr(bias), _ptr(out), N, K, w.stride(0), epilogue,
                                       _DT[w.dtype], self._stream(out)))
+        return out
+
+    def gemv_rmsnorm(self, w, x_f32, norm_weight, eps, out, epilogue=1):
+        """out = epilogue(w @ rmsnorm(x_f32)): the decode step's norm + projection in one launch (K = 4096)."""
+        N, K = w.shape
+        self._check(self.lib.lmi_gemv_rmsnorm(_ptr(w), _ptr(x_f32), _ptr(norm_weight), float(eps), _ptr(out), N, K, w.stride(0),
+                                              epilogue, _DT[w.dtype], self._stream(out)))
         return out

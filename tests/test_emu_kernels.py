@@ -419,3 +419,78 @@ def test_attention_kernel_variants(ops, dma):
     finally:
         ops.set_option("attn.dma", 1)
 
+
+
+def test_rope_at_device_position_matches_host_position(ops):
+    """lmi_rope_qk_at (position from device memory, full tables) = lmi_rope_qk (host position, table slice)."""
+    from oracle.leopard_oracle import rope_tables
+    from leopard_amd.config import RopeScaling
+    nq, nkv, D, cap = 4, 2, 128, 40
+    cos, sin = rope_tables(torch.arange(cap), D, 5e5, RopeScaling())
+    cos, sin = cos[:, :D // 2].contiguous(), sin[:, :D // 2].contiguous()
+    for pos, S in ((0, 1), (17, 1), (30, 3)):
+        qkv = rnd((S, (nq + 2 * nkv) * D), torch.float16, 80 + pos)
+        a, b = qkv.clone(), qkv.clone()
+        kc1, vc1 = torch.zeros(cap, nkv * D, dtype=torch.float16), torch.zeros(cap, nkv * D, dtype=torch.float16)
+        kc2, vc2 = torch.zeros_like(kc1), torch.zeros_like(vc1)
+        ops.rope_qk(a, nq, nkv, D, cos[pos:pos + S].contiguous(), sin[pos:pos + S].contiguous(), kc1, vc1, cache_pos0=pos)
+        ops.rope_qk_at(b, nq, nkv, D, cos, sin, kc2, vc2, torch.tensor([pos], dtype=torch.int32))
+        assert torch.equal(a, b) and torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+
+
+@pytest.mark.parametrize("lq,lk,cap", [(1, 70, 70), (1, 700, 2048), (5, 1300, 1300), (1, 1, 64)])
+def test_attention_decode_split_kv(ops, lq, lk, cap):
+    """Split-KV decode attention (partials + merge) = the reference attention, for a launch geometry fixed by `cap`."""
+    H, KV, D = 4, 2, 128
+    dtype = torch.float16
+    q = rnd((lq, H * D), dtype, 90)
+    k, v = rnd((lk, KV * D), dtype, 91), rnd((lk, KV * D), dtype, 92)
+    out = torch.full((lq, H * D), float("nan"), dtype=dtype)
+    ws = torch.empty(ops.decode_workspace_elems(lq, H, D, cap), dtype=torch.float32)
+    cu_q, cu_k = torch.tensor([0, lq], dtype=torch.int32), torch.tensor([0, lk], dtype=torch.int32)
+    ops.attention_decode(q, k, v, out, cu_q, cu_k, lq, cap, H, KV, D, D ** -0.5, ws)
+    ref = attn_ref(q, k, v, [0, lq], [0, lk], H, KV, D, D ** -0.5, True)
+    assert (out.float() - ref).abs().max() <= 4e-3
+    one = torch.empty_like(out)
+    ops.attention(q, k, v, one, cu_q, cu_k, lq, H, KV, D, D ** -0.5, True, True)
+    assert (out.float() - one.float()).abs().max() <= 2e-3
+
+
+@pytest.mark.parametrize("K,N", [(4096, 200), (14336, 70)])
+def test_gemv_split_k_kernel(ops, K, N):
+    """The decode GEMV that splits K over the waves of a workgroup (hidden sizes 4096 / 14336), every epilogue."""
+    dtype = torch.float16
+    w, x = rnd((N, K), dtype, 100, 0.05), rnd((K,), dtype, 101)
+    ref = w.float() @ x.float()
+    out = torch.empty(N)
+    ops.gemv(w, x, out)
+    assert ((out - ref).abs() / (1 + ref.abs())).max() <= 2e-3
+    o16 = torch.empty(N, dtype=dtype)
+    ops.gemv(w, x, o16, epilogue=1)
+    assert ((o16.float() - ref).abs() / (1 + ref.abs())).max() <= 4e-3
+    acc = torch.ones(N)
+    ops.gemv(w, x, acc, epilogue=2)
+    assert ((acc - 1 - ref).abs() / (1 + ref.abs())).max() <= 2e-3
+    if K == 4096:
+        N2 = 192
+        w2 = rnd((N2, K), dtype, 102, 0.05)
+        r2 = w2.float() @ x.float()
+        wi = torch.stack([w2[:96].view(3, 32, K), w2[96:].view(3, 32, K)], dim=1).reshape(N2, K).contiguous()
+        sw = torch.empty(96, dtype=dtype)
+        ops.gemv(wi, x, sw, epilogue=3)
+        r = torch.nn.functional.silu(r2[:96]) * r2[96:]
+        assert ((sw.float() - r).abs() / (1 + r.abs())).max() <= 4e-3
+
+
+def test_gemv_rmsnorm_equals_rmsnorm_then_gemv(ops):
+    dtype = torch.float16
+    K, N = 4096, 136
+    w = rnd((N, K), dtype, 110, 0.05)
+    x = rnd((1, K), torch.float32, 111, 3.0)
+    g = rnd((K,), torch.float32, 112).abs() + 0.5
+    h = torch.empty(1, K, dtype=dtype)
+    ops.rmsnorm(x, g, h, 1e-5)
+    a, b = torch.empty(N, dtype=dtype), torch.empty(N, dtype=dtype)
+    ops.gemv(w, h[0], a, epilogue=1)
+    ops.gemv_rmsnorm(w, x[0], g, 1e-5, b, epilogue=1)
+    assert torch.equal(a, b)
