@@ -308,3 +308,39 @@ def test_attention_full_size_properties(ops):
     ones = torch.ones(S, KV * D, dtype=dtype, device=DEV)
     ops.attention(q, k, ones, out, cu, cu, S, H, KV, D, D ** -0.5, True, True)
     assert (out.float() - 1).abs().max() <= 2.0 ** -7
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_decode_split_kv_long_cache(ops, dtype):
+    """lmi_attn_decode_fwd at the C3 context: one (and five) query rows against 7187 keys, launch geometry fixed by a
+    larger cache capacity (as under the captured decode graph), against the fp32 reference and the single-pass kernel."""
+    H, KV, D, lk, cap = 32, 8, 128, 7187, 7187 + 128
+    k, v = rnd((cap, KV * D), dtype, 65), rnd((cap, KV * D), dtype, 66)
+    for lq in (1, 5):
+        q = rnd((lq, H * D), dtype, 67)
+        out = torch.full((lq, H * D), float("nan"), dtype=dtype, device=DEV)
+        ws = torch.empty(ops.decode_workspace_elems(lq, H, D, cap), dtype=torch.float32, device=DEV)
+        cu_q = torch.tensor([0, lq], dtype=torch.int32, device=DEV)
+        cu_k = torch.tensor([0, lk], dtype=torch.int32, device=DEV)
+        ops.attention_decode(q, k, v, out, cu_q, cu_k, lq, cap, H, KV, D, D ** -0.5, ws)
+        ref = attn_ref(q, k[:lk], v[:lk], [0, lq], [0, lk], H, KV, D, D ** -0.5, True)
+        assert (out.float() - ref).abs().max() <= 3 * eps(dtype)
+        one = torch.empty_like(out)
+        ops.attention(q, k, v, one, cu_q, cu_k, lq, H, KV, D, D ** -0.5, True, True)
+        assert (out.float() - one.float()).abs().max() <= 3 * eps(dtype)
+
+
+def test_gemv_rmsnorm_equals_rmsnorm_then_gemv(ops):
+    dtype = torch.float16
+    K, N = 4096, 6144
+    w = rnd((N, K), dtype, 110, 0.02)
+    x = rnd((1, K), torch.float32, 111, 3.0)
+    g = rnd((K,), torch.float32, 112).abs() + 0.5
+    h = torch.empty(1, K, dtype=dtype, device=DEV)
+    ops.rmsnorm(x, g, h, 1e-5)
+    a, b = torch.empty(N, dtype=dtype, device=DEV), torch.empty(N, dtype=dtype, device=DEV)
+    ops.gemv(w, h[0], a, epilogue=1)
+    ops.gemv_rmsnorm(w, x[0], g, 1e-5, b, epilogue=1)
+    assert torch.equal(a, b)
+    ref = w.float() @ h[0].float()
+    check(a, ref, dtype, k=2, what="gemv_rmsnorm")
