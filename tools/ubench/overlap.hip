@@ -16,7 +16,7 @@ __device__ __forceinline__ void vop(float& x, float c1, float c2) {
 }
 
 // role 0: every wave runs NM MFMAs with NV/NM VALU ops after each; role 1: waves 0..3 MFMA only, waves 4..7 VALU only
-template <int NM, int NV, int OP>
+template <int NM, int NV, int OP, int NC = 4>
 __global__ void __launch_bounds__(512, 1) k(float* out, int iters, int role, int nwaves, unsigned long long* cyc) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= nwaves) return;
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(512, 1) k(float* out, int iters, int role, int
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                c[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[m & 3], 0, 0, 0);
+                c[m % NC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[m % NC], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < (NM > 0 ? NV / NM : 0); ++j) vop<OP>(v[j & 7], k1, k2);
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(512, 1) k(float* out, int iters, int role, int
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int m = 0; m < (NM > 0 ? NM : 16); ++m) {
-                c[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[m & 3], 0, 0, 0);
+                c[m % NC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[m % NC], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -61,16 +61,16 @@ __global__ void __launch_bounds__(512, 1) k(float* out, int iters, int role, int
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
-template <int NM, int NV, int OP = 0>
+template <int NM, int NV, int OP = 0, int NC = 4>
 void run(float* out, int role, int nwaves, const char* what) {
     static unsigned long long* cyc = nullptr;
     if (!cyc) hipMalloc(&cyc, 64);
     const int iters = 4000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k<NM, NV, OP><<<256, 512>>>(out, 10, role, nwaves, cyc);
+    k<NM, NV, OP, NC><<<256, 512>>>(out, 10, role, nwaves, cyc);
     hipEventRecord(e0);
-    k<NM, NV, OP><<<256, 512>>>(out, iters, role, nwaves, cyc);
+    k<NM, NV, OP, NC><<<256, 512>>>(out, iters, role, nwaves, cyc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -95,6 +95,9 @@ int main() {
     run<0, 96, 3>(out, 0, 4, "1 wave/SIMD: 96 v_exp_f32");
     run<16, 96, 3>(out, 0, 4, "1 wave/SIMD: 16 x (MFMA + 6 v_exp_f32)");
     run<16, 96, 4>(out, 0, 4, "1 wave/SIMD: 16 x (MFMA + 6 v_cvt_pk_f16_f32)");
+    run<16, 0, 0, 1>(out, 0, 4, "1 wave/SIMD: 16 MFMA on ONE accumulator");
+    run<16, 0, 0, 2>(out, 0, 4, "1 wave/SIMD: 16 MFMA on TWO accumulators (alternating)");
+    run<16, 64, 0, 2>(out, 0, 4, "1 wave/SIMD: 16 x (MFMA + 4 v_fma), TWO accumulators");
     run<16, 0>(out, 0, 8, "2 waves/SIMD: each 16 MFMA");
     run<0, 96>(out, 0, 8, "2 waves/SIMD: each 96 v_fma");
     run<16, 96>(out, 1, 8, "2 waves/SIMD: one 16 MFMA, the other 96 v_fma");
