@@ -69,6 +69,7 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []
+        self.bytes = 0              # algorithmic operand + output bytes of the timed launches
 
     def wrap(self, ops):
         inner = ops.gemm
@@ -83,6 +84,7 @@ class GemmTimer:
             r = inner(a, w, out, *args, **kw)
             e1.record(torch.cuda.current_stream())
             timer.records.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1))
+            timer.bytes += (M + w.shape[0]) * w.shape[1] * w.element_size() + out.numel() * out.element_size()
             return r
         ops.gemm = gemm
         return inner
@@ -320,9 +322,18 @@ def main():
         per_launch_flops = gflops / n
         avg_ms = gms / n
         achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (tools/hbm_traffic.py); the committed summary of
+        # the same command is reported here, null if it is absent
+        traffic, traffic_note = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_hbm_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic, traffic_note = round(tj["hbm_bytes_per_launch"]), "profiles/r01_gemm_hbm_traffic.json: " + tj["method"]
         out["roofline"] = {"bound": "mfma", "kernel": "lmi::gemm_kernel (all epilogues)", "achieved": round(achieved, 1),
                            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                           "traffic": None, "launches_per_step": n // min(args.steps, 2),
+                           "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": traffic_note,
+                           "algorithmic_bytes_per_launch": round(timer.bytes / n),
+                           "launches_per_step": n // min(args.steps, 2),
                            "avg_launch_ms": round(avg_ms, 4), "gemm_ms_per_step": round(gms / min(args.steps, 2), 2)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tflops, t = cpu_baseline(cfg)
