@@ -397,6 +397,14 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
     GemmArgs a;
     a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.add_rows = add_rows; a.row_map = row_map;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
+    // extents for the buffer resources the LDS-DMA reads through (32-bit offsets)
+    const long a_rows = (a_mode == LMI_A_PIXEL_SHUFFLE) ? (long)(M / ((ps_grid / 2) * (ps_grid / 2))) * ps_grid * ps_grid : (long)M;
+    const long a_cols = (a_mode == LMI_A_PIXEL_SHUFFLE) ? K / 4 : K;
+    const long a_bytes = a_rows > 0 ? ((a_rows - 1) * lda + a_cols) * 2 : 0, w_bytes = ((long)(N - 1) * ldw + K) * 2;
+    if (a_bytes >= (1L << 32) || w_bytes >= (1L << 32))
+        return fail(LMI_EINVAL, "lmi_gemm: operand extent >= 4 GiB (A %ld, W %ld bytes)", a_bytes, w_bytes);
+    a.a_bytes = (unsigned)a_bytes; a.w_bytes = (unsigned)w_bytes;
+    if (M == 0) return LMI_OK;
     LMI_DISPATCH_T(dtype, dispatch_gemm<f16_t>(a, epilogue, act, a_mode, stream),
                    dispatch_gemm<bf16_t>(a, epilogue, act, a_mode, stream));
 }

@@ -48,6 +48,7 @@ struct GemmArgs {
     int ps_grid;          // pixel-shuffle: G (26); output tokens per tile = (G/2)^2; C = K/4
     int group_m;          // row-tiles per L2 group in the XCD-aware tile order
     int order;            // 0 = each XCD owns a contiguous slab of the grouped order; 1 = XCDs take 32-tile chunks round-robin
+    unsigned a_bytes, w_bytes;   // extents of A and W (buffer resources of the LDS-DMA; both < 4 GiB)
 };
 
 constexpr int GEMM_BK = 64;
@@ -244,8 +245,9 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     // ---- per-thread staging sources: one row per pass; the 16-byte chunk position is fixed per thread ----------
     const int srow = tid >> 3;                       // physical row inside a pass
     const int pc = tid & 7;                          // physical 16-byte chunk inside the 128-byte row
-    const char* a_src[C::A_PASSES];
-    const char* w_src[C::W_PASSES];
+    // LDS-DMA through buffer resources: loop-invariant 32-bit lane offsets, the k-tile advances a scalar offset
+    const BufRsrc a_buf = make_buf(p.A, p.a_bytes), w_buf = make_buf(p.W, p.w_bytes);
+    unsigned a_src[C::A_PASSES], w_src[C::W_PASSES];
 #pragma unroll
     for (int ps = 0; ps < C::A_PASSES; ++ps) {
         const int r = ps * C::ROWS_PER_PASS + srow;
@@ -260,13 +262,13 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
         } else {
             arow = am;
         }
-        a_src[ps] = (const char*)p.A + (arow * p.lda + lc * 8) * 2;
+        a_src[ps] = (unsigned)((arow * p.lda + lc * 8) * 2);
     }
 #pragma unroll
     for (int ps = 0; ps < C::W_PASSES; ++ps) {
         const int r = ps * C::ROWS_PER_PASS + srow;
         const int lc = pc ^ ((r >> 1) & 7);
-        w_src[ps] = (const char*)p.W + ((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2;
+        w_src[ps] = (unsigned)(((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2);
     }
     const int ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;     // channels per shuffle segment
 
@@ -274,16 +276,16 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     auto issue_piece = [&](int g, int kt, int slot) {
         char* base = smem + slot * C::STAGE_BYTES + wave * 1024;
         if (g < C::A_PASSES) {
-            long a_off = (long)kt * GEMM_BK * 2;
+            unsigned a_off = (unsigned)kt * (GEMM_BK * 2);
             if (AMODE == AMODE_PIXSHUF) {
                 const int k0 = kt * GEMM_BK;
                 const int seg = k0 / ps_c;                           // 0..3 = (dh, dw)
-                a_off = ((long)((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2;
+                a_off = (unsigned)((((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2);
             }
-            glds16(a_src[g] + a_off, base + g * (C::ROWS_PER_PASS * 128));
+            glds16_buf(a_buf, a_src[g], a_off, base + g * (C::ROWS_PER_PASS * 128));
         } else {
             const int gw = g - C::A_PASSES;
-            glds16(w_src[gw] + (long)kt * GEMM_BK * 2, base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
+            glds16_buf(w_buf, w_src[gw], (unsigned)kt * (GEMM_BK * 2), base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
         }
     };
 
@@ -364,8 +366,9 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
     const int srow = tid >> 3, pc = tid & 7;
-    const char* a_src[C::A_PASSES];
-    const char* w_src[C::W_PASSES];
+    // LDS-DMA through buffer resources: loop-invariant 32-bit lane offsets, the k-tile advances a scalar offset
+    const BufRsrc a_buf = make_buf(p.A, p.a_bytes), w_buf = make_buf(p.W, p.w_bytes);
+    unsigned a_src[C::A_PASSES], w_src[C::W_PASSES];
 #pragma unroll
     for (int ps = 0; ps < C::A_PASSES; ++ps) {
         const int r = ps * C::ROWS_PER_PASS + srow;
@@ -380,28 +383,28 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
         } else {
             arow = am;
         }
-        a_src[ps] = (const char*)p.A + (arow * p.lda + lc * 8) * 2;
+        a_src[ps] = (unsigned)((arow * p.lda + lc * 8) * 2);
     }
 #pragma unroll
     for (int ps = 0; ps < C::W_PASSES; ++ps) {
         const int r = ps * C::ROWS_PER_PASS + srow;
         const int lc = pc ^ ((r >> 1) & 7);
-        w_src[ps] = (const char*)p.W + ((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2;
+        w_src[ps] = (unsigned)(((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2);
     }
     const int ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;
     auto issue_piece = [&](int g, int kt, int slot) {
         char* base = smem + slot * C::STAGE_BYTES + wave * 1024;
         if (g < C::A_PASSES) {
-            long a_off = (long)kt * GEMM_BK * 2;
+            unsigned a_off = (unsigned)kt * (GEMM_BK * 2);
             if (AMODE == AMODE_PIXSHUF) {
                 const int k0 = kt * GEMM_BK;
                 const int seg = k0 / ps_c;
-                a_off = ((long)((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2;
+                a_off = (unsigned)((((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2);
             }
-            glds16(a_src[g] + a_off, base + g * (C::ROWS_PER_PASS * 128));
+            glds16_buf(a_buf, a_src[g], a_off, base + g * (C::ROWS_PER_PASS * 128));
         } else {
             const int gw = g - C::A_PASSES;
-            glds16(w_src[gw] + (long)kt * GEMM_BK * 2, base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
+            glds16_buf(w_buf, w_src[gw], (unsigned)kt * (GEMM_BK * 2), base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
         }
     };
 
