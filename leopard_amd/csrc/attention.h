@@ -20,6 +20,7 @@
 //                   row-major V image; O^T's column is q, so the online-softmax rescale is a per-lane scalar.
 // Softmax statistics and accumulators are fp32; P is rounded to the 16-bit compute type for the PV MFMA.
 #pragma once
+#include <type_traits>
 #include "lmi_device.h"
 
 // timing-only ablations of the production attention kernel (tools/_ab builds with -DLMI_ATTN_ABLATE=n; results are wrong)
@@ -357,18 +358,18 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         p_ko[i] = (unsigned)(r * p.ldk + ((G::SWZ ? (c ^ (r & 15)) : c) << 3)) * 2u;
         p_vo[i] = (unsigned)(r * p.ldv + ((G::SWZ ? (c ^ ((r & 3) << 2)) : c) << 3)) * 2u;
     }
+    // piece j of this wave for tile t: j < PPW are its K pieces, the rest its V pieces
+    auto issue_piece = [&](int j, int t, int slot) {
+        const int i = j < PPW ? j : j - PPW;
+        if ((G::PIECES % NW) != 0 && wave + NW * i >= G::PIECES) return;      // wave-uniform; only ragged piece counts (d = 72) branch
+        if (LMI_ABL(4) && t >= 2) return;
+        char* dst = smem + slot * 2 * G::TILE_BYTES + (j < PPW ? 0 : G::TILE_BYTES) + (wave + NW * i) * 1024;
+        if (j < PPW) glds16_buf(k_buf, p_ko[i], (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldk, dst);
+        else glds16_buf(v_buf, p_vo[i], (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldv, dst);
+    };
     auto issue_tile = [&](int t, int slot) {
-        char* kdst = smem + slot * 2 * G::TILE_BYTES;
-        char* vdst = kdst + G::TILE_BYTES;
-        const unsigned k_so = (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldk;
-        const unsigned v_so = (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldv;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            if (wave + NW * i < G::PIECES) {                      // wave-uniform
-                if (!LMI_ABL(4) || t < 2) glds16_buf(k_buf, p_ko[i], k_so, kdst + (wave + NW * i) * 1024);
-                if (!LMI_ABL(4) || t < 2) glds16_buf(v_buf, p_vo[i], v_so, vdst + (wave + NW * i) * 1024);
-            }
-        }
+        for (int j = 0; j < 2 * PPW; ++j) issue_piece(j, t, slot);
     };
 
     f32x16 o_acc[NDB];
@@ -401,7 +402,6 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         LMI_PROF_MARK(0);
         wait_vmcnt_barrier<0>();                                   // tile t landed; slot of tile t-1 is free
         LMI_PROF_MARK(1);
-        if (t + 1 < t_end) issue_tile(t + 1, (t + 1 - t_begin) & 1);
         LMI_PROF_MARK(2);
         const int kv0 = t * ATT_BKV;
         const char* k_lds = smem + ((t - t_begin) & 1) * 2 * G::TILE_BYTES;
@@ -412,21 +412,37 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
-        sched_fence();
+        // S^T = K . Q^T.  K fragment reads run three MFMA pairs ahead of their use, and the LDS-DMA pieces of tile t+1 (an
+        // LDS-DMA instruction costs ~60 issue cycles) ride one per k-step between the MFMA pairs instead of in a burst.
+        auto qk = [&](auto with_dma) {
+            constexpr bool DMA = decltype(with_dma)::value;
+            constexpr int AHEAD = 3;                                 // K fragment pairs in flight ahead of their MFMAs
+            T8 kf[NKS][2];
+            sched_fence();
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
+            for (int ks = 0; ks < AHEAD && ks < NKS; ++ks)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const T8 kf = *(const T8*)(k_lds + b * 32 * G::ROWB + k_off[ks]);
-                if (!LMI_ABL(2)) s[b] = mfma32(kf, qf[ks], s[b]); else s[b][ks] += (float)kf[0];
+                for (int b = 0; b < 2; ++b) kf[ks][b] = *(const T8*)(k_lds + b * 32 * G::ROWB + k_off[ks]);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                sched_fence();                                       // one k-step per scheduling region: reads, 2 MFMAs, 1 DMA piece
+                if (ks + AHEAD < NKS) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) kf[ks + AHEAD][b] = *(const T8*)(k_lds + b * 32 * G::ROWB + k_off[ks + AHEAD]);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (!LMI_ABL(2)) s[b] = mfma32(kf[ks][b], qf[ks], s[b]); else s[b][ks] += (float)kf[ks][b][0];
+                }
+                if (DMA && ks < 2 * PPW) issue_piece(ks, t + 1, (t + 1 - t_begin) & 1);
             }
-        }
-        // K fragment reads run three MFMA pairs ahead of their use
-        LMI_SCHED_DSREAD(6);
+            sched_fence();
+            if (DMA) {
 #pragma unroll
-        for (int i = 0; i < NKS - 3; ++i) { LMI_SCHED_MFMA(2); LMI_SCHED_DSREAD(2); }
-        LMI_SCHED_MFMA(6);
-        sched_fence();
+                for (int j = NKS; j < 2 * PPW; ++j) issue_piece(j, t + 1, (t + 1 - t_begin) & 1);
+            }
+        };
+        if (t + 1 < t_end) qk(std::true_type{}); else qk(std::false_type{});
         LMI_PROF_TOUCH(s[0][15]); LMI_PROF_TOUCH(s[1][15]);
         LMI_PROF_MARK(3);
         const bool need_mask = (kv0 + ATT_BKV > len_k) || (CAUSAL && (kv0 + ATT_BKV - 1 > wave_q_lo + shift)) ||

@@ -95,6 +95,7 @@ LMI_DEV u32x2 ds_read_tr16_b64(const void* lds_ptr) {
 #define LMI_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 #define LMI_SCHED_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
 #define LMI_SCHED_DSREAD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define LMI_SCHED_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x010, n, 0)
 
 // Batched form used by attention: for d-block i = 0..N-1 read the 4-key groups at byte offsets i*64 and
 // i*64 + ROW8 from one base address, one wait for all 2N reads.  out[i] = {lo.x, lo.y, hi.x, hi.y}.
@@ -269,6 +270,7 @@ inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {
 #define LMI_SCHED_MFMA(n) ((void)0)
 #define LMI_SCHED_VALU(n) ((void)0)
 #define LMI_SCHED_DSREAD(n) ((void)0)
+#define LMI_SCHED_VMEM(n) ((void)0)
 
 template <int N, int ROW8>
 inline void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
