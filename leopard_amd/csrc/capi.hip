@@ -220,13 +220,13 @@ int dispatch_gemv(const void* W, const void* x, const float* gamma, float eps, c
 template <typename T, bool RMS>
 int norm_impl(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo,
                      float eps, void* stream, const char* what) {
-    if (!x || !w || !out || (!RMS && !b) || M < 0 || D <= 0 || (D & 3) || D > 4096 || (ldx & 3) || (ldo & 3) ||
+    if (!x || !w || !out || (!RMS && !b) || M < 0 || D <= 0 || (D & 7) || D > 4096 || (ldx & 3) || (ldo & 7) ||
         !aligned16(x) || !aligned16(w) || !aligned16(out))
-        return fail(LMI_EINVAL, "%s: bad argument (M=%d D=%d ldx=%d ldo=%d; D%%4==0, D<=4096)", what, M, D, ldx, ldo);
+        return fail(LMI_EINVAL, "%s: bad argument (M=%d D=%d ldx=%d ldo=%d; D%%8==0, D<=4096)", what, M, D, ldx, ldo);
     if (M == 0) return LMI_OK;
     const int grid = (M + 3) / 4;
-    if (D <= 1280) LMI_LAUNCH((norm_kernel<T, RMS, 5>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
-    else LMI_LAUNCH((norm_kernel<T, RMS, 16>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
+    if (D <= 1536) LMI_LAUNCH((norm_kernel<T, RMS, 3>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
+    else LMI_LAUNCH((norm_kernel<T, RMS, 8>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
     return check_launch(what);
 }
 

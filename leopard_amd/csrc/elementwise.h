@@ -94,24 +94,27 @@ __global__ void resample_u8_kernel(const uint8_t* src, uint8_t* dst, int rows, i
 // LayerNorm (SigLIP, eps 1e-6) / RMSNorm (Llama, eps 1e-5): fp32 stream row -> 16-bit GEMM operand row.
 // One wave per row, row kept in registers, statistics in fp32 with two passes (mean, then centred variance).
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool RMS, int MAXV>     // MAXV = max float4 chunks per lane (D <= MAXV*256)
+template <typename T, bool RMS, int MAXV>     // MAXV = max 8-element chunks per lane (D <= MAXV*512)
 __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* w, const float* b, T* out,
                                                    int M, int D, int ldx, int ldo, float eps) {
-    typedef typename vec_of<T>::x4 T4;
+    typedef typename vec_of<T>::x8 T8;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* xr = x + (long)row * ldx;
-    const int nvec = D >> 2;                         // float4 chunks in the row (D % 4 == 0)
-    f32x4 v[MAXV];
+    const int nvec = D >> 3;                         // 8-element chunks in the row (D % 8 == 0): 32 B in, 16 B out per lane
+    f32x4 v[MAXV][2];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = i * 64 + lane;
         if (c < nvec) {
-            v[i] = *(const f32x4*)(xr + c * 4);
-            s += RMS ? (v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3])
-                     : (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
+            v[i][0] = *(const f32x4*)(xr + c * 8);
+            v[i][1] = *(const f32x4*)(xr + c * 8 + 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                s += RMS ? (v[i][h][0] * v[i][h][0] + v[i][h][1] * v[i][h][1] + v[i][h][2] * v[i][h][2] + v[i][h][3] * v[i][h][3])
+                         : (v[i][h][0] + v[i][h][1] + v[i][h][2] + v[i][h][3]);
         }
     }
     s = wave_sum(s);
@@ -126,7 +129,9 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
             const int c = i * 64 + lane;
             if (c < nvec) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[i][h][e] - mean; q += d * d; }
             }
         }
         q = wave_sum(q);
@@ -137,17 +142,20 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
     for (int i = 0; i < MAXV; ++i) {
         const int c = i * 64 + lane;
         if (c < nvec) {
-            const f32x4 ww = *(const f32x4*)(w + c * 4);
-            T4 o;
-            if (RMS) {
+            T8 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)(ww[e] * (v[i][e] * rstd));
-            } else {
-                const f32x4 bb = *(const f32x4*)(b + c * 4);
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 ww = *(const f32x4*)(w + c * 8 + 4 * h);
+                if (RMS) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)((v[i][e] - mean) * rstd * ww[e] + bb[e]);
+                    for (int e = 0; e < 4; ++e) o[4 * h + e] = (T)(ww[e] * (v[i][h][e] * rstd));
+                } else {
+                    const f32x4 bb = *(const f32x4*)(b + c * 8 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[4 * h + e] = (T)((v[i][h][e] - mean) * rstd * ww[e] + bb[e]);
+                }
             }
-            *(T4*)(orow + c * 4) = o;
+            *(T8*)(orow + c * 8) = o;
         }
     }
 }
