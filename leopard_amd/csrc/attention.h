@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     const int t_begin = p.n_splits > 1 ? imin(n_tiles, split * p.split_tiles) : 0;
     const int t_end = p.n_splits > 1 ? imin(n_tiles, t_begin + p.split_tiles) : n_tiles;
     my_tiles = imin(my_tiles, t_end);
+    if (wave_q_lo >= len_q) my_tiles = t_begin;                    // all 32 rows of this wave are past the sequence: feed and sync only
 
     const int my_q = q0 + wave * 32 + fr;
     const T* q_row = (const T*)p.q + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldq + head * D;
