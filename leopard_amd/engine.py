@@ -290,10 +290,30 @@ class LeopardEngine:
         last, all_ = self.llm_prefill(x, [S], cache=cache, all_logits=all_logits)
         return PrefillResult(logits_last=last[0], seq_len=S, n_tiles=n_tiles, logits_all=all_, parts=parts)
 
-    # ------------------------------------------------------------------------------------------------
-    # a12: one greedy decode step with the KV cache (EVAL:291-320 semantics: position = number of cached tokens)
-    # ------------------------------------------------------------------------------------------------
     @torch.no_grad()
+    def prefill_batch(self, samples: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]]):
+        """Several samples in ONE pass (BASELINE config C5: a batch of multi-image samples): all ViT inputs go through the
+        vision tower and the projector together, every sample's merged sequence is packed into one varlen causal batch
+        (``cu_seqlens`` keeps the samples apart).  samples: [(input_ids [1, S_in], tiles u8 [N_i, S, S, 3] or None)].
+        Returns (logits_last [n_samples, vocab], seq_lens).  The reference runs one sample per ``generate`` call
+        (EVAL:448-454); results are identical to per-sample ``prefill`` calls."""
+        tiles = [t for _, t in samples if t is not None and t.shape[0] > 0]
+        visual = None
+        if tiles:
+            all_tiles = torch.cat(tiles, dim=0)
+            visual = self.project(self.vision_tower(all_tiles), all_tiles.shape[0])
+        xs, seq_lens, row = [], [], 0
+        for ids, t in samples:
+            n = 0 if t is None else t.shape[0]
+            vt = None if n == 0 else visual[row * self.cfg.tokens_per_tile:(row + n) * self.cfg.tokens_per_tile]
+            row += n
+            x = self.embed_merge(ids, vt)
+            xs.append(x)
+            seq_lens.append(x.shape[0])
+        x = torch.cat(xs, dim=0)
+        last, _ = self.llm_prefill(x, seq_lens)
+        return last, seq_lens
+
     # ------------------------------------------------------------------------------------------------
     # a12: decode.  One step = ~290 launches of memory-bound kernels, so the step is captured once per KV cache into a
     # HIP graph over static buffers; the token id and the position live in device memory (lmi_rope_qk_at, device

@@ -85,3 +85,21 @@ def test_plan_merge_matches_oracle_and_raises():
         assert np.array_equal(plan_merge(ids, 7, k * tpt, tpt), O.merge_plan(ids, 7, k * tpt, tpt))
     with pytest.raises(ValueError, match="number of image tokens"):
         plan_merge(np.array([1, 7, 2]), 7, 8, 4)
+
+
+
+def test_prefill_batch_equals_per_sample_prefill(setup):
+    """Packed multi-sample prefill (BASELINE config C5 shape) == per-sample prefill, on the emulator at the micro config."""
+    ops, cfg, _ = setup
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    rng = np.random.default_rng(5)
+    samples = [(torch.tensor([[5, 250, 9, 250, 17]]), torch.from_numpy(rng.integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))),
+               (torch.tensor([[7, 8, 9]]), None),
+               (torch.tensor([[250, 3]]), torch.from_numpy(rng.integers(0, 256, (1, 28, 28, 3), dtype=np.uint8)))]
+    logits, seq_lens = eng.prefill_batch(samples)
+    t = cfg.tokens_per_tile                          # visual tokens that replace each image token
+    assert seq_lens == [5 + 2 * (t - 1), 3, 2 + (t - 1)]
+    for i, (ids, tiles) in enumerate(samples):
+        one = eng.prefill(ids, tiles)
+        assert torch.equal(one.logits_last, logits[i])

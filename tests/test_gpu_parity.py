@@ -171,3 +171,22 @@ def test_c3_size_properties(ops):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.gpu
+def test_prefill_batch_equals_per_sample_prefill(ops):
+    """BASELINE config C5 shape (a batch of multi-image samples) at the mid depth: one packed pass over three samples with
+    different image counts / sizes gives, per sample, exactly the logits of its own prefill call."""
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    shapes = [(1, 800, 500, 3), (2, 1344, 896, 5), (1, 336, 336, 7)]
+    samples = []
+    for n, w, h, seed in shapes:
+        u8, ids, _ = sample_inputs(cfg, n, w, h, seed=seed)
+        samples.append((ids, torch.from_numpy(u8).to(DEV)))
+    batch_logits, seq_lens = eng.prefill_batch(samples)
+    assert len(seq_lens) == 3 and batch_logits.shape[0] == 3
+    for i, (ids, tiles) in enumerate(samples):
+        one = eng.prefill(ids, tiles)
+        assert one.seq_len == seq_lens[i]
+        assert torch.equal(one.logits_last, batch_logits[i])
