@@ -101,7 +101,8 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
  * q/k/v/out: T, head h of row r at base + r*ld + h*head_dim.  cu_seqlens: int32 [n_seq+1] on device.
  * Causal alignment is bottom-right (key j visible to query i iff j <= i + len_k - len_q); window > 0 additionally hides
  * keys with i + len_k - len_q - j >= window (Mistral sliding window), 0 = unlimited.
- * use_tr=1 uses ds_read_b64_tr_b16 for the V operand (production); 0 uses plain LDS gathers (cross-check). */
+ * use_tr=1 uses ds_read_b64_tr_b16 for the V operand (production); 0 uses plain LDS gathers (cross-check).
+ * Limit: the K (and V) rows of ONE sequence must span less than 4 GiB (32-bit buffer offsets); the kernel traps beyond. */
 int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,
                         const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads,
                         int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window,

@@ -349,6 +349,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     // advances a scalar offset, and rows past len_k read as zeros (no address clamp in the loop).
     const T* k_base = (const T*)p.k + (long)k_beg * p.ldk + kvh * D;
     const T* v_base = (const T*)p.v + (long)k_beg * p.ldv + kvh * D;
+    // 32-bit buffer offsets: one sequence's K (or V) rows must span < 4 GiB (ldk = 6144 halves: 349 k keys); fail loudly beyond
+    if (((long)len_k * p.ldk + D) * 2 >= (1L << 32) || ((long)len_k * p.ldv + D) * 2 >= (1L << 32)) lmi_trap();
     const BufRsrc k_buf = make_buf(k_base, len_k > 0 ? (unsigned)(((long)(len_k - 1) * p.ldk + D) * 2) : 0u);
     const BufRsrc v_buf = make_buf(v_base, len_k > 0 ? (unsigned)(((long)(len_k - 1) * p.ldv + D) * 2) : 0u);
     unsigned p_ko[PPW], p_vo[PPW];

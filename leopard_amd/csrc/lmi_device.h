@@ -172,6 +172,7 @@ LMI_DEV void swap_hi_lo(unsigned& a, unsigned& b) {
     a = r[0]; b = r[1];
 }
 LMI_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+LMI_DEV void lmi_trap() { __builtin_trap(); }
 LMI_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 LMI_DEV void setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 LMI_DEV void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
@@ -307,6 +308,7 @@ inline void swap_hi_lo(unsigned& a, unsigned& b) {
     const unsigned ta = (unsigned)emu_shfl_idx((int)a, lane_id() ^ 32), tb = (unsigned)emu_shfl_idx((int)b, lane_id() ^ 32);
     if (lane_id() < 32) b = ta; else a = tb;
 }
+inline void lmi_trap() { __builtin_trap(); }
 inline bool wave_any(bool p) {
     int v = p ? 1 : 0;
     for (int m = 32; m >= 1; m >>= 1) v |= emu_shfl_idx(v, lane_id() ^ m);
