@@ -134,6 +134,54 @@ def cpu_baseline(cfg):
     return tflops, t
 
 
+def bench_c5(args, dev, dtype, rank, world, D):
+    """BASELINE config 5 shape: a batch of 8 samples x 8 images of 1344x896 (40 ViT inputs and 6861 tokens per sample), all 8
+    samples in ONE packed pass (LeopardEngine.prefill_batch), 16-bit compute (the fp8 variant of that config is not built)."""
+    from leopard_amd.engine import LeopardEngine
+    from leopard_amd.gpu_tiler import GpuTiler
+    from leopard_amd.ops import Ops
+    from leopard_amd.weights import EngineWeights, SynthSource
+    cfg = full_config()
+    ops = Ops()
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
+    eng = LeopardEngine(cfg, W, ops=ops, device=dev)
+    tiler = GpuTiler(ops, dev)
+    n_samples, n_img = 8, 8
+    samples = []
+    for j in range(n_samples):
+        raw = [synth_image_u8((rank * 16 + j) * 100 + i, 1344, 896) for i in range(n_img)]
+        tiles, plan = tiler.tile_sample(raw)
+        ids = torch.from_numpy(synth_prompt_ids(plan.vit_inputs_per_image, cfg, seed=rank * 16 + j)).reshape(1, -1)
+        samples.append((ids, tiles))
+    n_tiles = sum(t.shape[0] for _, t in samples)
+
+    def barrier():
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        eng.prefill_batch(samples)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits, seq_lens = eng.prefill_batch(samples)
+    barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(logits).all()
+    fl = sum(algorithmic_flops(cfg, t.shape[0], S)["total"] for (_, t), S in zip(samples, seq_lens))
+    out = {"metric": "multi-image prefill images/sec (Leopard-LLaVA, batch 8 x 8 x 1344x896)",
+           "value": round(world * n_samples * n_img * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"C5 shape: {n_samples} samples x {n_img} x (1344x896) -> {n_tiles} ViT inputs, "
+                                  f"{sum(seq_lens)} tokens packed in one varlen pass; SigLIP-SO400M + Llama-3.1-8B prefill to "
+                                  "last-token logits; synthetic seeded weights", "parallelism": f"sample-sharded x{world}"},
+           "algorithmic_tflop_per_step": round(fl / 1e12, 2),
+           "prefill_mfma_frac": round(fl / 1e12 / (elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def bench_idefics2(args, dev, dtype, rank, world, D):
     """BASELINE config 4: Leopard-Idefics2, 4 images of 1344x896 (-> 980x653, 3220 patches, 64 visual tokens each)
     interleaved in a ~312-token prompt; NaViT SigLIP (27L) + modality projection + perceiver (3L) + Mistral-7B (32L)."""
@@ -207,7 +255,7 @@ def main():
     ap.add_argument("--images", type=int, default=6)
     ap.add_argument("--width", type=int, default=1344)
     ap.add_argument("--height", type=int, default=896)
-    ap.add_argument("--workload", default="llava-c3", choices=["llava-c3", "idefics2-c4"],
+    ap.add_argument("--workload", default="llava-c3", choices=["llava-c3", "idefics2-c4", "llava-c5"],
                     help="llava-c3 = the BASELINE metric's configuration (default); idefics2-c4 = Leopard-Idefics2, 4 x 1344x896")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent samples in flight per GPU, each on its own HIP stream (1 = the reference's one-sample-at-a-time loop)")
@@ -232,6 +280,8 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     if args.workload == "idefics2-c4":
         return bench_idefics2(args, dev, dtype, rank, world, D)
+    if args.workload == "llava-c5":
+        return bench_c5(args, dev, dtype, rank, world, D)
     cfg = full_config()
     ops = Ops()
     t0 = time.perf_counter()

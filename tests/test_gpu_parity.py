@@ -190,3 +190,25 @@ def test_prefill_batch_equals_per_sample_prefill(ops):
         one = eng.prefill(ids, tiles)
         assert one.seq_len == seq_lens[i]
         assert torch.equal(one.logits_last, batch_logits[i])
+
+
+@pytest.mark.gpu
+def test_c5_size_batch_properties(ops):
+    """BASELINE config C5 size (8 samples x 8 images of 1344x896 -> 320 ViT inputs, 8 x 6861 tokens in one packed pass) at the
+    mid depth: every sample of the packed batch reproduces its own single-sample prefill bit for bit, and equal samples give
+    equal logits wherever they sit in the batch."""
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    u8, ids, plan = sample_inputs(cfg, 8, 1344, 896, seed=11)
+    assert plan.n_vit_inputs == 40                                   # 8 x (thumbnail + 4 tiles)
+    tiles = torch.from_numpy(u8).to(DEV)
+    u8b, idsb, _ = sample_inputs(cfg, 8, 1344, 896, seed=12)
+    tiles_b = torch.from_numpy(u8b).to(DEV)
+    samples = [(ids, tiles), (idsb, tiles_b)] * 4                    # 8 samples, 320 ViT inputs
+    logits, seq_lens = eng.prefill_batch(samples)
+    assert len(seq_lens) == 8 and all(s == seq_lens[0] for s in seq_lens) and seq_lens[0] == ids.shape[1] + 40 * 168
+    assert torch.isfinite(logits).all()
+    for i in range(2, 8):
+        assert torch.equal(logits[i], logits[i % 2])
+    one = eng.prefill(ids, tiles)
+    assert torch.equal(one.logits_last, logits[0])
