@@ -259,6 +259,10 @@ def main():
                     help="llava-c3 = the BASELINE metric's configuration (default); idefics2-c4 = Leopard-Idefics2, 4 x 1344x896")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent samples in flight per GPU, each on its own HIP stream (1 = the reference's one-sample-at-a-time loop)")
+    ap.add_argument("--parallelism", default="sample", choices=["sample", "tp"],
+                    help="N > 1: 'sample' = one sample per rank, no data-path collective (default, weak scaling); 'tp' = ONE sample "
+                         "per step on all ranks: tile-sharded vision encode + all-gather, tensor-parallel LLM with two all-reduces "
+                         "per layer (strong scaling, single-sample latency)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -268,11 +272,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    dev = torch.device(f"cuda:{local_rank}")
+    # LMI_BENCH_ONE_DEVICE=1: every rank on cuda:0 with a gloo group — a functional check of the multi-rank paths on a 1-GPU box
+    one_device = os.environ.get("LMI_BENCH_ONE_DEVICE") == "1"
+    dev = torch.device("cuda:0" if one_device else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     from leopard_amd import dist as D
     if world > 1:
-        D.init(backend="nccl", device=dev)            # RCCL over xGMI; used for barrier / max-over-ranks only
+        D.init(backend="gloo" if one_device else "nccl", device=dev)     # RCCL over xGMI
 
     from leopard_amd.engine import KVCache, LeopardEngine
     from leopard_amd.ops import Ops
@@ -285,7 +291,8 @@ def main():
     cfg = full_config()
     ops = Ops()
     t0 = time.perf_counter()
-    W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
+    tp = args.parallelism == "tp" and world > 1
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype, tp_rank=rank if tp else 0, tp_size=world if tp else 1)
     torch.cuda.synchronize()
     eng = LeopardEngine(cfg, W, ops=ops, device=dev)
     load_s = time.perf_counter() - t0
@@ -298,7 +305,7 @@ def main():
     host_tiler_s = gpu_tiler_s = 0.0
     for j in range(args.inflight):
         c = Ctx()
-        u8, ids_np, plan, tiler_s, raw = make_sample(cfg, args.images, args.width, args.height, seed=rank * 16 + j)
+        u8, ids_np, plan, tiler_s, raw = make_sample(cfg, args.images, args.width, args.height, seed=(0 if tp else rank) * 16 + j)
         host_tiler_s = max(host_tiler_s, tiler_s)
         gpu_tiler.tile_sample(raw)                                 # warm (tap tables, allocator)
         torch.cuda.synchronize()
@@ -311,7 +318,7 @@ def main():
         c.ids = torch.from_numpy(ids_np).reshape(1, -1)            # token ids stay host-side, like a tokenizer's output
         c.n_tiles = u8.shape[0]
         c.S = c.ids.shape[1] + c.n_tiles * (cfg.tokens_per_tile - 1)
-        c.cache = KVCache(cfg, c.S, dtype, dev)
+        c.cache = KVCache(cfg, c.S, dtype, dev, tp_size=world if tp else 1)
         c.stream = torch.cuda.Stream(device=dev) if args.inflight > 1 else torch.cuda.current_stream(dev)
         ctxs.append(c)
     n_tiles, S = ctxs[0].n_tiles, ctxs[0].S
@@ -321,7 +328,10 @@ def main():
         for c in ctxs:
             with torch.cuda.stream(c.stream):
                 c.cache.length = 0
-                out = eng.prefill(c.ids, c.tiles, cache=c.cache)
+                if tp:       # every rank encodes its slice of the ViT inputs, one all-gather, then the tensor-parallel LLM
+                    out = eng.prefill(c.ids, None, cache=c.cache, visual_tokens=D.encode_images_sharded(eng, c.tiles))
+                else:
+                    out = eng.prefill(c.ids, c.tiles, cache=c.cache)
         return out
 
     def barrier():
@@ -340,26 +350,27 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev)
     assert res.seq_len == S and torch.isfinite(res.logits_last).all()
     ms_per_step = elapsed / args.steps * 1e3
-    images_per_s = world * args.inflight * args.images * args.steps / elapsed
+    images_per_s = (1 if tp else world) * args.inflight * args.images * args.steps / elapsed
     fl = algorithmic_flops(cfg, n_tiles, S)
 
     out = {
         "metric": "multi-image prefill images/sec (Leopard-LLaVA, 6x1344x896 per sample)",
         "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"C3: {args.images}x({args.width}x{args.height}) images -> {n_tiles} ViT inputs (364x364), "
                                f"{n_tiles * cfg.tokens_per_tile} visual tokens, S={S}; SigLIP-SO400M/14 (27L) + Llama-3.1-8B (32L) "
                                "prefill to last-token logits, KV cache written; synthetic seeded weights",
-                   "samples_per_rank_per_step": args.inflight, "samples_in_flight_per_gpu": args.inflight, "parallelism": f"sample-sharded x{world} (no data-path collective)"},
-        "visual_tokens_per_s": round(world * args.inflight * n_tiles * cfg.tokens_per_tile * args.steps / elapsed, 1),
+                   "samples_per_rank_per_step": args.inflight, "samples_in_flight_per_gpu": args.inflight, "parallelism": (f"one sample on {world} ranks: tile-sharded ViT + all-gather, TP{world} LLM (2 all-reduces / layer)" if tp
+                                   else f"sample-sharded x{world} (no data-path collective)")},
+        "visual_tokens_per_s": round((1 if tp else world) * args.inflight * n_tiles * cfg.tokens_per_tile * args.steps / elapsed, 1),
         "algorithmic_tflop_per_step": round(args.inflight * fl["total"] / 1e12, 2),
         "prefill_mfma_frac": round(args.inflight * fl["total"] / 1e12 / (elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4),
         "host_tiler_ms_per_sample": round(host_tiler_s * 1e3, 1), "gpu_tiler_ms_per_sample": round(gpu_tiler_s * 1e3, 2),
         "weight_load_s": round(load_s, 1),
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not tp:     # (under tp a rank-0-only pass would leave the collectives unmatched)
         timer = GemmTimer()
         inner = timer.wrap(ops)
         torch.cuda.synchronize()

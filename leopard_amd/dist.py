@@ -107,3 +107,17 @@ def encode_images_sharded(engine, tiles: torch.Tensor) -> torch.Tensor:
         dist.all_gather_into_tensor(gathered, mine)              # equal-size padded shards, one collective
     parts = [gathered[r * max_rows:r * max_rows + (b - a) * tpt] for r, (a, b) in enumerate(slices)]
     return torch.cat(parts, dim=0)
+
+
+def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """In-place sum over ranks (the tensor-parallel exchange of the LLM: partial o_proj / down_proj products).  RCCL reduces
+    the device tensor on the current stream; gloo (CPU tests) reduces host tensors."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo" and t.device.type == "cuda":      # fallback group: stage through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+

@@ -82,9 +82,9 @@ class PrefillResult:
 
 
 class KVCache:
-    def __init__(self, cfg: LeopardConfig, capacity: int, dtype, device):
+    def __init__(self, cfg: LeopardConfig, capacity: int, dtype, device, tp_size: int = 1):
         tc = cfg.text_config
-        w = tc.num_key_value_heads * tc.head_dim
+        w = tc.num_key_value_heads // tp_size * tc.head_dim          # a tensor-parallel rank caches its own kv heads
         self.k = [torch.zeros(capacity, w, dtype=dtype, device=device) for _ in range(tc.num_hidden_layers)]
         self.v = [torch.zeros(capacity, w, dtype=dtype, device=device) for _ in range(tc.num_hidden_layers)]
         self.capacity, self.length = capacity, 0
@@ -105,6 +105,26 @@ class LeopardEngine:
         self._vit_cu_cache: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------
+    @property
+    def tp_size(self) -> int:
+        return getattr(self.W, "tp_size", 1)
+
+    def _llm_heads(self) -> Tuple[int, int]:
+        """(query heads, kv heads) this rank computes."""
+        tc = self.cfg.text_config
+        return (getattr(self.W, "llm_heads", 0) or tc.num_attention_heads, getattr(self.W, "llm_kv_heads", 0) or tc.num_key_value_heads)
+
+    def _row_parallel(self, a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, tmp: Optional[torch.Tensor]):
+        """x += a @ w.T for o_proj / down_proj.  Single rank: fused in the GEMM's fp32 residual epilogue.  Tensor parallel: the
+        rank's partial product goes to ``tmp`` (fp32), ONE all-reduce sums it over the ranks (RCCL over xGMI), then it is added."""
+        if self.tp_size == 1:
+            self.ops.gemm(a, w, x, epilogue=_lib.EPI_RESIDUAL)
+            return
+        from . import dist as D
+        self.ops.gemm(a, w, tmp, epilogue=_lib.EPI_STORE_F32)
+        D.all_reduce_sum(tmp)
+        x.add_(tmp)
+
     def _empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
 
@@ -220,7 +240,7 @@ class LeopardEngine:
         logits_all or None).  ``cache`` (single sequence only) receives rotated K and V."""
         ops, W, tc = self.ops, self.W, self.cfg.text_config
         S, D = x.shape
-        H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        (H, KV), hd = self._llm_heads(), tc.head_dim
         qw, kw = H * hd, KV * hd
         cu, cos, sin, last_rows, cu_list = self.sequence_geometry(seq_lens)
         assert cu_list[-1] == S
@@ -230,6 +250,7 @@ class LeopardEngine:
         qkv = self._empty(S, qw + 2 * kw)
         att = self._empty(S, qw)
         gu = self._empty(S, W.llm_ff)
+        tmp = self._empty(S, D, dtype=torch.float32) if self.tp_size > 1 else None
         scale = hd ** -0.5
         max_len = max(int(l) for l in seq_lens)
         for i, L in enumerate(W.llm_layers):
@@ -238,10 +259,10 @@ class LeopardEngine:
             ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
             ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
                           True, self.use_tr, window=tc.sliding_window or 0)
-            ops.gemm(att, L.o_w, x, epilogue=_lib.EPI_RESIDUAL)
+            self._row_parallel(att, L.o_w, x, tmp)
             ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
             ops.gemm(h, L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
-            ops.gemm(gu, L.down_w, x, epilogue=_lib.EPI_RESIDUAL)
+            self._row_parallel(gu, L.down_w, x, tmp)
         if cache is not None:
             cache.length = S
         return self._lm_head(x, last_rows, all_logits)
@@ -324,7 +345,7 @@ class LeopardEngine:
         if st is not None:
             return st
         W, tc = self.W, self.cfg.text_config
-        H, KV, hd, D = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim, tc.hidden_size
+        (H, KV), hd, D = self._llm_heads(), tc.head_dim, tc.hidden_size
         dev = self.device
 
         class St:
@@ -338,6 +359,7 @@ class LeopardEngine:
         st.x = self._empty(1, D, dtype=torch.float32)
         st.h, st.qkv, st.att = self._empty(1, D), self._empty(1, (H + 2 * KV) * hd), self._empty(1, H * hd)
         st.gu = self._empty(1, W.llm_ff)
+        st.part = torch.zeros(D, dtype=torch.float32, device=dev)     # tensor parallel: partial o_proj / down_proj row
         st.logits = self._empty(W.lm_head.shape[0], dtype=torch.float32)
         st.cos, st.sin = self.rope_tables(torch.arange(cache.capacity))
         st.ws = torch.empty(self.ops.decode_workspace_elems(1, H, hd, cache.capacity), dtype=torch.float32, device=dev)
@@ -348,8 +370,18 @@ class LeopardEngine:
     def _decode_body(self, st, cache: KVCache):
         """Everything of one decode step that does not depend on host values."""
         ops, W, tc = self.ops, self.W, self.cfg.text_config
-        H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        (H, KV), hd = self._llm_heads(), tc.head_dim
         qw = H * hd
+        tp = self.tp_size > 1
+
+        def row_parallel(w, a):
+            if not tp:
+                ops.gemv(w, a, st.x[0], epilogue=2)
+                return
+            from . import dist as D
+            ops.gemv(w, a, st.part, epilogue=0)
+            D.all_reduce_sum(st.part)
+            st.x[0].add_(st.part)
         ops.embed_merge(st.tok, st.src0, W.embed, None, st.x)
         fuse = tc.hidden_size == 4096                 # lmi_gemv_rmsnorm: the norm rides in the projection's launch
         for i, L in enumerate(W.llm_layers):
@@ -361,13 +393,13 @@ class LeopardEngine:
             ops.rope_qk_at(st.qkv, H, KV, hd, st.cos, st.sin, cache.k[i], cache.v[i], st.pos)
             ops.attention_decode(st.qkv[:, :qw], cache.k[i], cache.v[i], st.att, st.cu_q, st.cu_k, 1, cache.capacity, H, KV, hd,
                                  hd ** -0.5, st.ws, window=tc.sliding_window or 0)
-            ops.gemv(L.o_w, st.att[0], st.x[0], epilogue=2)
+            row_parallel(L.o_w, st.att[0])
             if fuse:
                 ops.gemv_rmsnorm(L.gu_w, st.x[0], L.post_norm, tc.rms_norm_eps, st.gu[0], epilogue=3)
             else:
                 ops.rmsnorm(st.x, L.post_norm, st.h, tc.rms_norm_eps)
                 ops.gemv(L.gu_w, st.h[0], st.gu[0], epilogue=3)
-            ops.gemv(L.down_w, st.gu[0], st.x[0], epilogue=2)
+            row_parallel(L.down_w, st.gu[0])
         if fuse:
             ops.gemv_rmsnorm(W.lm_head, st.x[0], W.final_norm, tc.rms_norm_eps, st.logits, epilogue=0)
         else:
@@ -379,7 +411,7 @@ class LeopardEngine:
         st.cu_k[1:].add_(1)
 
     def _decode_run(self, st, cache: KVCache):
-        if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs:
+        if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs or self.tp_size > 1:   # no collectives inside a captured graph
             self._decode_body(st, cache)
             return
         if st.graph is None:
@@ -421,7 +453,7 @@ class LeopardEngine:
         ids = input_ids.reshape(1, -1)
         n_img = int((ids == self.cfg.image_token_index).sum())
         S = ids.shape[1] + n_img * (self.cfg.tokens_per_tile - 1)
-        cache = KVCache(self.cfg, S + max_new_tokens, self.dtype, self.device)
+        cache = KVCache(self.cfg, S + max_new_tokens, self.dtype, self.device, tp_size=self.tp_size)
         res = self.prefill(ids, tiles, cache=cache)
         out = [int(t) for t in ids.reshape(-1).tolist()]
         nxt = int(res.logits_last.argmax())

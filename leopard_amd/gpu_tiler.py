@@ -57,7 +57,7 @@ class GpuTiler:
         tiles = torch.empty((plan.n_vit_inputs, T, T, 3), dtype=torch.uint8, device=self.device)
         n = 0
         for im, size, canvas in zip(images, sizes, plan.canvases):
-            src = torch.from_numpy(np.ascontiguousarray(im))
+            src = torch.from_numpy(np.array(im, dtype=np.uint8, order="C"))             # a writable copy (images may be read-only views)
             src = src.to(self.device, non_blocking=True) if self.device.type != "cpu" else src
             self._resize_into(src, tiles[n])                                       # the thumbnail: aspect-squashing resize
             n += 1

@@ -109,11 +109,24 @@ class EngineWeights:
     patch_k: int = 0        # im2col K padded to 64
     vit_ff: int = 0         # fc1 width padded to 128
     llm_ff: int = 0
+    # tensor-parallel shard of the LLM (1 = whole model): local head counts, llm_ff is the local FFN slice
+    llm_heads: int = 0
+    llm_kv_heads: int = 0
+    tp_rank: int = 0
+    tp_size: int = 1
 
     @classmethod
-    def build(cls, cfg: LeopardConfig, source, dtype) -> "EngineWeights":
+    def build(cls, cfg: LeopardConfig, source, dtype, tp_rank: int = 0, tp_size: int = 1) -> "EngineWeights":
+        """``tp_size`` > 1: Megatron-style tensor-parallel shard ``tp_rank`` of the LLM (SURVEY.md 8e phase B): q/k/v and gate/up
+        split by output rows (whole heads / FFN slices), o_proj and down_proj by input columns; norms, embedding, lm_head and
+        the whole vision side are replicated.  The engine all-reduces the two partial products per layer (leopard_amd.dist)."""
         vc, tc = cfg.vision_config, cfg.text_config
         W = cls(cfg=cfg, dtype=dtype)
+        W.tp_rank, W.tp_size = tp_rank, tp_size
+        if tp_size > 1 and (tc.num_attention_heads % tp_size or tc.num_key_value_heads % tp_size or (tc.intermediate_size // tp_size) % 64
+                            or tc.intermediate_size % tp_size):
+            raise ValueError(f"tensor parallel degree {tp_size} must divide the head counts ({tc.num_attention_heads}/"
+                             f"{tc.num_key_value_heads}) and leave an FFN slice that is a multiple of 64")
         for dim, what in ((vc.hidden_size, "vision hidden"), (tc.hidden_size, "text hidden"),
                           (tc.num_attention_heads * tc.head_dim, "q width"), (tc.num_key_value_heads * tc.head_dim, "kv width")):
             if dim % 128:
@@ -124,7 +137,8 @@ class EngineWeights:
         v = "vision_tower.vision_model."
         W.patch_k = _round_up(vc.patch_dim, 64)
         W.vit_ff = _round_up(vc.intermediate_size, 128)
-        W.llm_ff = tc.intermediate_size
+        W.llm_ff = tc.intermediate_size // tp_size
+        W.llm_heads, W.llm_kv_heads = tc.num_attention_heads // tp_size, tc.num_key_value_heads // tp_size
         W.patch_w = _pad2(g(v + "embeddings.patch_embedding.weight").reshape(vc.hidden_size, -1), vc.hidden_size, W.patch_k)
         W.patch_b = _pad1(g(v + "embeddings.patch_embedding.bias"), vc.hidden_size)
         W.pos_emb = g(v + "embeddings.position_embedding.weight").to(torch.float32).contiguous()
@@ -148,14 +162,17 @@ class EngineWeights:
         W.embed = g(l + "embed_tokens.weight").contiguous()
         for i in range(tc.num_hidden_layers):
             p = f"{l}layers.{i}."
-            qkv_w = torch.cat([g(p + f"self_attn.{n}_proj.weight") for n in "qkv"], dim=0).contiguous()
+            qw, kw, ff = W.llm_heads * tc.head_dim, W.llm_kv_heads * tc.head_dim, W.llm_ff
+            rq, rk, rf = slice(tp_rank * qw, (tp_rank + 1) * qw), slice(tp_rank * kw, (tp_rank + 1) * kw), slice(tp_rank * ff, (tp_rank + 1) * ff)
+            qkv_w = torch.cat([g(p + "self_attn.q_proj.weight")[rq], g(p + "self_attn.k_proj.weight")[rk],
+                               g(p + "self_attn.v_proj.weight")[rk]], dim=0).contiguous()
             W.llm_layers.append(LlmLayerW(
                 in_norm=g(p + "input_layernorm.weight").float().contiguous(),
                 qkv_w=qkv_w,
-                o_w=g(p + "self_attn.o_proj.weight").contiguous(),
+                o_w=g(p + "self_attn.o_proj.weight")[:, rq].contiguous(),
                 post_norm=g(p + "post_attention_layernorm.weight").float().contiguous(),
-                gu_w=interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")),
-                down_w=g(p + "mlp.down_proj.weight").contiguous()))
+                gu_w=interleave_gate_up(g(p + "mlp.gate_proj.weight")[rf], g(p + "mlp.up_proj.weight")[rf]),
+                down_w=g(p + "mlp.down_proj.weight")[:, rf].contiguous()))
         W.final_norm = g(l + "norm.weight").float().contiguous()
         head = g("language_model.lm_head.weight")
         W.lm_head = _pad2(head, _round_up(head.shape[0], 128), tc.hidden_size)

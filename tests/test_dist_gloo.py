@@ -71,3 +71,66 @@ def test_tile_slices_balanced():
             s = tile_slices(n, w)
             assert s[0][0] == 0 and s[-1][1] == n and all(a[1] == b[0] for a, b in zip(s, s[1:]))
             assert max(b - a for a, b in s) - min(b - a for a, b in s) <= 1
+
+
+def _tp_config():
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    return LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16,
+                                   image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                               num_key_value_heads=2, vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+
+
+def _tp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from leopard_amd import dist as D
+    from leopard_amd.engine import KVCache, LeopardEngine
+    from leopard_amd.weights import EngineWeights, SynthSource
+    from tests.emu_util import emu_ops
+    D.init(backend="gloo")
+    ops = emu_ops()
+    cfg = _tp_config()
+    src = SynthSource(cfg, ops, "cpu", torch.float16)
+    eng = LeopardEngine(cfg, EngineWeights.build(cfg, src, torch.float16, tp_rank=rank, tp_size=world), ops=ops, device="cpu")
+    assert eng.tp_size == world and eng.W.llm_layers[0].qkv_w.shape[0] == (1 + 2) * 128 and eng.W.llm_layers[0].down_w.shape[1] == 64
+    tiles = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
+    ids = torch.tensor([[5, 250, 9, 250, 17, 33]])
+    cache = KVCache(cfg, 16, torch.float16, "cpu", tp_size=world)
+    assert cache.k[0].shape[1] == 128                              # this rank's one kv head
+    res = eng.prefill(ids, tiles, cache=cache)
+    step = eng.decode_step(int(res.logits_last.argmax()), cache).clone()
+    gen = eng.generate(ids, tiles, max_new_tokens=3, eos_token_id=())
+    ref = None
+    if rank == 0:                                                  # the same model on one rank
+        one = LeopardEngine(cfg, EngineWeights.build(cfg, src, torch.float16), ops=ops, device="cpu")
+        c1 = KVCache(cfg, 16, torch.float16, "cpu")
+        r1 = one.prefill(ids, tiles, cache=c1)
+        s1 = one.decode_step(int(r1.logits_last.argmax()), c1).clone()
+        ref = (float((res.logits_last - r1.logits_last).abs().max()), float((step - s1).abs().max()),
+               gen.tolist() == one.generate(ids, tiles, max_new_tokens=3, eos_token_id=()).tolist(), float(r1.logits_last.abs().max()))
+    out.put((rank, res.logits_last.tolist(), ref))
+    D.barrier()
+
+
+def test_tensor_parallel_llm_two_ranks_gloo():
+    """SURVEY.md 8e phase B on CPU: the LLM sharded over 2 ranks (heads / FFN slices, all-reduce of the partial o_proj and
+    down_proj products) gives every rank the logits of the unsharded model, in prefill, decode and greedy generation."""
+    mp.set_start_method("spawn", force=True)
+    from tests.emu_util import emu_ops
+    emu_ops()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, ref), (_, l1, _) = res
+    assert l0 == l1                                                # both ranks hold the same, complete logits
+    d_prefill, d_decode, same_tokens, scale = ref
+    assert d_prefill <= 2e-3 * max(1.0, scale) and d_decode <= 2e-3 * max(1.0, scale) and same_tokens
