@@ -56,21 +56,10 @@ template <int N> LMI_DEV void wait_vmcnt_barrier() { asm volatile("s_waitcnt vmc
 // receives D[(r&3)+8*(r>>2)+4*(l>>5)][l&31], r=0..15.
 LMI_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 LMI_DEV f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-// D[16x16] += A[16x32] * B[32x16].  Lane l supplies A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15];
-// receives D[4*(l>>4)+r][l&15], r=0..3.
-LMI_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-LMI_DEV f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// async 16-byte global -> LDS copy: LDS destination = lds_wave_base + lane*16 (wave-uniform base).
-LMI_DEV void glds16(const void* gptr, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// LDS transpose read: within each 16-lane group, lane i = 4*j+g supplies the address of 4 consecutive
-// 16-bit elements (row j, column group g); lane c receives {row0[c], row1[c], row2[c], row3[c]}.
-// Same through a buffer resource: source byte = base + voffset (per lane) + soffset (wave-uniform), both 32-bit; bytes at
-// or beyond num_records read as zero (raw-buffer range check), so ragged tile tails need no address clamp.
+// async 16-byte global -> LDS copy through a buffer resource: LDS destination = lds_wave_base + lane*16 (wave-uniform base);
+// source byte = base + voffset (per lane) + soffset (wave-uniform), both 32-bit; bytes at or beyond num_records read as zero
+// (raw-buffer range check), so ragged tile tails need no address clamp.
 struct BufRsrc {
     __amdgpu_buffer_rsrc_t r;
 };
@@ -91,11 +80,6 @@ LMI_DEV u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
-// scheduling-group hints (LLVM igrouplp): one group of `n` instructions of a class, in program order of the hints
-#define LMI_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
-#define LMI_SCHED_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
-#define LMI_SCHED_DSREAD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
-#define LMI_SCHED_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x010, n, 0)
 
 // Batched form used by attention: for d-block i = 0..N-1 read the 4-key groups at byte offsets i*64 and
 // i*64 + ROW8 from one base address, one wait for all 2N reads.  out[i] = {lo.x, lo.y, hi.x, hi.y}.
@@ -165,7 +149,6 @@ LMI_DEV void lgkm_fence(u32x2 (&lo)[N], u32x2 (&hi)[N]) {
 
 LMI_DEV float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 LMI_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
-LMI_DEV float shfl(float v, int l) { return __shfl(v, l, 64); }
 // v_permlane32_swap_b32: lanes 32..63 of `a` trade places with lanes 0..31 of `b` (no LDS round trip)
 LMI_DEV void swap_hi_lo(unsigned& a, unsigned& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -215,30 +198,8 @@ inline f32x16 emu_mfma32(V8 a, V8 b, f32x16 c) {
     hipemu::wave_sync();
     return c;
 }
-template <typename V8>
-inline f32x4 emu_mfma16(V8 a, V8 b, f32x4 c) {
-    struct Slot { float a[8], b[8]; };
-    Slot* s = (Slot*)hipemu::wave_buf();
-    const int l = lane_id();
-    for (int j = 0; j < 8; ++j) { s[l].a[j] = (float)a[j]; s[l].b[j] = (float)b[j]; }
-    hipemu::wave_sync();
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * (l >> 4) + r, col = l & 15;
-        float acc = c[r];
-        for (int k = 0; k < 32; ++k) acc += s[row + 16 * (k >> 3)].a[k & 7] * s[col + 16 * (k >> 3)].b[k & 7];
-        c[r] = acc;
-    }
-    hipemu::wave_sync();
-    return c;
-}
 inline f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return emu_mfma32(a, b, c); }
 inline f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return emu_mfma32(a, b, c); }
-inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return emu_mfma16(a, b, c); }
-inline f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return emu_mfma16(a, b, c); }
-
-inline void glds16(const void* gptr, void* lds_wave_base) {
-    __builtin_memcpy((char*)lds_wave_base + lane_id() * 16, gptr, 16);
-}
 
 struct BufRsrc {
     const char* base;
@@ -268,10 +229,6 @@ inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
-#define LMI_SCHED_MFMA(n) ((void)0)
-#define LMI_SCHED_VALU(n) ((void)0)
-#define LMI_SCHED_DSREAD(n) ((void)0)
-#define LMI_SCHED_VMEM(n) ((void)0)
 
 template <int N, int ROW8>
 inline void ds_read_tr16_batch(const void* lds_ptr, u32x4* out) {
@@ -303,7 +260,6 @@ inline S emu_shfl_idx(S v, int src) {
 }
 inline float shfl_xor(float v, int m) { return emu_shfl_idx(v, lane_id() ^ m); }
 inline int shfl_xor(int v, int m) { return emu_shfl_idx(v, lane_id() ^ m); }
-inline float shfl(float v, int l) { return emu_shfl_idx(v, l); }
 inline void swap_hi_lo(unsigned& a, unsigned& b) {
     const unsigned ta = (unsigned)emu_shfl_idx((int)a, lane_id() ^ 32), tb = (unsigned)emu_shfl_idx((int)b, lane_id() ^ 32);
     if (lane_id() < 32) b = ta; else a = tb;
