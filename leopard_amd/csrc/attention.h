@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // attn_fwd_dma_kernel — production variant (head_dim 128 and 72).  Same register-level design as attn_fwd_kernel, but K and V
-// tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 2-slot ring: no staging VGPRs, no ds_write
+// tiles go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) into a 2-slot ring: no staging VGPRs, no ds_write
 // pass, one counted wait + one raw barrier per 64-key tile, and the register budget fits 2 waves per SIMD so a
 // second workgroup's MFMAs run under this one's softmax.  LDS-DMA writes lane-linearly, so the LDS images are
 // unpadded [64][256 B] and de-conflicted by XOR swizzles applied to the per-lane SOURCE chunk and again on read:

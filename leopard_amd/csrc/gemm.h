@@ -6,7 +6,7 @@
 //
 // One kernel template, several tile geometries (GemmCfg): BM x BN output tile, BK = 64, WAVES_M x WAVES_N
 // waves, each wave owning a (BM/WAVES_M) x (BN/WAVES_N) sub-tile as MI x NI v_mfma_f32_32x32x16 accumulators.
-//   * Both operands are K-contiguous and go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip)
+//   * Both operands are K-contiguous and go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (LDS-DMA, no VGPR round trip)
 //     into a ring of STAGES k-tile slots.  Loads for tile t+STAGES-1 are issued, interleaved between the MFMAs,
 //     while tile t is being multiplied; the only synchronisation per k-tile is one counted `s_waitcnt vmcnt(N)`
 //     (never 0 in steady state for STAGES >= 3) + one raw s_barrier.

@@ -1,7 +1,7 @@
 // lmi_device.h — the few hardware primitives every Leopard-MI kernel is written against.
 //
 // Device build (hipcc --offload-arch=gfx950): thin inline wrappers over the CDNA4 builtins
-// (v_mfma_f32_32x32x16_{bf16,f16}, global_load_lds_dwordx4, ds_read_b64_tr_b16, wave64 shuffles).
+// (v_mfma_f32_32x32x16_{bf16,f16}, buffer_load_dwordx4 ... lds, ds_read_b64_tr_b16, wave64 shuffles).
 //
 // LMI_EMU build (host clang, tools/hipemu): the same names implemented by a lock-step fibre emulator
 // so that kernel *logic* (tile indexing, swizzles, masks, epilogues) can be unit-tested on a machine
