@@ -28,10 +28,31 @@ def tol(dtype):
     return 2e-3 if dtype == torch.float16 else 1.6e-2
 
 
+def _declared_symbols():
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "leopard_amd.h")).read()
+    return sorted(set(re.findall(r"^(?:int|int64_t|const char\*)\s+(lmi_\w+)\(", hdr, flags=re.M)))
+
+
 def test_abi_exports_every_declared_symbol(ops):
-    for name in _lib.SIGNATURES:
-        assert hasattr(ops.lib, name)
+    """Every entry point include/leopard_amd.h declares is exported by the emulator build AND by the product library
+    (libleopard_amd.so, built by `make`; no compute call is made on it here), and has a ctypes prototype in _lib."""
+    import ctypes
+    import os
+    declared = _declared_symbols()
+    assert len(declared) >= 18 and "lmi_gemm" in declared and "lmi_attn_decode_fwd" in declared
+    bound = set(_lib.SIGNATURES) | {"lmi_last_error", "lmi_attn_decode_workspace_bytes"}
+    assert set(declared) == bound, set(declared) ^ bound
+    for name in declared:
+        assert hasattr(ops.lib, name), name
     assert ops.lib.lmi_abi_version() == 1
+    if os.path.exists(_lib.LIB_PATH):
+        prod = ctypes.CDLL(_lib.LIB_PATH)
+        for name in declared:
+            assert hasattr(prod, name), f"libleopard_amd.so does not export {name}"
+    else:
+        pytest.skip("libleopard_amd.so not built (run `make`)")
 
 
 def test_fill_synthetic_bit_exact(ops):
