@@ -73,6 +73,15 @@ class LeopardForConditionalGeneration:
             raise RuntimeError("call .to(device) first (the HIP engine is built on the target device)")
         return self._engine
 
+    def _as_tiles(self, pixel_values):
+        """``pixel_values``: the reference's normalised fp32 [N,3,S,S], or the GPU tiler's u8 [N,S,S,3] tile stack (the
+        normalisation then happens in lmi_preprocess_tiles)."""
+        if pixel_values is None:
+            return None
+        if pixel_values.dtype == torch.uint8:
+            return pixel_values.to(self.device).contiguous()
+        return pixel_values.to(device=self.device, dtype=torch.float32).contiguous()
+
     # ---- EVAL:201-361 ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None, past_key_values=None,
@@ -88,7 +97,7 @@ class LeopardForConditionalGeneration:
         if past_key_values is not None and input_ids.shape[1] == 1:          # decode branch, EVAL:291-320
             logits = eng.decode_step(int(input_ids[0, 0]), past_key_values)
             return LlavaCausalLMOutputWithPast(logits=logits.view(1, 1, -1), past_key_values=past_key_values)
-        tiles = None if pixel_values is None else pixel_values.to(device=self.device, dtype=torch.float32).contiguous()
+        tiles = self._as_tiles(pixel_values)
         S = input_ids.shape[1] + int((input_ids == self.config.image_token_index).sum()) * (self.config.tokens_per_tile - 1)
         cache = KVCache(self.config, S + 256, self.compute_dtype, self.device) if use_cache else None
         res = eng.prefill(input_ids.to(self.device), tiles, cache=cache, all_logits=True)
@@ -103,7 +112,7 @@ class LeopardForConditionalGeneration:
         if input_ids.shape[0] != 1:
             raise NotImplementedError("batch 1 per call, as in the reference harness")
         eos = eos_token_id if isinstance(eos_token_id, (list, tuple)) else ([] if eos_token_id is None else [eos_token_id])
-        tiles = None if pixel_values is None else pixel_values.to(device=self.device, dtype=torch.float32).contiguous()
+        tiles = self._as_tiles(pixel_values)
         return self.engine.generate(input_ids.to(self.device), tiles, max_new_tokens=max_new_tokens, eos_token_id=eos)
 
 

@@ -21,8 +21,11 @@ from .ops import Ops
 
 
 class GpuTiler:
-    def __init__(self, ops: Ops, device, tile: int = tiler.TILE, sample_budget: int = tiler.SAMPLE_BUDGET):
+    def __init__(self, ops: Ops, device, tile: int = tiler.TILE, sample_budget: int = tiler.SAMPLE_BUDGET, out_size: int = 0):
+        """``out_size``: side of the ViT inputs when it differs from the planner's tile (the processor then resizes every
+        input, tiles included — never the case for Leopard's 364 / 364, used by reduced test configurations)."""
         self.ops, self.device, self.tile, self.sample_budget = ops, torch.device(device), tile, sample_budget
+        self.out_size = out_size or tile
         self._coef = {}
 
     def _coeffs(self, in_size: int, out_size: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -54,7 +57,7 @@ class GpuTiler:
         T = self.tile
         sizes = [(int(im.shape[1]), int(im.shape[0])) for im in images]            # PIL (W, H)
         plan = tiler.plan_sample(sizes, T, self.sample_budget)
-        tiles = torch.empty((plan.n_vit_inputs, T, T, 3), dtype=torch.uint8, device=self.device)
+        tiles = torch.empty((plan.n_vit_inputs, self.out_size, self.out_size, 3), dtype=torch.uint8, device=self.device)
         n = 0
         for im, size, canvas in zip(images, sizes, plan.canvases):
             src = torch.from_numpy(np.array(im, dtype=np.uint8, order="C"))             # a writable copy (images may be read-only views)
@@ -69,7 +72,7 @@ class GpuTiler:
             self._resize_into(src, board[py:py + nh, px:px + nw])
             for y in range(0, ch, T):
                 for x in range(0, cw, T):
-                    tiles[n].copy_(board[y:y + T, x:x + T])
+                    self._resize_into(board[y:y + T, x:x + T], tiles[n])              # a copy when the sizes agree
                     n += 1
         assert n == plan.n_vit_inputs
         return tiles, plan

@@ -108,11 +108,19 @@ def build_prompt(question: str, n_images: int, tiles_per_image: List[int], setti
     return prompt, question, sum(g.count(TOK_IMG) for g in groups)
 
 
-def prepare_sample(record: dict, setting: str, open_image: Optional[Callable] = None) -> PreparedSample:
+def prepare_sample(record: dict, setting: str, open_image: Optional[Callable] = None, pixels: bool = True) -> PreparedSample:
+    """``pixels=False``: plan only — ``vit_inputs`` then holds the source images and the tile cutting is left to the GPU tiler
+    (leopard_amd.gpu_tiler), which produces the very tiles ``tile_images`` would."""
     from PIL import Image
     opener = open_image or (lambda p: Image.open(p).convert("RGB"))
     images = [opener(p) for p in record["images_path"]]
-    vit_inputs, real = tile_images(images)
+    if pixels:
+        vit_inputs, real = tile_images(images)
+    else:
+        from .tiler import plan_sample
+        budget = SAMPLE_BUDGET - len(images)
+        real = [1] * len(images) if budget <= 0 else plan_sample([im.size for im in images]).tiles_per_image     # sic (EVAL:400-401)
+        vit_inputs = images
     prompt, question, n_tok = build_prompt(record["question"], len(images), real, setting, record["ques_type"])
     return PreparedSample(prompt, question, vit_inputs, real, n_tok)
 
@@ -136,21 +144,31 @@ def shard_result_path(checkpoint: str, shard: int, setting: str, dataset: str) -
 
 
 def run_inference(records: List[dict], model, tokenizer, setting: str = "direct", scorer: Optional[Callable] = None,
-                  device=None) -> List[dict]:
-    """The hot loop (EVAL:381-487) over already-sharded records, batch 1, greedy."""
+                  device=None, gpu_tiler=None) -> List[dict]:
+    """The hot loop (EVAL:381-487) over already-sharded records, batch 1, greedy.  ``gpu_tiler`` (a
+    leopard_amd.gpu_tiler.GpuTiler): resize / pad / crop run on the device and the u8 tile stack goes straight to the model
+    (same pixels as the PIL path, bit for bit); without it the reference's host pipeline is used."""
+    import numpy as np
     import torch
     from .tiler import siglip_preprocess
     rows = []
+    size = getattr(getattr(getattr(model, "config", None), "vision_config", None), "image_size", TILE)    # 364 for Leopard
     for rec in records:
-        s = prepare_sample(rec, setting)
-        pixel_values = torch.from_numpy(siglip_preprocess(s.vit_inputs))
+        dev = device if device is not None else model.device
+        if gpu_tiler is not None:
+            s = prepare_sample(rec, setting, pixels=False)
+            pixel_values, plan = gpu_tiler.tile_sample([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in s.vit_inputs])
+            n_vit = plan.n_vit_inputs
+        else:
+            s = prepare_sample(rec, setting)
+            pixel_values = torch.from_numpy(siglip_preprocess(s.vit_inputs, size)).to(dev)
+            n_vit = len(s.vit_inputs)
         enc = tokenizer([s.prompt], return_tensors="pt", truncation=True, max_length=MAX_PROMPT_TOKENS)["input_ids"]
         attn = enc != tokenizer.pad_token_id
-        dev = device if device is not None else model.device
-        out = model.generate(enc.to(dev), pixel_values=pixel_values.to(dev), attention_mask=attn.to(dev),
+        out = model.generate(enc.to(dev), pixel_values=pixel_values, attention_mask=attn.to(dev),
                              **generate_kwargs(tokenizer.pad_token_id))
         response = tokenizer.batch_decode(out[:, enc.shape[1]:], skip_special_tokens=True)[0]
-        rows.append(result_row(rec, s.question, response, len(s.vit_inputs), scorer))
+        rows.append(result_row(rec, s.question, response, n_vit, scorer))
     return rows
 
 

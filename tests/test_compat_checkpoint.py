@@ -60,3 +60,42 @@ def test_reference_call_sequence(ckpt):
     assert nxt.logits.shape == (1, 1, cfg.text_config.vocab_size)
     with pytest.raises(ValueError, match="number of image tokens"):
         llava.generate(input_ids, pixel_values=images[:1], max_new_tokens=1)
+
+
+def test_harness_gpu_tiler_path_equals_host_path(ckpt, tmp_path):
+    """harness.run_inference with the GPU tiler (emulated here) writes the same rows as with the reference's host pipeline:
+    same prompt, same pixels (bit-exact tiles), same greedy continuation."""
+    from PIL import Image
+    from leopard_amd import harness
+    from leopard_amd.gpu_tiler import GpuTiler
+    from leopard_amd.synth import synth_image_u8
+    d, cfg = ckpt
+    ops = emu_ops()
+    model = compat.LeopardForConditionalGeneration.from_pretrained(str(d / "single"), ops=ops).to("cpu").eval()
+
+    class Tok:
+        pad_token_id = 0
+
+        def __call__(self, texts, **kw):
+            ids = []
+            for piece in texts[0].split(harness.TOK_IMG):
+                ids += [1 + (ord(c) % 200) for c in piece[::9]] + [cfg.image_token_index]
+            return {"input_ids": torch.tensor([ids[:-1]])}
+
+        def batch_decode(self, ids, **kw):
+            return [" ".join(str(int(i)) for i in ids[0])]
+
+    paths = []
+    for i, (w, h) in enumerate([(800, 500), (300, 300)]):          # thumbnail + 2 tiles, thumbnail only
+        p = str(tmp_path / f"im{i}.png")
+        Image.fromarray(synth_image_u8(40 + i, w, h)).save(p)
+        paths.append(p)
+    recs = [{"images_path": paths, "question": "<image><image> which?", "answers": ["A"], "ques_type": "open-ended", "options": None}]
+    gen_kw = harness.generate_kwargs
+    harness.generate_kwargs = lambda pad: {**gen_kw(pad), "max_new_tokens": 3}
+    try:
+        host = harness.run_inference(recs, model, Tok())
+        dev = harness.run_inference(recs, model, Tok(), gpu_tiler=GpuTiler(ops, "cpu", out_size=cfg.vision_config.image_size))
+    finally:
+        harness.generate_kwargs = gen_kw
+    assert host == dev and len(host) == 1 and host[0]["raw"] and host[0]["multi_img"]
