@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Race screen: the C3 prefill (and a few decode steps) repeated; every launch is deterministic, so all repetitions must give
+bit-identical logits.  A stale LDS read or an early DMA overwrite shows up as a mismatch that comes and goes."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from leopard_amd.config import full_config  # noqa: E402
+from leopard_amd.engine import KVCache, LeopardEngine  # noqa: E402
+from leopard_amd.gpu_tiler import GpuTiler  # noqa: E402
+from leopard_amd.ops import Ops  # noqa: E402
+from leopard_amd.synth import synth_image_u8, synth_prompt_ids  # noqa: E402
+from leopard_amd.weights import EngineWeights, SynthSource  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda:0")
+cfg = full_config()
+ops = Ops()
+eng = LeopardEngine(cfg, EngineWeights.build(cfg, SynthSource(cfg, ops, dev, torch.float16), torch.float16), ops=ops, device=dev)
+tiles, plan = GpuTiler(ops, dev).tile_sample([synth_image_u8(i, 1344, 896) for i in range(6)])
+ids = torch.from_numpy(synth_prompt_ids(plan.vit_inputs_per_image, cfg, seed=0)).reshape(1, -1)
+S = ids.shape[1] + tiles.shape[0] * (cfg.tokens_per_tile - 1)
+ref, ref_dec, bad = None, None, 0
+for r in range(reps):
+    cache = KVCache(cfg, S + 8, torch.float16, dev)
+    res = eng.prefill(ids, tiles, cache=cache)
+    dec = [eng.decode_step(int(res.logits_last.argmax()), cache).clone()]
+    dec.append(eng.decode_step(int(dec[0].argmax()), cache).clone())
+    torch.cuda.synchronize()
+    if ref is None:
+        ref, ref_dec = res.logits_last.clone(), dec
+    else:
+        same = torch.equal(ref, res.logits_last) and all(torch.equal(a, b) for a, b in zip(ref_dec, dec))
+        bad += 0 if same else 1
+        if not same:
+            print(f"rep {r}: MISMATCH max|d| prefill {float((ref - res.logits_last).abs().max()):.3e}")
+print(f"{reps} repetitions, {bad} mismatches")
+sys.exit(1 if bad else 0)
