@@ -263,6 +263,7 @@ def main():
                     help="N > 1: 'sample' = one sample per rank, no data-path collective (default, weak scaling); 'tp' = ONE sample "
                          "per step on all ranks: tile-sharded vision encode + all-gather, tensor-parallel LLM with two all-reduces "
                          "per layer (strong scaling, single-sample latency)")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (lmi_set_option), e.g. gemm.wide=7 for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -290,6 +291,9 @@ def main():
         return bench_c5(args, dev, dtype, rank, world, D)
     cfg = full_config()
     ops = Ops()
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ops.set_option(k, int(v))
     t0 = time.perf_counter()
     tp = args.parallelism == "tp" and world > 1
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype, tp_rank=rank if tp else 0, tp_size=world if tp else 1)

@@ -92,7 +92,7 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
 int choose_gemm_cfg(const GemmArgs& a) {
     if (g_gemm_cfg >= 0) return g_gemm_cfg;
     if (a.M < 512) return 8;
-    if (a.N >= 2048) return 7;
+    if (a.N >= 2048) return a.K <= 1536 ? 2 : 7;   // short K (SigLIP qkv / fc1): the 3-slot ring's shorter prologue wins
     if (a.K >= 2048) return 2;
     return 0;
 }

@@ -52,7 +52,7 @@ struct GemmArgs {
 };
 
 constexpr int GEMM_BK = 64;
-constexpr int GEMM_GROUP_M = 8;
+constexpr int GEMM_GROUP_M = 4;                 // end-to-end sweep 2..16 on the C3 prefill: 4-6 best (-0.5 % vs 8), 16 +4 %
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int STAGES_>
 struct GemmCfg {
@@ -93,7 +93,7 @@ LMI_DEV float act_apply(float x, int act) {
 LMI_DEV int gemm_lds_off(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); }
 
 // XCD-aware, grouped tile order.  Tiles are linearised in groups of `group_m` row-tiles, row-tile fastest, so that 32
-// consecutive ids form an (8 x 4)-tile patch whose A / W panels one XCD's 4 MiB L2 can hold.  Workgroup b runs on XCD
+// consecutive ids form a (group_m x 32/group_m)-tile patch whose current k-tiles one XCD's 4 MiB L2 can hold.  Workgroup b runs on XCD
 // b % 8 (observed dispatch; speed only).  order 0: XCD x owns the x-th contiguous eighth of the linear order (bijective
 // for any tile count).  order 1: the XCDs take 32-tile patches round-robin, so at any time all eight work on
 // neighbouring patches of the SAME row-tile group and share its A panel through the Infinity Cache; the grid is rounded
@@ -119,116 +119,123 @@ LMI_DEV bool gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, in
     return true;
 }
 
-// ---- epilogue shared by every geometry: lane owns row m = .. + fr and 4 consecutive n per accumulator quad -----
-// Written so that hipcc can batch the memory operations: the per-lane bias quads are loaded once, and for each output
-// row all residual / position-table loads are issued back to back before the first use (a per-quad load -> wait -> store
-// chain costs a full memory round trip per quad: 32 serialized round trips per lane on a 128x64 wave tile).
-template <typename T, int EPI, int ACT, typename C>
-LMI_DEV void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[C::NI][C::MI], int m0, int n0, int wm, int wn, int fr, int fh) {
-    typedef typename vec_of<T>::x4 T4;
+// ---- epilogue shared by every geometry -------------------------------------------------------------------------
+// The accumulator layout gives a lane ONE output row and 4-column quads, so storing straight from it writes 8/16-byte
+// pieces into 32 different rows per instruction (measured: 1.8-2.8 TB/s on the output stream, a quarter of the SigLIP
+// GEMMs' time).  Instead every wave turns its tile through its own slice of the (now idle) LDS, 32 rows at a time:
+//   write: lane (fr, fh) puts its 4*NI quads of row fr into a [32][WTN] fp32 image (row stride WTN*4 + 16 bytes: the 8
+//          lanes of a ds_write_b128 group land in 8 distinct 16-byte bank groups);
+//   read:  lane l takes 8 consecutive columns of row l / LPR, so that a wave instruction covers whole rows of the
+//          wave tile: 16-byte T stores / 32-byte fp32 loads and stores per lane, 256-512 contiguous bytes per row.
+// bias / position table / activation / residual add are applied on the read side, in the same order per element as the
+// definition (acc + bias, + table row, act, + residual), so results are bit-identical to the direct form.
+// DS operations of one wave execute in order, so the write -> read -> next write sequence needs no barrier; the caller
+// guarantees that no other wave still reads k-tiles from `stage`.
+// `put(mi, stage)` writes rows mi*32 .. mi*32+31 of the wave tile into the image (it depends on the MFMA shape's accumulator layout).
+template <int WTN> struct GemmImage { static constexpr int RS = WTN * 4 + 16; };   // LDS row stride of the fp32 image
+template <typename T, int EPI, int ACT, typename C, typename Put>
+LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, int wn, int lane, char* stage) {
+    typedef typename vec_of<T>::x8 T8;
+    constexpr int RS = GemmImage<C::WTN>::RS;
+    static_assert(32 * RS <= C::SMEM / (C::NT / 64), "per-wave LDS slice too small for the epilogue image");
     const int nw0 = n0 + wn * C::WTN;                                   // first column of this wave
-    if (EPI == EPI_SWIGLU_T) {
-        // W rows are interleaved in 32-row blocks [gate | up]: accumulator ni = 2j holds gate, 2j+1 holds up
-#pragma unroll
-        for (int mi = 0; mi < C::MI; ++mi) {
-            const int m = m0 + wm * C::WTM + mi * 32 + fr;
-            if (m >= p.M) continue;
-            const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
-#pragma unroll
-            for (int nj = 0; nj < C::NI / 2; ++nj) {
-                const int nb = nw0 + nj * 64;
-                if (nb >= p.N) continue;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    T4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (T)(fast_silu(acc[2 * nj][mi][q * 4 + e]) * acc[2 * nj + 1][mi][q * 4 + e]);
-                    *(T4*)((T*)p.out + orow * p.ldo + (nb >> 1) + q * 8 + fh * 4) = v;
-                }
-            }
-        }
-        return;
+    if (nw0 >= p.N) return;                                             // N % 128 == 0 and WTN | 128: all or nothing
+    constexpr int OUT_COLS = (EPI == EPI_SWIGLU_T) ? C::WTN / 2 : C::WTN;
+    constexpr int LPR = OUT_COLS / 8, RPI = 64 / LPR, ITERS = 32 / RPI; // lanes per row, rows per instruction
+    const int oc = (lane % LPR) * 8, r_in = lane / LPR;
+    // source columns of this lane in the image: plain = oc..oc+7; SwiGLU = gate block, up block 32 columns further
+    const int sc = (EPI == EPI_SWIGLU_T) ? (oc >> 5) * 64 + (oc & 31) : oc;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
+    if (EPI != EPI_SWIGLU_T && p.bias) {
+        bias0 = *(const f32x4*)(p.bias + nw0 + oc);
+        bias1 = *(const f32x4*)(p.bias + nw0 + oc + 4);
     }
-    // columns of this lane: n(ni, q) = nw0 + ni*32 + q*8 + fh*4 ; valid while the 32-column block starts below N
-    f32x4 bias[C::NI][4];
-#pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = nw0 + ni * 32 + q * 8 + fh * 4;
-            bias[ni][q] = (p.bias && nw0 + ni * 32 < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi) {
-        const int m = m0 + wm * C::WTM + mi * 32 + fr;
-        if (m >= p.M) continue;
-        const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
-        f32x4 v[C::NI][4];
+        const int mb = m0 + wm * C::WTM + mi * 32;
+        if (mb >= p.M) break;
+        put(mi, stage);
+        wave_lds_fence();
+        if (EPI == EPI_SWIGLU_T) {
 #pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni)
+            for (int it = 0; it < ITERS; ++it) {
+                const int row = it * RPI + r_in, m = mb + row;
+                const char* src = stage + row * RS + sc * 4;
+                const f32x4 g0 = *(const f32x4*)src, g1 = *(const f32x4*)(src + 16);
+                const f32x4 u0 = *(const f32x4*)(src + 128), u1 = *(const f32x4*)(src + 144);
+                T8 o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[ni][q][e] = acc[ni][mi][q * 4 + e];
-                v[ni][q] += bias[ni][q];
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (T)(fast_silu(g0[e]) * u0[e]);
+                    o[4 + e] = (T)(fast_silu(g1[e]) * u1[e]);
+                }
+                if (m < p.M) {
+                    const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
+                    *(T8*)((T*)p.out + orow * p.ldo + (nw0 >> 1) + oc) = o;
+                }
             }
-        if (p.addmat) {                                                  // SigLIP position table (patch-embed GEMM only)
-            const float* arow = p.addmat + (long)(p.add_rows ? p.add_rows[m] : m % p.add_period) * p.N;
-#pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni)
-                if (nw0 + ni * 32 < p.N) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[ni][q] += *(const f32x4*)(arow + nw0 + ni * 32 + q * 8 + fh * 4);
-                }
+            wave_lds_fence();
+            continue;
         }
-        if (ACT != ACT_NONE) {
+        f32x4 v0[ITERS], v1[ITERS], old0[ITERS], old1[ITERS];
+        long orow[ITERS];
 #pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[ni][q][e] = act_apply(v[ni][q][e], ACT);
+        for (int it = 0; it < ITERS; ++it) {                              // all loads of the 32 rows first ...
+            const int row = it * RPI + r_in;
+            const int mc = imin(mb + row, p.M - 1);                       // clamped: loads are unconditional, stores masked
+            orow[it] = p.row_map ? (long)p.row_map[mc] : (long)mc;
+            const char* src = stage + row * RS + sc * 4;
+            v0[it] = *(const f32x4*)src + bias0;
+            v1[it] = *(const f32x4*)(src + 16) + bias1;
+            if (p.addmat) {                                               // SigLIP position table (patch-embed GEMM only)
+                const float* arow = p.addmat + (long)(p.add_rows ? p.add_rows[mc] : mc % p.add_period) * p.N + nw0 + oc;
+                v0[it] += *(const f32x4*)arow;
+                v1[it] += *(const f32x4*)(arow + 4);
+            }
+            if (EPI == EPI_RESID_F32) {
+                const float* drow = (const float*)p.out + orow[it] * p.ldo + nw0 + oc;
+                old0[it] = *(const f32x4*)drow;
+                old1[it] = *(const f32x4*)(drow + 4);
+            }
         }
-        if (EPI == EPI_RESID_F32) {
-            float* drow = (float*)p.out + orow * p.ldo;
-            f32x4 old[C::NI][4];
+        wave_lds_fence();
 #pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni)                            // all residual loads first ...
-                if (nw0 + ni * 32 < p.N) {
+        for (int it = 0; it < ITERS; ++it) {                              // ... then the arithmetic and the stores
+            if (ACT != ACT_NONE) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) old[ni][q] = *(const f32x4*)(drow + nw0 + ni * 32 + q * 8 + fh * 4);
-                }
+                for (int e = 0; e < 4; ++e) { v0[it][e] = act_apply(v0[it][e], ACT); v1[it][e] = act_apply(v1[it][e], ACT); }
+            }
+            if (mb + it * RPI + r_in >= p.M) continue;
+            if (EPI == EPI_STORE_T) {
+                T8 o;
 #pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni)                            // ... then the adds and stores
-                if (nw0 + ni * 32 < p.N) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *(f32x4*)(drow + nw0 + ni * 32 + q * 8 + fh * 4) = old[ni][q] + v[ni][q];
-                }
-        } else if (EPI == EPI_STORE_T) {
-            T* drow = (T*)p.out + orow * p.ldo;
-#pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni)
-                if (nw0 + ni * 32 < p.N) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        T4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (T)v[ni][q][e];
-                        *(T4*)(drow + nw0 + ni * 32 + q * 8 + fh * 4) = o;
-                    }
-                }
-        } else {
-            float* drow = (float*)p.out + orow * p.ldo;
-#pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni)
-                if (nw0 + ni * 32 < p.N) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *(f32x4*)(drow + nw0 + ni * 32 + q * 8 + fh * 4) = v[ni][q];
-                }
+                for (int e = 0; e < 4; ++e) { o[e] = (T)v0[it][e]; o[4 + e] = (T)v1[it][e]; }
+                *(T8*)((T*)p.out + orow[it] * p.ldo + nw0 + oc) = o;
+            } else {
+                float* drow = (float*)p.out + orow[it] * p.ldo + nw0 + oc;
+                if (EPI == EPI_RESID_F32) { v0[it] += old0[it]; v1[it] += old1[it]; }
+                *(f32x4*)drow = v0[it];
+                *(f32x4*)(drow + 4) = v1[it];
+            }
         }
     }
 }
 
+// write phase for v_mfma_f32_32x32x16 accumulators acc[NI][MI]: lane (fr, fh) owns row fr and the quads n = ni*32 + q*8 + fh*4
+template <typename C>
+LMI_DEV void gemm_put32(const f32x16 (&acc)[C::NI][C::MI], int mi, int lane, char* stage) {
+    constexpr int RS = GemmImage<C::WTN>::RS;
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][q * 4 + e];
+            *(f32x4*)(stage + fr * RS + (ni * 32 + q * 8 + fh * 4) * 4) = v;
+        }
+}
 template <typename T, int EPI, int ACT, int AMODE, typename C>
 __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     typedef typename vec_of<T>::x8 T8;
@@ -336,7 +343,9 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
         }
     }
 
-    gemm_epilogue<T, EPI, ACT, C>(p, acc, m0, n0, wm, wn, fr, fh);
+    raw_barrier();                                                 // every wave is done reading k-tiles: LDS is free
+    gemm_epilogue<T, EPI, ACT, C>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
+                                  smem + wave * (C::SMEM / (C::NT / 64)));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -459,7 +468,9 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
         }
     }
     if (grp == 0) raw_barrier();                                   // balance the barrier count
-    gemm_epilogue<T, EPI, ACT, C>(p, acc, m0, n0, wm, wn, fr, fh);
+    // past its last barrier a wave knows that every other wave has finished its last LOAD segment: LDS is free
+    gemm_epilogue<T, EPI, ACT, C>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
+                                  smem + wave * (C::SMEM / (C::NT / 64)));
 }
 
 }  // namespace lmi

@@ -73,6 +73,10 @@ LMI_DEV void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, vo
 
 LMI_DEV void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+// Between a wave's LDS writes and its reads of what OTHER lanes of the same wave wrote.  The hardware needs nothing (the DS
+// operations of a wave execute in order); the empty asm only stops the compiler from reordering across it.
+LMI_DEV void wave_lds_fence() { asm volatile("" ::: "memory"); }
+
 LMI_DEV u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     u32x2 r;
     unsigned addr = (unsigned)(size_t)lds_ptr;
@@ -181,6 +185,7 @@ inline int lane_id() { return threadIdx.x & 63; }
 inline int wave_id() { return (int)(threadIdx.x >> 6); }
 template <int N> inline void wait_vmcnt_barrier() { __syncthreads(); }
 inline void raw_barrier() { __syncthreads(); }
+inline void wave_lds_fence() { hipemu::wave_sync(); }
 
 template <typename V8>
 inline f32x16 emu_mfma32(V8 a, V8 b, f32x16 c) {
