@@ -27,6 +27,7 @@
 // on store).
 #pragma once
 #include "lmi_device.h"
+#include <type_traits>
 
 namespace lmi {
 
@@ -433,19 +434,28 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     if (grp == 1) raw_barrier();                                   // waves 4-7 run one barrier behind
 
     constexpr bool DMA_IN_MFMA = (VAR == 2);
-    for (int t = 0; t < nt; ++t) {
+    // 32-row blocks of this wave's tile that hold rows below M: the tail row-tile (M = 7187 leaves 19 rows of 256) skips the
+    // MFMAs and fragment reads of the blocks that are entirely padding — they would cost as much energy as useful ones, and
+    // the step runs at the package power cap.  Barriers and LDS-DMA pieces are unaffected.
+    const int rows_left = p.M - (m0 + wm * C::WTM);
+    const int nmi = rows_left >= C::WTM ? C::MI : (rows_left <= 0 ? 0 : (rows_left + 31) >> 5);
+    // ISSUE (a next k-tile exists) and FULL (no padding blocks) are compile-time: a runtime test per LDS-DMA piece or per
+    // MFMA would cut the MFMA segment into scheduling regions with a branch each
+    auto tile = [&](auto issue_tag, auto full_tag, int t) {
+        constexpr bool ISSUE = decltype(issue_tag)::value, FULL = decltype(full_tag)::value;
         const char* a_t = smem + (t & 1) * C::STAGE_BYTES;
         const char* w_t = a_t + C::A_BYTES;
-        const bool do_issue = t + 1 < nt;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             // ---- LOAD segment ---------------------------------------------------------------------------------
             T8 af[C::MI], wf[C::NI];
 #pragma unroll
-            for (int i = 0; i < C::MI; ++i) af[i] = *(const T8*)(a_t + gemm_lds_off(wm * C::WTM + i * 32 + fr, ks * 2 + fh));
+            for (int i = 0; i < C::MI; ++i)
+                if (FULL || i < nmi) af[i] = *(const T8*)(a_t + gemm_lds_off(wm * C::WTM + i * 32 + fr, ks * 2 + fh));
 #pragma unroll
-            for (int i = 0; i < C::NI; ++i) wf[i] = *(const T8*)(w_t + gemm_lds_off(wn * C::WTN + i * 32 + fr, ks * 2 + fh));
-            if (VAR < 2 && ks < 2 && do_issue) {
+            for (int i = 0; i < C::NI; ++i)
+                if (FULL || nmi > 0) wf[i] = *(const T8*)(w_t + gemm_lds_off(wn * C::WTN + i * 32 + fr, ks * 2 + fh));
+            if (VAR < 2 && ks < 2 && ISSUE) {
 #pragma unroll
                 for (int g = ks * C::G / 2; g < (ks + 1) * C::G / 2; ++g) issue_piece(g, t + 1, (t + 1) & 1);
             }
@@ -457,15 +467,22 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
             for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < C::MI; ++mi) {
-                    acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
+                    if (FULL || mi < nmi) acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
                     // the LDS-DMA pieces of tile t+1 ride in the issue slots between the MFMAs of k-steps 0, 1
                     const int idx = ni * C::MI + mi, g = ks * (C::G / 2) + (idx >> 1);    // compile-time after unrolling
-                    if (DMA_IN_MFMA && ks < 2 && (idx & 1) && (idx >> 1) < C::G / 2 && do_issue) issue_piece(g, t + 1, (t + 1) & 1);
+                    if (DMA_IN_MFMA && ISSUE && ks < 2 && (idx & 1) && (idx >> 1) < C::G / 2) issue_piece(g, t + 1, (t + 1) & 1);
                 }
             if (VAR == 0) setprio_lo();
             sched_fence();
             raw_barrier();
         }
+    };
+    if (nmi == C::MI) {
+        for (int t = 0; t + 1 < nt; ++t) tile(std::true_type{}, std::true_type{}, t);
+        tile(std::false_type{}, std::true_type{}, nt - 1);
+    } else {
+        for (int t = 0; t + 1 < nt; ++t) tile(std::true_type{}, std::false_type{}, t);
+        tile(std::false_type{}, std::false_type{}, nt - 1);
     }
     if (grp == 0) raw_barrier();                                   // balance the barrier count
     // past its last barrier a wave knows that every other wave has finished its last LOAD segment: LDS is free
