@@ -15,11 +15,11 @@
 //     c ^ ((r>>1)&7).  With 128-byte rows every 16-lane ds_read_b128 group hits 16 distinct 16-byte slots of the
 //     256-byte bank row (checked in tests/test_emu_kernels.py).
 //   * The MFMA is issued "swapped": A-operand = W rows (n), B-operand = A rows (m), so that a lane owns ONE
-//     output row m and 4 consecutive n per accumulator quad -> 8/16-byte vector epilogue stores and row-wise
-//     fused epilogues (bias, GELU, residual add into the fp32 stream, SwiGLU on interleaved gate/up blocks,
-//     position-table add, row scatter).
+//     output row m and 4 consecutive n per accumulator quad; the fused epilogue (bias, GELU, residual add into the
+//     fp32 stream, SwiGLU on interleaved gate/up blocks, position-table add, row scatter) turns each wave's tile
+//     through the idle LDS so that every store instruction covers whole row segments (gemm_epilogue).
 //   * blockIdx -> tile map is XCD-aware: the 8 XCDs each get a contiguous slab of the tile space, walked in
-//     groups of GROUP_M row-tiles so that a slab's A/W panels stay in that XCD's private 4 MiB L2.
+//     groups of GROUP_M row-tiles so that the k-tiles a slab is working on stay in that XCD's private 4 MiB L2.
 // Why big tiles: at full MFMA rate a 128x128 tile needs 64 B/clk/CU of L2->LDS traffic — the whole per-CU vector
 // memory path; 256x256 halves it.
 // Requirements (met by weight preparation, leopard_amd/weights.py): N % 128 == 0, K % 64 == 0, 16-byte aligned
@@ -222,6 +222,68 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
     }
 }
 
+// ---- operand staging shared by both schedules -----------------------------------------------------------------
+// Per-thread LDS-DMA sources: one 128-byte row per pass (8 lanes per row), the 16-byte chunk position fixed per thread
+// and swizzled on the source side; loop-invariant 32-bit lane offsets, the k-tile advances a scalar offset.  Tail rows
+// are clamped to the last valid row (their products are masked on store).  In pixel-shuffle mode logical A row m is the
+// 2x2 neighbourhood of ViT tokens of shuffled token m, its K axis the four (dh, dw) segments of C channels.
+template <int AMODE, typename C>
+struct GemmStager {
+    BufRsrc a_buf, w_buf;
+    unsigned a_src[C::A_PASSES], w_src[C::W_PASSES];
+    int ps_c, ps_grid, lda;
+    char* wave_base;
+
+    LMI_DEV void init(const GemmArgs& p, int m0, int n0, int tid, char* smem, int wave) {
+        a_buf = make_buf(p.A, p.a_bytes);
+        w_buf = make_buf(p.W, p.w_bytes);
+        const int srow = tid >> 3;                       // physical row inside a pass
+        const int pc = tid & 7;                          // physical 16-byte chunk inside the 128-byte row
+#pragma unroll
+        for (int ps = 0; ps < C::A_PASSES; ++ps) {
+            const int r = ps * C::ROWS_PER_PASS + srow;
+            const int lc = pc ^ ((r >> 1) & 7);
+            const int am = imin(m0 + r, p.M - 1);
+            long arow;
+            if (AMODE == AMODE_PIXSHUF) {
+                const int g = p.ps_grid, h = g >> 1, per = h * h;
+                const int tile = am / per, pp = am - tile * per;
+                const int ph = pp / h, pw = pp - ph * h;
+                arow = (long)tile * g * g + (long)(2 * ph) * g + 2 * pw;
+            } else {
+                arow = am;
+            }
+            a_src[ps] = (unsigned)((arow * p.lda + lc * 8) * 2);
+        }
+#pragma unroll
+        for (int ps = 0; ps < C::W_PASSES; ++ps) {
+            const int r = ps * C::ROWS_PER_PASS + srow;
+            const int lc = pc ^ ((r >> 1) & 7);
+            w_src[ps] = (unsigned)(((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2);
+        }
+        ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;    // channels per shuffle segment
+        ps_grid = p.ps_grid;
+        lda = p.lda;
+        wave_base = smem + wave * 1024;
+    }
+    // one LDS-DMA instruction: piece g (0..G-1) of k-tile kt into ring slot `slot`
+    LMI_DEV void issue(int g, int kt, int slot) const {
+        char* base = wave_base + slot * C::STAGE_BYTES;
+        if (g < C::A_PASSES) {
+            unsigned a_off = (unsigned)kt * (GEMM_BK * 2);
+            if (AMODE == AMODE_PIXSHUF) {
+                const int k0 = kt * GEMM_BK;
+                const int seg = k0 / ps_c;                           // 0..3 = (dh, dw)
+                a_off = (unsigned)((((seg >> 1) * ps_grid + (seg & 1)) * lda + (k0 - seg * ps_c)) * 2);
+            }
+            glds16_buf(a_buf, a_src[g], a_off, base + g * (C::ROWS_PER_PASS * 128));
+        } else {
+            const int gw = g - C::A_PASSES;
+            glds16_buf(w_buf, w_src[gw], (unsigned)kt * (GEMM_BK * 2), base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
+        }
+    }
+};
+
 // write phase for v_mfma_f32_32x32x16 accumulators acc[NI][MI]: lane (fr, fh) owns row fr and the quads n = ni*32 + q*8 + fh*4
 template <typename C>
 LMI_DEV void gemm_put32(const f32x16 (&acc)[C::NI][C::MI], int mi, int lane, char* stage) {
@@ -250,52 +312,9 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     if (!gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn)) return;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
-    // ---- per-thread staging sources: one row per pass; the 16-byte chunk position is fixed per thread ----------
-    const int srow = tid >> 3;                       // physical row inside a pass
-    const int pc = tid & 7;                          // physical 16-byte chunk inside the 128-byte row
-    // LDS-DMA through buffer resources: loop-invariant 32-bit lane offsets, the k-tile advances a scalar offset
-    const BufRsrc a_buf = make_buf(p.A, p.a_bytes), w_buf = make_buf(p.W, p.w_bytes);
-    unsigned a_src[C::A_PASSES], w_src[C::W_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < C::A_PASSES; ++ps) {
-        const int r = ps * C::ROWS_PER_PASS + srow;
-        const int lc = pc ^ ((r >> 1) & 7);
-        const int am = imin(m0 + r, p.M - 1);
-        long arow;
-        if (AMODE == AMODE_PIXSHUF) {
-            const int g = p.ps_grid, h = g >> 1, per = h * h;
-            const int tile = am / per, pp = am - tile * per;
-            const int ph = pp / h, pw = pp - ph * h;
-            arow = (long)tile * g * g + (long)(2 * ph) * g + 2 * pw;
-        } else {
-            arow = am;
-        }
-        a_src[ps] = (unsigned)((arow * p.lda + lc * 8) * 2);
-    }
-#pragma unroll
-    for (int ps = 0; ps < C::W_PASSES; ++ps) {
-        const int r = ps * C::ROWS_PER_PASS + srow;
-        const int lc = pc ^ ((r >> 1) & 7);
-        w_src[ps] = (unsigned)(((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2);
-    }
-    const int ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;     // channels per shuffle segment
-
-    // one LDS-DMA instruction: piece g (0..G-1) of k-tile kt into ring slot `slot`
-    auto issue_piece = [&](int g, int kt, int slot) {
-        char* base = smem + slot * C::STAGE_BYTES + wave * 1024;
-        if (g < C::A_PASSES) {
-            unsigned a_off = (unsigned)kt * (GEMM_BK * 2);
-            if (AMODE == AMODE_PIXSHUF) {
-                const int k0 = kt * GEMM_BK;
-                const int seg = k0 / ps_c;                           // 0..3 = (dh, dw)
-                a_off = (unsigned)((((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2);
-            }
-            glds16_buf(a_buf, a_src[g], a_off, base + g * (C::ROWS_PER_PASS * 128));
-        } else {
-            const int gw = g - C::A_PASSES;
-            glds16_buf(w_buf, w_src[gw], (unsigned)kt * (GEMM_BK * 2), base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
-        }
-    };
+    GemmStager<AMODE, C> stager;
+    stager.init(p, m0, n0, tid, smem, wave);
+    auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
 
     f32x16 acc[C::NI][C::MI];
 #pragma unroll
@@ -375,48 +394,9 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     if (!gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn)) return;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
-    const int srow = tid >> 3, pc = tid & 7;
-    // LDS-DMA through buffer resources: loop-invariant 32-bit lane offsets, the k-tile advances a scalar offset
-    const BufRsrc a_buf = make_buf(p.A, p.a_bytes), w_buf = make_buf(p.W, p.w_bytes);
-    unsigned a_src[C::A_PASSES], w_src[C::W_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < C::A_PASSES; ++ps) {
-        const int r = ps * C::ROWS_PER_PASS + srow;
-        const int lc = pc ^ ((r >> 1) & 7);
-        const int am = imin(m0 + r, p.M - 1);
-        long arow;
-        if (AMODE == AMODE_PIXSHUF) {
-            const int g = p.ps_grid, h = g >> 1, per = h * h;
-            const int tile = am / per, pp = am - tile * per;
-            const int ph = pp / h, pw = pp - ph * h;
-            arow = (long)tile * g * g + (long)(2 * ph) * g + 2 * pw;
-        } else {
-            arow = am;
-        }
-        a_src[ps] = (unsigned)((arow * p.lda + lc * 8) * 2);
-    }
-#pragma unroll
-    for (int ps = 0; ps < C::W_PASSES; ++ps) {
-        const int r = ps * C::ROWS_PER_PASS + srow;
-        const int lc = pc ^ ((r >> 1) & 7);
-        w_src[ps] = (unsigned)(((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2);
-    }
-    const int ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;
-    auto issue_piece = [&](int g, int kt, int slot) {
-        char* base = smem + slot * C::STAGE_BYTES + wave * 1024;
-        if (g < C::A_PASSES) {
-            unsigned a_off = (unsigned)kt * (GEMM_BK * 2);
-            if (AMODE == AMODE_PIXSHUF) {
-                const int k0 = kt * GEMM_BK;
-                const int seg = k0 / ps_c;
-                a_off = (unsigned)((((seg >> 1) * p.ps_grid + (seg & 1)) * p.lda + (k0 - seg * ps_c)) * 2);
-            }
-            glds16_buf(a_buf, a_src[g], a_off, base + g * (C::ROWS_PER_PASS * 128));
-        } else {
-            const int gw = g - C::A_PASSES;
-            glds16_buf(w_buf, w_src[gw], (unsigned)kt * (GEMM_BK * 2), base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
-        }
-    };
+    GemmStager<AMODE, C> stager;
+    stager.init(p, m0, n0, tid, smem, wave);
+    auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
 
     f32x16 acc[C::NI][C::MI];
 #pragma unroll
