@@ -291,7 +291,21 @@ template <int D> struct AttnDmaGeom {
     static constexpr int SMEM = 4 * TILE_BYTES + 64;          // 2 slots x (K + V) (+ slack read by padded columns)
     static constexpr bool SWZ = (D == 128);                   // XOR swizzles need power-of-two rows; 144-byte rows
                                                               // (9 chunks, odd) are conflict-free for b128 as they are
+    static constexpr bool VPERM = (D == 72);                  // ... but not for the transposed V reads: see att_vpos72
 };
+// d = 72: a ds_read_b64_tr_b16 lane group takes the four 16-byte chunks of one 32-wide d-block from four consecutive key
+// rows; with 144-byte rows those 16 chunks fall on only 12 of the 16 chunk slots of the 256-byte bank row (PMC: 35 % of the
+// kernel's LDS cycles were conflict cycles).  The V image therefore stores chunk c of key row r at position
+// att_vpos72(r & 3, c) of the row (a free permutation: LDS-DMA lanes pick their source chunk): for each d-block the four
+// rows' chunks then cover all 16 slots exactly once, and the rows' chunk 8 (d 64..71) land on four different slots.
+LMI_DEV int att_vpos72(int r4, int c) {
+    constexpr unsigned long long POS[4] = {0x087654321ull, 0x876543210ull, 0x087216543ull, 0x876105432ull};   // nibble c = position
+    return (int)((POS[r4] >> (4 * c)) & 15);
+}
+LMI_DEV int att_vchunk72(int r4, int pos) {                    // inverse: which chunk sits at `pos`
+    constexpr unsigned long long INV[4] = {0x765432108ull, 0x876543210ull, 0x763210548ull, 0x876321054ull};
+    return (int)((INV[r4] >> (4 * pos)) & 15);
+}
 
 template <typename T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p) {
@@ -359,7 +373,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         const int ci = (wave + NW * i) * 64 + lane;
         const int r = ci / G::CH, c = ci - r * G::CH;
         p_ko[i] = (unsigned)(r * p.ldk + ((G::SWZ ? (c ^ (r & 15)) : c) << 3)) * 2u;
-        p_vo[i] = (unsigned)(r * p.ldv + ((G::SWZ ? (c ^ ((r & 3) << 2)) : c) << 3)) * 2u;
+        const int cv = G::VPERM ? att_vchunk72(r & 3, c) : (G::SWZ ? (c ^ ((r & 3) << 2)) : c);
+        p_vo[i] = (unsigned)(r * p.ldv + (cv << 3)) * 2u;
     }
     // piece j of this wave for tile t: j < PPW are its K pieces, the rest its V pieces
     auto issue_piece = [&](int j, int t, int slot) {
@@ -395,8 +410,15 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     const int tr_j = (lane & 15) >> 2, tr_g = lane & 3, tr_half = (lane >> 4) & 1;
     int v_off[NDB];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
-        v_off[db] = (4 * fh + tr_j) * G::ROWB + ((G::SWZ ? (db ^ tr_j) : db) << 6) + tr_half * 32 + tr_g * 8;
+    for (int db = 0; db < NDB; ++db) {
+        if (G::VPERM) {
+            // lanes past the last real chunk (d >= 72) repeat chunk 8's address: identical addresses broadcast
+            const int c = imin(db * 4 + tr_half * 2 + (tr_g >> 1), G::CH - 1);
+            v_off[db] = (4 * fh + tr_j) * G::ROWB + att_vpos72(tr_j, c) * 16 + (tr_g & 1) * 8;
+        } else {
+            v_off[db] = (4 * fh + tr_j) * G::ROWB + ((G::SWZ ? (db ^ tr_j) : db) << 6) + tr_half * 32 + tr_g * 8;
+        }
+    }
 
     if (t_begin < t_end) issue_tile(t_begin, 0);
     int t = t_begin;
