@@ -143,7 +143,12 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
     if (nw0 >= p.N) return;                                             // N % 128 == 0 and WTN | 128: all or nothing
     constexpr int OUT_COLS = (EPI == EPI_SWIGLU_T) ? C::WTN / 2 : C::WTN;
     constexpr int LPR = OUT_COLS / 8, RPI = 64 / LPR, ITERS = 32 / RPI; // lanes per row, rows per instruction
-    const int oc = (lane % LPR) * 8, r_in = lane / LPR;
+    const int r_in = lane / LPR;
+    // 8 lanes per 64-column row (every production geometry, plain epilogues): rotating the lanes' column groups by one on
+    // rows 2, 3, 6, 7 of an instruction makes each of ds_read_b128's four lane groups hit 16 distinct 16-byte slots (with
+    // lane -> column fixed, rows two apart share slots: 2-way conflicts, 4.5 % of the ring kernels' LDS cycles by PMC).
+    // A row is still covered by 8 consecutive lanes, so stores stay whole 128/256-byte row segments.
+    const int oc = ((LPR == 8 && EPI != EPI_SWIGLU_T) ? ((lane + 7 * ((r_in >> 1) & 1)) & 7) : (lane % LPR)) * 8;
     // source columns of this lane in the image: plain = oc..oc+7; SwiGLU = gate block, up block 32 columns further
     const int sc = (EPI == EPI_SWIGLU_T) ? (oc >> 5) * 64 + (oc & 31) : oc;
     f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
