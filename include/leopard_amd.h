@@ -43,8 +43,14 @@ enum { LMI_A_PLAIN = 0, LMI_A_PIXEL_SHUFFLE = 1 };
 const char* lmi_last_error(void);
 int lmi_abi_version(void);
 
-/* Tuning knobs (process-global).  "gemm.config": -1 = choose the GEMM tile geometry per shape (default),
- * 0..4 = force one of the geometries listed in csrc/capi.hip (used by tools/bench_kernels.py for A/B runs). */
+/* Tuning knobs (process-global; experiments and A/B runs only, the defaults are the measured best):
+ *   "gemm.config"   -1 = choose the GEMM geometry / schedule per shape (default); 0..9 = force one of those listed in
+ *                   csrc/capi.hip (tools/bench_kernels.py)
+ *   "gemm.group_m"  row-tiles per group of the XCD-aware tile order (default 4)
+ *   "gemm.order"    0 = each XCD owns a contiguous slab of the tile order (default), 1 = round-robin 32-tile patches
+ *   "attn.dma"      1 = LDS-DMA attention kernel (default), 0 = register-staged cross-check kernel
+ *   "attn.lds_pad"  extra dynamic LDS per attention workgroup in bytes (lowers residency; default 0)
+ * Unknown keys and out-of-range values return LMI_EINVAL. */
 int lmi_set_option(const char* key, int value);
 
 /* Deterministic synthetic parameters (no checkpoints exist offline): element i = f(seed, i, kind); bit-identical
