@@ -62,7 +62,7 @@ typedef GemmCfg<256, 128, 4, 2, 2> Cfg3;   //  96 KiB LDS
 typedef GemmCfg<128, 256, 2, 4, 3> Cfg4;   // 144 KiB LDS, wave tile 64x64, 3-slot ring
 typedef GemmCfg<64, 128, 2, 2, 3> CfgS;    //  72 KiB LDS, 256 threads, wave tile 32x64: small-M problems
 typedef GemmCfg<64, 128, 2, 2, 6> CfgS6;   // 144 KiB LDS: 5 k-tiles in flight for latency-bound weight streaming at small M
-constexpr int kNumGemmCfg = 10;             // 0-4 ring geometries; 5-7 staggered 256x256 schedules
+constexpr int kNumGemmCfg = 10;             // 0-4 ring geometries; 5-7 staggered 256x256 schedules; 8-9 small-M rings
 int g_gemm_cfg = -1;                        // -1 = choose per shape
 int g_gemm_group_m = GEMM_GROUP_M;
 int g_gemm_order = 0;
@@ -87,7 +87,7 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
     return check_launch("lmi_gemm");
 }
 
-// Geometry per shape, from tools/bench_kernels.py on MI355X (profiles/r01_gemm_geometries.md): wide outputs take the
+// Geometry per shape, from tools/bench_kernels.py on MI355X (profiles/README.md, r01_gemm_micro_final.txt): wide outputs take the
 // staggered 256x256 schedule; narrow-N / deep-K (SigLIP fc2) the 256x128 3-slot ring; small problems 128x128.
 int choose_gemm_cfg(const GemmArgs& a) {
     if (g_gemm_cfg >= 0) return g_gemm_cfg;
