@@ -336,6 +336,43 @@ def test_gemm_lds_swizzle_is_conflict_free():
                 assert len(slots) == 16
 
 
+def test_attention_d72_v_image_is_conflict_free():
+    """attention.h att_vpos72: ds_read_b64_tr_b16 serves the two 32-lane halves of a wave in one LDS cycle each when the 32
+    eight-byte pieces cover the 256-byte bank row exactly.  A half reads, for one 32-wide d-block, the four 16-byte chunks of
+    four consecutive key rows (144-byte rows at d = 72); with the per-row chunk permutation those 16 chunks must hit 16
+    distinct slots, and the rows' last chunk (d 64..71, shared by the padded lanes through broadcast) four distinct ones."""
+    pos = [[(p >> (4 * c)) & 15 for c in range(9)] for p in (0x087654321, 0x876543210, 0x087216543, 0x876105432)]
+    inv = [[(p >> (4 * q)) & 15 for q in range(9)] for p in (0x765432108, 0x876543210, 0x763210548, 0x876321054)]
+    for r4 in range(4):
+        assert sorted(pos[r4]) == list(range(9)) and all(inv[r4][pos[r4][c]] == c for c in range(9))
+    for r0 in range(0, 64, 4):                       # every 4-row group of a 64-key tile
+        for db in range(3):
+            slots = [((r0 + j) * 144 + pos[j][min(c, 8)] * 16) // 16 % 16 for j in range(4) for c in range(4 * db, 4 * db + 4)]
+            assert len(set(slots)) == (16 if db < 2 else 4)
+
+
+def test_gemm_epilogue_image_reads_are_conflict_free():
+    """gemm.h gemm_epilogue, plain epilogues at 64-column wave tiles: lane l reads two 16-byte pieces of row l/8 of the fp32
+    image (row stride 272 bytes) at column group ((l + 7*((l/8 >> 1) & 1)) & 7); each ds_read_b128 lane group must hit 16
+    distinct 16-byte slots (without the rotation rows two apart collide)."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    RS = 64 * 4 + 16
+    for it in range(4):                              # 8 rows per instruction, 32 rows per image
+        for half in (0, 16):
+            for g in groups:
+                slots = set()
+                for lane in g:
+                    r_in = lane // 8
+                    oc = ((lane + 7 * ((r_in >> 1) & 1)) & 7) * 8
+                    slots.add(((it * 8 + r_in) * RS + oc * 4 + half) % 256 // 16)
+                assert len(slots) == 16
+    # write side: ds_write_b128 is served in contiguous 8-lane groups over 32 banks: rows fr..fr+7 at one column
+    for fr0 in range(0, 32, 8):
+        assert len({((fr0 + i) * RS) % 128 // 16 for i in range(8)}) == 8
+
+
 def test_attention_sliding_window(ops):
     """Mistral window: query i sees keys j with i - j < window (bottom-right aligned)."""
     H, KV, D, S, Wn = 2, 1, 128, 150, 40
