@@ -46,6 +46,8 @@ int lmi_abi_version(void);
 /* Tuning knobs (process-global; experiments and A/B runs only, the defaults are the measured best):
  *   "gemm.config"   -1 = choose the GEMM geometry / schedule per shape (default); 0..9 = force one of those listed in
  *                   csrc/capi.hip (tools/bench_kernels.py)
+ *   "gemm.wide" / "gemm.short_k" / "gemm.narrow_n" / "gemm.small"   geometry 0..7 per shape class (csrc/capi.hip
+ *                   choose_gemm_cfg: N >= 2048 with K > 1536 / K <= 1536; N < 2048 with K >= 2048 / K < 2048)
  *   "gemm.group_m"  row-tiles per group of the XCD-aware tile order (default 4)
  *   "gemm.order"    0 = each XCD owns a contiguous slab of the tile order (default), 1 = round-robin 32-tile patches
  *   "attn.dma"      1 = LDS-DMA attention kernel (default), 0 = register-staged cross-check kernel

@@ -66,6 +66,12 @@ constexpr int kNumGemmCfg = 10;             // 0-4 ring geometries; 5-7 staggere
 int g_gemm_cfg = -1;                        // -1 = choose per shape
 int g_gemm_group_m = GEMM_GROUP_M;
 int g_gemm_order = 0;
+// per-shape-class geometry (end-to-end A/B knobs; defaults = best measured on the C3 prefill, which runs at the power cap
+// and does not always agree with isolated bursts of one GEMM)
+int g_gemm_wide = 5;                        // N >= 2048, K > 1536 (Llama projections)
+int g_gemm_short = 5;                       // N >= 2048, K <= 1536 (SigLIP qkv, fc1)
+int g_gemm_narrow = 2;                      // N < 2048, K >= 2048 (SigLIP fc2)
+int g_gemm_small = 0;                       // N < 2048, K < 2048 (SigLIP out_proj, patch embedding)
 
 template <typename T, int EPI, int ACT, int AMODE, typename C>
 int launch_gemm_cfg(const GemmArgs& a, void* stream) {
@@ -87,14 +93,13 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
     return check_launch("lmi_gemm");
 }
 
-// Geometry per shape, from tools/bench_kernels.py on MI355X (profiles/README.md, r01_gemm_micro_final.txt): wide outputs take the
+// Geometry per shape class, from end-to-end A/B runs of the C3 prefill (`bench.py --opt`, profiles/README.md): N >= 2048 takes the
 // staggered 256x256 schedule; narrow-N / deep-K (SigLIP fc2) the 256x128 3-slot ring; small problems 128x128.
 int choose_gemm_cfg(const GemmArgs& a) {
     if (g_gemm_cfg >= 0) return g_gemm_cfg;
     if (a.M < 512) return 8;
-    if (a.N >= 2048) return a.K <= 1536 ? 2 : 7;   // short K (SigLIP qkv / fc1): the 3-slot ring's shorter prologue wins
-    if (a.K >= 2048) return 2;
-    return 0;
+    if (a.N >= 2048) return a.K <= 1536 ? g_gemm_short : g_gemm_wide;
+    return a.K >= 2048 ? g_gemm_narrow : g_gemm_small;
 }
 
 template <typename T, int EPI, int ACT, int AMODE>
@@ -104,9 +109,9 @@ int launch_gemm(const GemmArgs& a, void* stream) {
         case 2: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg2>(a, stream);
         case 3: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg3>(a, stream);
         case 4: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg4>(a, stream);
-        case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 0>(a, stream);   // setprio, DMA in LOAD segments
+        case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 0>(a, stream);   // setprio, DMA in LOAD segments (production)
         case 6: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 1>(a, stream);   // DMA in LOAD segments
-        case 7: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 2>(a, stream);   // DMA between MFMAs (production)
+        case 7: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 2>(a, stream);   // DMA between MFMAs (fastest in isolated bursts, 2.4 % slower end to end)
         case 8: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgS>(a, stream);
         case 9: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgS6>(a, stream);
         default: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg0>(a, stream);
@@ -315,6 +320,16 @@ int lmi_set_option(const char* key, int value) {
         return LMI_OK;
     }
     if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
+    {
+        struct { const char* key; int* var; } classes[] = {{"gemm.wide", &g_gemm_wide}, {"gemm.short_k", &g_gemm_short},
+                                                          {"gemm.narrow_n", &g_gemm_narrow}, {"gemm.small", &g_gemm_small}};
+        for (auto& c : classes)
+            if (!strcmp(key, c.key)) {
+                if (value < 0 || value > 7) return fail(LMI_EINVAL, "lmi_set_option: %s in [0, 7]", key);
+                *c.var = value;
+                return LMI_OK;
+            }
+    }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.lds_pad")) { g_attn_lds_pad = value < 0 ? 0 : (value > 90 * 1024 ? 90 * 1024 : value); return LMI_OK; }
     return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);

@@ -384,6 +384,8 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 // k-steps 0 and 1 of tile t (the slot's previous tenant, tile t-1, was last read one full segment earlier by the
 // lagging group) and every wave drains its own pieces (vmcnt(0)) before the barrier that closes its k-step-3 LOAD
 // segment, which precedes the first read of tile t+1 by either group.
+// VAR 0 = as described (production); 1 = without s_setprio; 2 = the LDS-DMA pieces ride between the MFMAs of k-steps 0 / 1
+// instead (1-2 % faster in isolated bursts of one GEMM, 2.4 % slower over the power-capped prefill step).
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR>
 __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+run() { python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'], d['roofline']['achieved'])"; }
+run
+run --opt gemm.wide=6 --opt gemm.short_k=6
+run --opt gemm.order=1
+run --opt gemm.group_m=8
+run --opt gemm.group_m=6
+run

@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+run() { python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'], d['roofline']['achieved'])"; }
+run
+run --opt gemm.short_k=5
+run --opt gemm.short_k=0
+run --opt gemm.narrow_n=5
+run --opt gemm.narrow_n=0
+run --opt gemm.small=2
+run
