@@ -96,10 +96,44 @@ class GemmTimer:
         return flops, ms, len(self.records)
 
 
-def cpu_baseline(cfg):
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: stamps PMC summaries so that a stale one is refused (tools/collect_traffic.sh)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "leopard_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_c1(cfg, ops, dev):
+    """the CPU oracle's END-TO-END prefill of config C1 (1 x 336x336 image + 32-token question, S = 228,
+    27 SigLIP + 32 Llama-3.1-8B layers, fp32, same synthetic parameters) on the host cores: 1 warm-up (the bounded sample of
+    cpu_baseline_sample below) + 3 timed runs, median.  Returns (seconds, algorithmic TFLOP of C1)."""
+    from PIL import Image
+    from leopard_amd.tiler import siglip_normalize, tile_sample, to_u8_tiles
+    from leopard_amd.weights import SynthSource
+    from oracle import leopard_oracle as O
+    src = SynthSource(cfg, ops, dev, torch.float16)      # lmi_fill_synthetic == the numpy generator, bit for bit (tests)
+    Wt = {name: src.get(name).float().cpu() for name in src.specs}
+    vit_inputs, plan = tile_sample([Image.fromarray(synth_image_u8(0, 336, 336))])
+    u8 = to_u8_tiles(vit_inputs)
+    ids = torch.from_numpy(synth_prompt_ids(plan.vit_inputs_per_image, cfg, seed=0)).reshape(1, -1)
+    pix = torch.from_numpy(siglip_normalize(u8))
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        logits = O.prefill_logits(ids, pix, Wt, cfg, last_only=True)
+        times.append(time.perf_counter() - t0)
+    assert torch.isfinite(logits).all()
+    S = ids.shape[1] + u8.shape[0] * (cfg.tokens_per_tile - 1)
+    return sorted(times)[1], algorithmic_flops(cfg, u8.shape[0], S)["total"] / 1e12, S
+
+
+def cpu_baseline_sample(cfg):
     """The CPU oracle (fp32 PyTorch restatement of the reference path) timed on the host cores on a bounded sample
-    of the same workload: 2 SigLIP layers on 2 tiles + 1 Llama layer at S=1024, converted to images/s of the C3
-    workload through the algorithmic FLOP count."""
+    of the C3 workload: 2 SigLIP layers on 2 tiles + 1 Llama layer at S=1024, converted to images/s of the C3
+    workload through the algorithmic FLOP count (C3 itself would take ~7 minutes per sample on the host)."""
     from leopard_amd.synth import param_specs, synth_array
     from oracle import leopard_oracle as O
     specs = {n: (s, k) for n, s, k in param_specs(cfg)}
@@ -314,7 +348,10 @@ def main():
         gpu_tiler.tile_sample(raw)                                 # warm (tap tables, allocator)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        c.tiles, _ = gpu_tiler.tile_sample(raw)                    # the tiler on the GPU; resident before the timed region
+        c.raw = [torch.from_numpy(np.ascontiguousarray(r)).to(dev) for r in raw]   # source pixels resident in HBM before the timed region
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        c.tiles, _ = gpu_tiler.tile_sample(c.raw)                  # the tiler on the GPU (a3-a5), from resident source pixels
         torch.cuda.synchronize()
         gpu_tiler_s = max(gpu_tiler_s, time.perf_counter() - t1)
         if not torch.equal(c.tiles.cpu(), torch.from_numpy(u8)):   # same pixels as the host (PIL) tiler, bit for bit
@@ -327,15 +364,18 @@ def main():
         ctxs.append(c)
     n_tiles, S = ctxs[0].n_tiles, ctxs[0].S
 
-    def step():
+    def step(with_tiler=True):
+        """One pass of the hot path over one sample: tiler (a1-a5, on the GPU, from the resident source pixels) -> SigLIP ->
+        projector -> merge -> Llama prefill -> last-position logits ("tiler -> logits of last position")."""
         out = None
         for c in ctxs:
             with torch.cuda.stream(c.stream):
                 c.cache.length = 0
+                tiles = gpu_tiler.tile_sample(c.raw)[0] if with_tiler else c.tiles
                 if tp:       # every rank encodes its slice of the ViT inputs, one all-gather, then the tensor-parallel LLM
-                    out = eng.prefill(c.ids, None, cache=c.cache, visual_tokens=D.encode_images_sharded(eng, c.tiles))
+                    out = eng.prefill(c.ids, None, cache=c.cache, visual_tokens=D.encode_images_sharded(eng, tiles))
                 else:
-                    out = eng.prefill(c.ids, c.tiles, cache=c.cache)
+                    out = eng.prefill(c.ids, tiles, cache=c.cache)
         return out
 
     def barrier():
@@ -354,6 +394,14 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev)
     assert res.seq_len == S and torch.isfinite(res.logits_last).all()
     ms_per_step = elapsed / args.steps * 1e3
+    # the same step from ready-made tiles (what round 1 timed): the tiler's share of the headline
+    n_ex = max(2, min(args.steps, 5))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_ex):
+        step(with_tiler=False)
+    barrier()
+    ms_excl_tiler = D.max_over_ranks(time.perf_counter() - t0, dev) / n_ex * 1e3
     images_per_s = (1 if tp else world) * args.inflight * args.images * args.steps / elapsed
     fl = algorithmic_flops(cfg, n_tiles, S)
 
@@ -370,6 +418,8 @@ def main():
         "visual_tokens_per_s": round((1 if tp else world) * args.inflight * n_tiles * cfg.tokens_per_tile * args.steps / elapsed, 1),
         "algorithmic_tflop_per_step": round(args.inflight * fl["total"] / 1e12, 2),
         "prefill_mfma_frac": round(args.inflight * fl["total"] / 1e12 / (elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4),
+        "timed_region": "tiler (GPU, from source pixels resident in HBM) -> ViT -> projector -> merge -> LLM prefill -> last-token logits",
+        "ms_per_step_excl_tiler": round(ms_excl_tiler, 3),
         "host_tiler_ms_per_sample": round(host_tiler_s * 1e3, 1), "gpu_tiler_ms_per_sample": round(gpu_tiler_s * 1e3, 2),
         "weight_load_s": round(load_s, 1),
     }
@@ -387,25 +437,38 @@ def main():
         per_launch_flops = gflops / n
         avg_ms = gms / n
         achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12
-        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (tools/hbm_traffic.py); the committed summary of
-        # the same command is reported here, null if it is absent
-        traffic, traffic_note = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_hbm_traffic.json")
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes over this very command (tools/collect_traffic.sh ->
+        # tools/hbm_traffic.py).  The committed summary is stamped with the hash of the kernel sources it was measured on and is
+        # reported only when that hash matches the sources in this tree: a stale summary is refused (traffic = null).
+        traffic, traffic_note = None, "no PMC summary for these kernel sources (run tools/collect_traffic.sh on the GPU box)"
+        tpath = os.path.join(REPO, "profiles", "gemm_hbm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            traffic, traffic_note = round(tj["hbm_bytes_per_launch"]), "profiles/r01_gemm_hbm_traffic.json: " + tj["method"]
+            if tj.get("kernel_source_hash") == kernel_source_hash():
+                traffic, traffic_note = round(tj["hbm_bytes_per_launch"]), "profiles/gemm_hbm_traffic.json: " + tj["method"]
+            else:
+                traffic_note = f"profiles/gemm_hbm_traffic.json is stale (measured on kernel sources {tj.get('kernel_source_hash')}); refused"
         out["roofline"] = {"bound": "mfma", "kernel": "lmi::gemm_kernel (all epilogues)", "achieved": round(achieved, 1),
                            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": traffic_note,
                            "algorithmic_bytes_per_launch": round(timer.bytes / n),
+                           "kernel_source_hash": kernel_source_hash(),
                            "launches_per_step": n // min(args.steps, 2),
                            "avg_launch_ms": round(avg_ms, 4), "gemm_ms_per_step": round(gms / min(args.steps, 2), 2)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        tflops, t = cpu_baseline(cfg)
-        out["cpu_baseline"] = {"value": round(args.images / (fl["total"] / 1e12 / tflops), 5), "unit": "images/s",
-                               "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"CPU oracle (fp32 PyTorch): 2 SigLIP layers x 2 tiles + 1 Llama layer at S=1024 "
-                                         f"({t:.2f} s, {tflops:.3f} TFLOP/s), scaled to the C3 sample by algorithmic FLOPs"}
+        tflops, t = cpu_baseline_sample(cfg)                   # doubles as the warm-up of the timed C1 runs
+        del eng, W, ctxs
+        torch.cuda.empty_cache()
+        c1_s, c1_tf, c1_S = cpu_baseline_c1(cfg, ops, dev)
+        out["cpu_baseline"] = {
+            "value": round(1.0 / c1_s, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"CPU oracle (fp32 PyTorch restatement of the reference path, oracle/leopard_oracle.py) END-TO-END prefill of "
+                      f"config C1 (1 x 336x336 image, S = {c1_S}, 27 + 32 layers, {c1_tf:.2f} TFLOP): median of 3 runs after 1 warm-up "
+                      f"= {c1_s:.2f} s = {c1_tf / c1_s:.3f} TFLOP/s on {torch.get_num_threads()} host threads",
+            "seconds_c1": round(c1_s, 3), "tflops_c1": round(c1_tf / c1_s, 4),
+            "c3_extrapolated": {"value": round(args.images / (fl["total"] / 1e12 / tflops), 5), "unit": "images/s",
+                                "sample": f"2 SigLIP layers x 2 tiles + 1 Llama layer at S=1024 ({t:.2f} s, {tflops:.3f} TFLOP/s), "
+                                          "scaled to the C3 sample (140.1 TFLOP) by algorithmic FLOPs"}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

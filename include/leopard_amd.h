@@ -10,7 +10,9 @@
  * Conventions
  *   - raw device pointers + explicit sizes / leading dimensions (in ELEMENTS) + dtype enum + hipStream_t
  *     (passed as void*); no torch types.  All pointers must be 16-byte aligned, leading dimensions multiples of 8.
- *   - stream-ordered, no implicit synchronisation, no allocation: the caller owns every buffer.
+ *   - stream-ordered, no implicit synchronisation, no allocation: the caller owns every buffer.  Entry points may be called
+ *     concurrently from several host threads (one stream / device each); the only process-global state is lmi_set_option's
+ *     experiment knobs, which are not meant to be changed while launches are in flight.
  *   - returns 0 on success, a negative LMI_E* code otherwise; lmi_last_error() gives a thread-local message.
  *   - "T" below is the 16-bit compute type selected by `dtype` (LMI_F16 or LMI_BF16); accumulation, softmax
  *     statistics, normalisation statistics and the residual stream are fp32.
@@ -27,6 +29,7 @@ extern "C" {
 #define LMI_OK 0
 #define LMI_EINVAL (-1)   /* bad argument (shape / alignment / enum) */
 #define LMI_ELAUNCH (-2)  /* HIP launch error */
+#define LMI_ECOMM (-3)    /* RCCL unavailable or a collective failed */
 
 enum { LMI_F16 = 0, LMI_BF16 = 1, LMI_F32 = 2 };
 
@@ -84,7 +87,8 @@ int lmi_preprocess_images(const void* in, int from_u8, void* out, int n_images, 
 
 /* LayerNorm (SigLIP layer_norm1/2, post_layernorm; analogue idefics_vision_tower.py:77-81,176) and
  * RMSNorm (Llama input/post_attention/final norm; megatron/legacy/model/rms_norm.py:26-31):
- * x fp32 [M, ldx] -> out T [M, ldo]; w, b fp32 [D]. */
+ * x fp32 [M, ldx] -> out T [M, ldo]; w, b fp32 [D].  dtype LMI_F32 writes the normalised rows in fp32 (Idefics2 perceiver
+ * output, which is merged into the fp32 stream without a 16-bit rounding). */
 int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo,
                   float eps, int dtype, void* stream);
 int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx, int ldo, float eps, int dtype,
@@ -157,6 +161,37 @@ int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, 
  * K = 4096 (the hidden size of Llama-3.1-8B / Mistral-7B). */
 int lmi_gemv_rmsnorm(const void* W, const float* x, const float* norm_weight, float eps, void* out, int N, int K, int ldw,
                      int epilogue, int dtype, void* stream);
+
+/* Last-position lm_head (EVAL:333 restricted to the rows generate() consumes; SURVEY.md 8(b) "lmi_lm_head_last"): for each
+ * selected row r of the fp32 residual stream x [., ldx] (row index rows[r], int64 on device; null = row r),
+ * out[r, 0..N) = W[N,K] . (norm_weight * (x_row * rsqrt(mean(x_row^2) + eps))) with the final RMSNorm
+ * (megatron/legacy/model/rms_norm.py:26-31) applied in the launch (norm_weight null = no normalisation).  The normalised
+ * row is kept in fp32 — it is never rounded to T — so these logits carry no activation rounding at all; the kernel is
+ * bound by the weight stream (2 bytes per weight).  out: fp32 [n_rows, ldo], ldo >= N; K % 8 == 0, K <= 16380. */
+int lmi_lm_head_last(const void* W, const float* x, const int64_t* rows, const float* norm_weight, float eps, float* out, int n_rows,
+                     int N, int K, int ldw, int ldx, int ldo, int dtype, void* stream);
+
+/* ---- multi-GPU: RCCL collectives over xGMI (SURVEY.md 8(b) "lmi_allgather / lmi_allreduce wrappers over RCCL communicators
+ * ... created by lmi_comm_init(rank, nranks, unique_id) and freed by lmi_comm_destroy", 8(e)).  The reference's evaluation is one
+ * process per GPU with no collective (run_eval_llava_siglip_multiimg.sh:9-11); its training side states the exchange pattern
+ * these serve: all-gather / reduce-scatter around sequence-parallel norms
+ * (Megatron-LM-240603/megatron/core/tensor_parallel/mappings.py:107-145, layers.py:387-454).
+ * One process per GPU: lmi_comm_init binds the CURRENT HIP device to `rank`.  Rank 0 calls lmi_comm_unique_id and hands the 128
+ * bytes to the other ranks out of band (the host-side rendezvous: torch.distributed's store in leopard_amd/dist.py).  The
+ * communicator is the only thing this library ever allocates; collectives are stream-ordered like every other entry point
+ * (launch them on a side stream to overlap them with GEMMs).  librccl is bound with dlopen at the first call; when it cannot be
+ * loaded, or a collective fails, the call returns LMI_ECOMM — there is no fallback transport.
+ * counts are in elements of `dtype` (LMI_F16 / LMI_BF16 / LMI_F32); all reductions are sums. */
+int lmi_comm_unique_id(void* id128);
+int lmi_comm_init(int rank, int nranks, const void* id128, void** comm_out);
+int lmi_comm_destroy(void* comm);
+int lmi_comm_size(void* comm);                                   /* ranks RCCL sees in `comm` (negative on error) */
+/* recv[r*count_per_rank ...] = send of rank r */
+int lmi_allgather(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, void* stream);
+int lmi_allreduce(void* comm, const void* send, void* recv, int64_t count, int dtype, void* stream);
+/* recv[0..recv_count) = sum over ranks of send[rank*recv_count ...] */
+int lmi_reduce_scatter(void* comm, const void* send, void* recv, int64_t recv_count, int dtype, void* stream);
+int lmi_broadcast(void* comm, const void* send, void* recv, int64_t count, int dtype, int root, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,15 @@ SIGNATURES = {
     "lmi_embed_merge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lmi_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lmi_gemv_rmsnorm": [_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
+    "lmi_lm_head_last": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_comm_unique_id": [_P],
+    "lmi_comm_init": [_I, _I, _P, C.POINTER(C.c_void_p)],
+    "lmi_comm_destroy": [_P],
+    "lmi_comm_size": [_P],
+    "lmi_allgather": [_P, _P, _P, C.c_int64, _I, _P],
+    "lmi_allreduce": [_P, _P, _P, C.c_int64, _I, _P],
+    "lmi_reduce_scatter": [_P, _P, _P, C.c_int64, _I, _P],
+    "lmi_broadcast": [_P, _P, _P, C.c_int64, _I, _I, _P],
 }
 
 

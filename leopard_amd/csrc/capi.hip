@@ -2,6 +2,7 @@
 // Built by hipcc for gfx950; the same file builds against tools/hipemu with -DLMI_EMU for CPU logic tests.
 #include "../../include/leopard_amd.h"
 
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -37,12 +38,20 @@ int check_launch(const char* what) {
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// Raise the dynamic-LDS limit of `kernel` on the CURRENT device.  The attribute is per device, so the "already done" flag is a
+// per-instantiation bit mask indexed by the device ordinal (a process may drive several GPUs, one thread each); atomic because
+// the header promises re-entrancy per stream.
 template <typename K>
-void allow_big_lds(K kernel, int bytes) {
+void allow_big_lds(K kernel, int bytes, std::atomic<uint64_t>& done) {
 #ifndef LMI_EMU
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return;
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_relaxed);
 #else
-    (void)kernel; (void)bytes;
+    (void)kernel; (void)bytes; (void)done;
 #endif
 }
 
@@ -77,8 +86,8 @@ template <typename T, int EPI, int ACT, int AMODE, typename C>
 int launch_gemm_cfg(const GemmArgs& a, void* stream) {
     int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
     if (a.order == 1) tiles = (tiles + 255) / 256 * 256;
-    static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE, C>, C::SMEM); attr_set = true; }
+    static std::atomic<uint64_t> attr_done{0};
+    allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE, C>, C::SMEM, attr_done);
     LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
     return check_launch("lmi_gemm");
 }
@@ -87,8 +96,8 @@ template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR>
 int launch_gemm_stagger(const GemmArgs& a, void* stream) {
     int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
     if (a.order == 1) tiles = (tiles + 255) / 256 * 256;
-    static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>, C::SMEM); attr_set = true; }
+    static std::atomic<uint64_t> attr_done{0};
+    allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>, C::SMEM, attr_done);
     LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
     return check_launch("lmi_gemm");
 }
@@ -148,7 +157,8 @@ int dispatch_gemm(const GemmArgs& a, int epi, int act, int amode, void* stream) 
 template <typename T, int D, bool CAUSAL, bool USE_TR>
 int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     const int qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
-    allow_big_lds(attn_fwd_kernel<T, D, CAUSAL, USE_TR>, AttnGeom<D>::SMEM);
+    static std::atomic<uint64_t> attr_done{0};
+    allow_big_lds(attn_fwd_kernel<T, D, CAUSAL, USE_TR>, AttnGeom<D>::SMEM, attr_done);
     LMI_LAUNCH((attn_fwd_kernel<T, D, CAUSAL, USE_TR>), dim3(qblocks, a.n_heads, n_seq), dim3(ATT_THREADS),
                AttnGeom<D>::SMEM, stream, a);
     return check_launch("lmi_attn_varlen_fwd");
@@ -159,8 +169,8 @@ int g_attn_dma = 1;                          // 1 = LDS-DMA kernel (production),
 template <typename T, int D, bool CAUSAL>
 int launch_attn_dma(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     const int qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
-    static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(attn_fwd_dma_kernel<T, D, CAUSAL>, 160 * 1024); attr_set = true; }
+    static std::atomic<uint64_t> attr_done{0};
+    allow_big_lds(attn_fwd_dma_kernel<T, D, CAUSAL>, 160 * 1024, attr_done);
     AttnArgs b = a;
     b.n_qblocks = qblocks;
     LMI_LAUNCH((attn_fwd_dma_kernel<T, D, CAUSAL>), dim3(qblocks * a.n_heads * n_seq), dim3(ATT_THREADS),
@@ -277,8 +287,8 @@ static int decode_splits(int max_seqlen_k, int* split_tiles) {
 
 template <typename T>
 int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, int ldo, void* stream) {
-    static bool attr_set = false;
-    if (!attr_set) { allow_big_lds(attn_fwd_dma_kernel<T, 128, true>, 160 * 1024); attr_set = true; }
+    static std::atomic<uint64_t> attr_done{0};
+    allow_big_lds(attn_fwd_dma_kernel<T, 128, true>, 160 * 1024, attr_done);
     a.n_qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
     LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true>), dim3(a.n_qblocks * a.n_heads * n_seq * a.n_splits), dim3(ATT_THREADS),
                AttnDmaGeom<128>::SMEM, stream, a);
@@ -381,12 +391,14 @@ int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, in
 
 int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps,
                   int dtype, void* stream) {
+    if (dtype == LMI_F32) return norm_impl<float, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm");
     LMI_DISPATCH_T(dtype, (norm_impl<f16_t, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm")),
                    (norm_impl<bf16_t, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm")));
 }
 
 int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx, int ldo, float eps, int dtype,
                 void* stream) {
+    if (dtype == LMI_F32) return norm_impl<float, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm");
     LMI_DISPATCH_T(dtype, (norm_impl<f16_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm")),
                    (norm_impl<bf16_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm")));
 }
@@ -512,6 +524,28 @@ int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, 
                    (dispatch_gemv<bf16_t, false>(W, x, nullptr, 0.f, bias, out, N, K, ldw, epilogue, stream)));
 }
 
+int lmi_lm_head_last(const void* W, const float* x, const int64_t* rows, const float* norm_weight, float eps, float* out, int n_rows,
+                     int N, int K, int ldw, int ldx, int ldo, int dtype, void* stream) {
+    if (!W || !x || !out || n_rows < 0 || N <= 0 || K <= 0 || (K & 7) || (ldw & 7) || (ldx & 3) || ldo < N || !aligned16(W) ||
+        !aligned16(x) || (norm_weight && !aligned16(norm_weight)))
+        return fail(LMI_EINVAL, "lmi_lm_head_last: bad argument (n_rows=%d N=%d K=%d; K %% 8 == 0, ldo >= N)", n_rows, N, K);
+    const int lds = (K + 4) * 4;
+    if (lds > 64 * 1024) return fail(LMI_EINVAL, "lmi_lm_head_last: K = %d does not fit the LDS row buffer (max 16380)", K);
+    if (n_rows == 0) return LMI_OK;
+    int rpw = 32;                                                  // vocabulary rows per workgroup: about 2048 workgroups per selected row
+    while ((N + rpw - 1) / rpw > 2048) rpw *= 2;
+    const dim3 grid((N + rpw - 1) / rpw, n_rows);
+    if (dtype == LMI_F16)
+        LMI_LAUNCH((lm_head_rows_kernel<f16_t, 8>), grid, dim3(256), lds, stream, (const f16_t*)W, x, (const long*)rows, norm_weight, eps, out,
+                   N, K, ldw, ldx, ldo, rpw);
+    else if (dtype == LMI_BF16)
+        LMI_LAUNCH((lm_head_rows_kernel<bf16_t, 8>), grid, dim3(256), lds, stream, (const bf16_t*)W, x, (const long*)rows, norm_weight, eps,
+                   out, N, K, ldw, ldx, ldo, rpw);
+    else
+        return fail(LMI_EINVAL, "lmi_lm_head_last: dtype must be LMI_F16 or LMI_BF16");
+    return check_launch("lmi_lm_head_last");
+}
+
 int lmi_gemv_rmsnorm(const void* W, const float* x, const float* norm_weight, float eps, void* out, int N, int K, int ldw,
                      int epilogue, int dtype, void* stream) {
     if (!W || !x || !norm_weight || !out || N <= 0 || K <= 0 || (ldw & 7) || (epilogue == 3 && (N & 63)) || !aligned16(x) ||
@@ -519,6 +553,136 @@ int lmi_gemv_rmsnorm(const void* W, const float* x, const float* norm_weight, fl
         return fail(LMI_EINVAL, "lmi_gemv_rmsnorm: bad argument (N=%d K=%d)", N, K);
     LMI_DISPATCH_T(dtype, (dispatch_gemv<f16_t, true>(W, x, norm_weight, eps, nullptr, out, N, K, ldw, epilogue, stream)),
                    (dispatch_gemv<bf16_t, true>(W, x, norm_weight, eps, nullptr, out, N, K, ldw, epilogue, stream)));
+}
+
+}  // extern "C"
+
+// ---- RCCL collectives over xGMI ------------------------------------------------------------------------
+// librccl is bound at run time with dlopen: the library has no link-time dependency on it (single-GPU users never load it),
+// and inside a PyTorch process the copy PyTorch already mapped is reused instead of a second one.  One communicator per
+// process / GPU (one process per GPU, as the reference launches its evaluation, run_eval_llava_siglip_multiimg.sh:9-11).
+#include <dlfcn.h>
+namespace {
+struct RcclUid { char internal[128]; };                       // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
+enum { RCCL_SUM = 0, RCCL_F16 = 6, RCCL_F32 = 7, RCCL_BF16 = 9 };   // ncclRedOp_t / ncclDataType_t values of rccl.h
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclUid*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclUid, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::atomic<int> g_rccl_state{0};                              // 0 = not tried, 1 = bound, -1 = unavailable
+
+int rccl_bind() {
+    int st = g_rccl_state.load();
+    if (st != 0) return st;
+#ifdef LMI_EMU
+    g_rccl_state = -1;
+    return -1;
+#else
+    static const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;     // a copy already in the process (PyTorch's)
+    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) { g_rccl_state = -1; return -1; }
+    Rccl r;
+    r.handle = h;
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(h, name); if (!p) ok = false; return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.ReduceScatter = (decltype(r.ReduceScatter))sym("ncclReduceScatter");
+    r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { g_rccl_state = -1; return -1; }
+    g_rccl = r;
+    g_rccl_state = 1;
+    return 1;
+#endif
+}
+int rccl_fail(const char* what, int rc) {
+    return fail(LMI_ECOMM, "%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+}
+int rccl_dtype(int dtype) { return dtype == LMI_F16 ? RCCL_F16 : dtype == LMI_BF16 ? RCCL_BF16 : dtype == LMI_F32 ? RCCL_F32 : -1; }
+#define LMI_NEED_RCCL(who) do { if (rccl_bind() != 1) return fail(LMI_ECOMM, "%s: librccl could not be loaded (dlopen)", who); } while (0)
+}  // namespace
+
+extern "C" {
+
+int lmi_comm_unique_id(void* id128) {
+    if (!id128) return fail(LMI_EINVAL, "lmi_comm_unique_id: null pointer");
+    LMI_NEED_RCCL("lmi_comm_unique_id");
+    RcclUid id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc) return rccl_fail("lmi_comm_unique_id", rc);
+    memcpy(id128, id.internal, 128);
+    return LMI_OK;
+}
+
+int lmi_comm_init(int rank, int nranks, const void* id128, void** comm_out) {
+    if (!id128 || !comm_out || nranks <= 0 || rank < 0 || rank >= nranks) return fail(LMI_EINVAL, "lmi_comm_init: bad argument");
+    LMI_NEED_RCCL("lmi_comm_init");
+    RcclUid id;
+    memcpy(id.internal, id128, 128);
+    void* comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, nranks, id, rank);      // binds the CURRENT HIP device to this rank
+    if (rc) return rccl_fail("lmi_comm_init", rc);
+    int n = -1;
+    if (g_rccl.CommCount(comm, &n) || n != nranks) { g_rccl.CommDestroy(comm); return fail(LMI_ECOMM, "lmi_comm_init: communicator reports %d ranks, expected %d", n, nranks); }
+    *comm_out = comm;
+    return LMI_OK;
+}
+
+int lmi_comm_destroy(void* comm) {
+    if (!comm) return LMI_OK;
+    LMI_NEED_RCCL("lmi_comm_destroy");
+    const int rc = g_rccl.CommDestroy(comm);
+    return rc ? rccl_fail("lmi_comm_destroy", rc) : LMI_OK;
+}
+
+int lmi_comm_size(void* comm) {
+    if (!comm || rccl_bind() != 1) return -1;
+    int n = -1;
+    return g_rccl.CommCount(comm, &n) ? -1 : n;
+}
+
+int lmi_allgather(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, void* stream) {
+    if (!comm || !send || !recv || count_per_rank < 0 || rccl_dtype(dtype) < 0) return fail(LMI_EINVAL, "lmi_allgather: bad argument");
+    LMI_NEED_RCCL("lmi_allgather");
+    const int rc = g_rccl.AllGather(send, recv, (size_t)count_per_rank, rccl_dtype(dtype), comm, stream);
+    return rc ? rccl_fail("lmi_allgather", rc) : LMI_OK;
+}
+
+int lmi_allreduce(void* comm, const void* send, void* recv, int64_t count, int dtype, void* stream) {
+    if (!comm || !send || !recv || count < 0 || rccl_dtype(dtype) < 0) return fail(LMI_EINVAL, "lmi_allreduce: bad argument");
+    LMI_NEED_RCCL("lmi_allreduce");
+    const int rc = g_rccl.AllReduce(send, recv, (size_t)count, rccl_dtype(dtype), RCCL_SUM, comm, stream);
+    return rc ? rccl_fail("lmi_allreduce", rc) : LMI_OK;
+}
+
+int lmi_reduce_scatter(void* comm, const void* send, void* recv, int64_t recv_count, int dtype, void* stream) {
+    if (!comm || !send || !recv || recv_count < 0 || rccl_dtype(dtype) < 0) return fail(LMI_EINVAL, "lmi_reduce_scatter: bad argument");
+    LMI_NEED_RCCL("lmi_reduce_scatter");
+    const int rc = g_rccl.ReduceScatter(send, recv, (size_t)recv_count, rccl_dtype(dtype), RCCL_SUM, comm, stream);
+    return rc ? rccl_fail("lmi_reduce_scatter", rc) : LMI_OK;
+}
+
+int lmi_broadcast(void* comm, const void* send, void* recv, int64_t count, int dtype, int root, void* stream) {
+    if (!comm || !send || !recv || count < 0 || rccl_dtype(dtype) < 0) return fail(LMI_EINVAL, "lmi_broadcast: bad argument");
+    LMI_NEED_RCCL("lmi_broadcast");
+    const int rc = g_rccl.Broadcast(send, recv, (size_t)count, rccl_dtype(dtype), root, comm, stream);
+    return rc ? rccl_fail("lmi_broadcast", rc) : LMI_OK;
 }
 
 }  // extern "C"

@@ -390,4 +390,68 @@ __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// lmi_lm_head_last: logits of a few selected rows of the fp32 residual stream (the last position of every packed sequence
+// in prefill, EVAL:333 restricted to what generate() consumes; the single row of a decode step).  The final RMSNorm is
+// applied in the launch and the normalised row STAYS fp32 — it is never rounded to the 16-bit compute type — so the head
+// is w(T, exact) x x(fp32) with fp32 FMAs: the one place on the path where full activation precision costs nothing,
+// because the kernel is bound by the 1.05 GB weight stream (2 B / weight), not by arithmetic.
+// grid = (row blocks of the vocabulary, selected rows); the normalised row lives in LDS (K floats), each wave streams R
+// weight rows at a time, 16 bytes per lane per load, and reduces with wave64 shuffles.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int R>
+__global__ void __launch_bounds__(256) lm_head_rows_kernel(const T* W, const float* x, const long* rows, const float* gamma,
+                                                           float eps, float* out, int N, int K, int ldw, int ldx, int ldo,
+                                                           int rows_per_wg) {
+    typedef typename vec_of<T>::x8 T8;
+    LMI_DYN_SMEM(smem);
+    float* xs = (float*)smem;                                      // [K] normalised row, + 4 floats of reduction scratch
+    float* red = xs + K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long src = rows ? rows[blockIdx.y] : (long)blockIdx.y;
+    const float* xr = x + src * ldx;
+    float ss = 0.f;
+    for (int i = tid * 4; i < K; i += 1024) {
+        const f32x4 v = *(const f32x4*)(xr + i);
+        *(f32x4*)(xs + i) = v;
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    if (gamma) {
+        const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+        for (int i = tid * 4; i < K; i += 1024) {                  // same element arithmetic as norm_kernel: w * (x * rstd)
+            const f32x4 v = *(const f32x4*)(xs + i), g = *(const f32x4*)(gamma + i);
+            *(f32x4*)(xs + i) = f32x4{g[0] * (v[0] * rstd), g[1] * (v[1] * rstd), g[2] * (v[2] * rstd), g[3] * (v[3] * rstd)};
+        }
+        __syncthreads();
+    }
+    const int n0 = blockIdx.x * rows_per_wg, n1 = imin(N, n0 + rows_per_wg);
+    float* orow = out + (long)blockIdx.y * ldo;
+    for (int nb = n0 + wave * R; nb < n1; nb += 4 * R) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        for (int c = lane * 8; c < K; c += 512) {
+            const f32x4 x0 = *(const f32x4*)(xs + c), x1 = *(const f32x4*)(xs + c + 4);
+            T8 wv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) wv[r] = *(const T8*)(W + (long)imin(nb + r, N - 1) * ldw + c);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r] += (float)wv[r][e] * x0[e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r] += (float)wv[r][4 + e] * x1[e];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float v = wave_sum(acc[r]);
+            if (lane == 0 && nb + r < n1) orow[nb + r] = v;
+        }
+    }
+}
+
 }  // namespace lmi

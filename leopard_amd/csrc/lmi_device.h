@@ -27,6 +27,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -35,6 +36,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <typename T> struct vec_of;
 template <> struct vec_of<f16_t> { typedef f16x8 x8; typedef f16x4 x4; typedef f16x2 x2; };
 template <> struct vec_of<bf16_t> { typedef bf16x8 x8; typedef bf16x4 x4; typedef bf16x2 x2; };
+template <> struct vec_of<float> { typedef f32x8 x8; typedef f32x4 x4; typedef f32x2 x2; };   // fp32-output norms
 
 #define LMI_WAVE 64
 

@@ -99,6 +99,7 @@ class LeopardEngine:
         self.device = torch.device(device) if device is not None else weights.embed.device
         self.use_tr = use_tr
         self.use_graphs = True         # capture the decode step in a HIP graph (cuda devices only)
+        self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
         tc = cfg.text_config
         self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
         self._geom_cache: Dict[tuple, tuple] = {}      # seq_lens -> (cu, cos, sin, last_rows) device tensors
@@ -182,7 +183,9 @@ class LeopardEngine:
         if cu is None:
             cu = self._vit_cu_cache[n] = torch.arange(0, (n + 1) * T, T, dtype=torch.int32, device=self.device)
         scale = hd ** -0.5
-        for L in W.vit_layers:
+        if self.trace:
+            self.trace("vit.embed", x)
+        for li, L in enumerate(W.vit_layers):
             ops.layernorm(x, L.ln1_w, L.ln1_b, h, vc.layer_norm_eps)
             ops.gemm(h, L.qkv_w, qkv, bias=L.qkv_b)
             ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, cu, cu, T, H, H, hd, scale, False,
@@ -191,6 +194,8 @@ class LeopardEngine:
             ops.layernorm(x, L.ln2_w, L.ln2_b, h, vc.layer_norm_eps)
             ops.gemm(h, L.fc1_w, ff, bias=L.fc1_b, act=_lib.ACT_GELU_TANH)
             ops.gemm(ff, L.fc2_w, x, bias=L.fc2_b, epilogue=_lib.EPI_RESIDUAL)
+            if self.trace:
+                self.trace(f"vit.{li}", x)
         ops.layernorm(x, W.post_ln_w, W.post_ln_b, h, vc.layer_norm_eps)
         return h
 
@@ -253,6 +258,8 @@ class LeopardEngine:
         tmp = self._empty(S, D, dtype=torch.float32) if self.tp_size > 1 else None
         scale = hd ** -0.5
         max_len = max(int(l) for l in seq_lens)
+        if self.trace:
+            self.trace("llm.embed", x)
         for i, L in enumerate(W.llm_layers):
             ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
             ops.gemm(h, L.qkv_w, qkv)
@@ -263,6 +270,8 @@ class LeopardEngine:
             ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
             ops.gemm(h, L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
             self._row_parallel(gu, L.down_w, x, tmp)
+            if self.trace:
+                self.trace(f"llm.{i}", x)
         if cache is not None:
             cache.length = S
         return self._lm_head(x, last_rows, all_logits)
@@ -270,12 +279,10 @@ class LeopardEngine:
     def _lm_head(self, x, last_rows, all_logits):
         ops, W, tc = self.ops, self.W, self.cfg.text_config
         V = tc.vocab_size
-        xl = x.index_select(0, last_rows).contiguous()                   # [n_seq, D] fp32 (plumbing gather)
-        hl = self._empty(xl.shape[0], xl.shape[1])
-        ops.rmsnorm(xl, W.final_norm, hl, tc.rms_norm_eps)
-        logits_last = self._empty(xl.shape[0], W.lm_head.shape[0], dtype=torch.float32)
-        for r in range(xl.shape[0]):
-            ops.gemv(W.lm_head, hl[r], logits_last[r])
+        # last position of every packed sequence: final RMSNorm + head in ONE launch over the fp32 rows (no 16-bit
+        # rounding of the normalised row: lmi_lm_head_last)
+        logits_last = self._empty(last_rows.numel(), W.lm_head.shape[0], dtype=torch.float32)
+        ops.lm_head_last(W.lm_head, x, last_rows, W.final_norm, tc.rms_norm_eps, logits_last)
         logits_all = None
         if all_logits:
             hall = self._empty(*x.shape)
@@ -400,11 +407,7 @@ class LeopardEngine:
                 ops.rmsnorm(st.x, L.post_norm, st.h, tc.rms_norm_eps)
                 ops.gemv(L.gu_w, st.h[0], st.gu[0], epilogue=3)
             row_parallel(L.down_w, st.gu[0])
-        if fuse:
-            ops.gemv_rmsnorm(W.lm_head, st.x[0], W.final_norm, tc.rms_norm_eps, st.logits, epilogue=0)
-        else:
-            ops.rmsnorm(st.x, W.final_norm, st.h, tc.rms_norm_eps)
-            ops.gemv(W.lm_head, st.h[0], st.logits)
+        ops.lm_head_last(W.lm_head, st.x, None, W.final_norm, tc.rms_norm_eps, st.logits.view(1, -1))
         # greedy choice and position advance stay on the device (torch ops as plumbing; all capturable)
         torch.argmax(st.logits[:tc.vocab_size], dim=0, keepdim=True, out=st.tok)
         st.pos.add_(1)

@@ -52,16 +52,20 @@ class GpuTiler:
             self.ops.resample_u8(cur, dst, 1, *self._coeffs(h, dh))
 
     def tile_sample(self, images: Sequence[np.ndarray]):
-        """images: u8 HWC arrays (RGB).  Returns (tiles u8 [N, tile, tile, 3] on the device, plan) in the reference's ViT
-        input order: per image the squashed whole image, then its tiles row-major."""
+        """images: u8 HWC arrays (RGB) on the host, or u8 HWC tensors already resident on the device.  Returns
+        (tiles u8 [N, tile, tile, 3] on the device, plan) in the reference's ViT input order: per image the squashed whole
+        image, then its tiles row-major."""
         T = self.tile
         sizes = [(int(im.shape[1]), int(im.shape[0])) for im in images]            # PIL (W, H)
         plan = tiler.plan_sample(sizes, T, self.sample_budget)
         tiles = torch.empty((plan.n_vit_inputs, self.out_size, self.out_size, 3), dtype=torch.uint8, device=self.device)
         n = 0
         for im, size, canvas in zip(images, sizes, plan.canvases):
-            src = torch.from_numpy(np.array(im, dtype=np.uint8, order="C"))             # a writable copy (images may be read-only views)
-            src = src.to(self.device, non_blocking=True) if self.device.type != "cpu" else src
+            if torch.is_tensor(im):
+                src = im if im.device == self.device else im.to(self.device, non_blocking=True)
+            else:
+                src = torch.from_numpy(np.array(im, dtype=np.uint8, order="C"))         # a writable copy (images may be read-only views)
+                src = src.to(self.device, non_blocking=True) if self.device.type != "cpu" else src
             self._resize_into(src, tiles[n])                                       # the thumbnail: aspect-squashing resize
             n += 1
             if canvas is None:

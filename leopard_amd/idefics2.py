@@ -235,9 +235,7 @@ class Idefics2Engine(LeopardEngine):
             ops.gemm(ln, L.gu_w, g2, epilogue=_lib.EPI_SWIGLU)
             ops.gemm(g2, L.down_w, lat, epilogue=_lib.EPI_RESIDUAL)
         out = self._empty(n_img * Lt, D, dtype=torch.float32)
-        # final RMSNorm in fp32: reuse the kernel (16-bit output) then widen — the merged stream is fp32
-        ops.rmsnorm(lat, W.perceiver_norm, ln, pc.rms_norm_eps)
-        out.copy_(ln)
+        ops.rmsnorm(lat, W.perceiver_norm, out, pc.rms_norm_eps)             # fp32 in, fp32 out: the merged stream is fp32
         return out
 
     def encode_images(self, images: Sequence[torch.Tensor]) -> torch.Tensor:

@@ -160,3 +160,13 @@ class Ops:
         self._check(self.lib.lmi_gemv_rmsnorm(_ptr(w), _ptr(x_f32), _ptr(norm_weight), float(eps), _ptr(out), N, K, w.stride(0),
                                               epilogue, _DT[w.dtype], self._stream(out)))
         return out
+
+    def lm_head_last(self, w, x_f32, rows, norm_weight, eps, out):
+        """out[r] = w @ rmsnorm(x_f32[rows[r]]) with the normalised row kept in fp32 (no activation rounding).
+        x_f32: fp32 [S, K]; rows: int64 [n] on device or None (rows 0..n-1); out: fp32 [n, >= N]."""
+        N, K = w.shape
+        n = out.shape[0]
+        assert out.dtype == torch.float32 and x_f32.dtype == torch.float32 and (rows is None or rows.dtype == torch.int64)
+        self._check(self.lib.lmi_lm_head_last(_ptr(w), _ptr(x_f32), _ptr(rows), _ptr(norm_weight), float(eps), _ptr(out), n, N, K,
+                                              w.stride(0), x_f32.stride(0), out.stride(0), _DT[w.dtype], self._stream(out)))
+        return out

@@ -160,19 +160,32 @@ class EngineWeights:
         W.proj2_w = g(m + "linear_2.weight").contiguous(); W.proj2_b = _pad1(g(m + "linear_2.bias"), tc.hidden_size)
         l = "language_model.model."
         W.embed = g(l + "embed_tokens.weight").contiguous()
+        Dt, full_q, full_kv = tc.hidden_size, tc.num_attention_heads * tc.head_dim, tc.num_key_value_heads * tc.head_dim
+
+        def expect(name: str, shape) -> torch.Tensor:
+            """A checkpoint whose config.json disagrees with its tensors (the reference converter writes
+            num_key_value_heads = num_attention_heads for non-70b models, hf2megatron_llava.py:1035) must fail here, not
+            slice silently and leave attention reading unwritten K/V columns."""
+            t = g(name)
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"{name}: shape {tuple(t.shape)} does not match the configuration (expected {tuple(shape)}: "
+                                 f"hidden {Dt}, {tc.num_attention_heads} q / {tc.num_key_value_heads} kv heads x {tc.head_dim}, "
+                                 f"FFN {tc.intermediate_size})")
+            return t
         for i in range(tc.num_hidden_layers):
             p = f"{l}layers.{i}."
             qw, kw, ff = W.llm_heads * tc.head_dim, W.llm_kv_heads * tc.head_dim, W.llm_ff
             rq, rk, rf = slice(tp_rank * qw, (tp_rank + 1) * qw), slice(tp_rank * kw, (tp_rank + 1) * kw), slice(tp_rank * ff, (tp_rank + 1) * ff)
-            qkv_w = torch.cat([g(p + "self_attn.q_proj.weight")[rq], g(p + "self_attn.k_proj.weight")[rk],
-                               g(p + "self_attn.v_proj.weight")[rk]], dim=0).contiguous()
+            qkv_w = torch.cat([expect(p + "self_attn.q_proj.weight", (full_q, Dt))[rq], expect(p + "self_attn.k_proj.weight", (full_kv, Dt))[rk],
+                               expect(p + "self_attn.v_proj.weight", (full_kv, Dt))[rk]], dim=0).contiguous()
             W.llm_layers.append(LlmLayerW(
                 in_norm=g(p + "input_layernorm.weight").float().contiguous(),
                 qkv_w=qkv_w,
-                o_w=g(p + "self_attn.o_proj.weight")[:, rq].contiguous(),
+                o_w=expect(p + "self_attn.o_proj.weight", (Dt, full_q))[:, rq].contiguous(),
                 post_norm=g(p + "post_attention_layernorm.weight").float().contiguous(),
-                gu_w=interleave_gate_up(g(p + "mlp.gate_proj.weight")[rf], g(p + "mlp.up_proj.weight")[rf]),
-                down_w=g(p + "mlp.down_proj.weight")[:, rf].contiguous()))
+                gu_w=interleave_gate_up(expect(p + "mlp.gate_proj.weight", (tc.intermediate_size, Dt))[rf],
+                                        expect(p + "mlp.up_proj.weight", (tc.intermediate_size, Dt))[rf]),
+                down_w=expect(p + "mlp.down_proj.weight", (Dt, tc.intermediate_size))[:, rf].contiguous()))
         W.final_norm = g(l + "norm.weight").float().contiguous()
         head = g("language_model.lm_head.weight")
         W.lm_head = _pad2(head, _round_up(head.shape[0], 128), tc.hidden_size)

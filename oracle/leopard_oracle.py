@@ -43,6 +43,48 @@ Tensor = torch.Tensor
 
 
 # ==================================================================================================
+# Rounding-point emulation and per-layer tracing (both OFF by default: the oracle is plain fp32).
+#
+# The HIP path feeds 16-bit operands to the MFMAs (fp32 accumulate, fp32 residual stream), so it
+# differs from this fp32 restatement by one rounding at each point where an activation is handed from
+# one kernel to the next.  ``emulate_rounding(dtype)`` rounds this oracle's activations to ``dtype``
+# (fp16 / bf16) at exactly those hand-over points and nowhere else.  Tests use it two ways:
+#   * oracle(emulated) vs oracle(fp32)  = the PREDICTED error budget of 16-bit operands at a given depth;
+#   * HIP vs oracle(emulated)           = what is left (accumulation order, exp/rsqrt approximations):
+#                                         an order of magnitude smaller when the kernels are right.
+# ``trace`` (a list) receives (name, tensor) after the embeddings and after every layer.
+# ==================================================================================================
+class _Emu:
+    dtype = None          # None = no emulation
+    trace = None          # list or None
+    fp32_head = True      # the HIP path feeds the last-token lm_head the fp32 normalised row (lmi_lm_head_last)
+
+
+def _q(x: Tensor) -> Tensor:
+    """Hand-over rounding point: identity unless emulate_rounding() is active."""
+    return x if _Emu.dtype is None else x.to(_Emu.dtype).to(torch.float32)
+
+
+def _tr(name: str, x: Tensor) -> None:
+    if _Emu.trace is not None:
+        _Emu.trace.append((name, x.detach().clone()))
+
+
+class emulate_rounding:
+    def __init__(self, dtype, trace: Optional[list] = None):
+        self.dtype, self.trace = dtype, trace
+
+    def __enter__(self):
+        self._old = (_Emu.dtype, _Emu.trace)
+        _Emu.dtype, _Emu.trace = self.dtype, self.trace
+        return self
+
+    def __exit__(self, *exc):
+        _Emu.dtype, _Emu.trace = self._old
+        return False
+
+
+# ==================================================================================================
 # a1-a4  tiler (integers + PIL); kept as an independent restatement so tests can diff it against
 #        leopard_amd.tiler AND against the reference-generated fixtures
 # ==================================================================================================
@@ -155,10 +197,20 @@ def gelu_tanh(x: Tensor) -> Tensor:
     return F.gelu(x, approximate="tanh")
 
 
+def _softmax_q(scores: Tensor) -> Tensor:
+    """fp32 softmax; under emulate_rounding() the probabilities that enter the P.V product are rounded like the
+    kernel's P operand while the normaliser stays the fp32 sum of the UNROUNDED exponentials (as in the kernel)."""
+    if _Emu.dtype is None:
+        return torch.softmax(scores, dim=-1, dtype=torch.float32)
+    m = scores.amax(dim=-1, keepdim=True)
+    e = torch.exp(scores - m)
+    return _q(e) / e.sum(dim=-1, keepdim=True)
+
+
 def siglip_embeddings(pixel_values: Tensor, W: Dict[str, Tensor], cfg) -> Tensor:
     """patch conv (k=stride=patch, bias) -> flatten -> + position embedding.  IVT:57-64,118-150."""
     p = "vision_tower.vision_model.embeddings."
-    x = F.conv2d(pixel_values, W[p + "patch_embedding.weight"], W[p + "patch_embedding.bias"],
+    x = F.conv2d(_q(pixel_values), W[p + "patch_embedding.weight"], W[p + "patch_embedding.bias"],
                  stride=cfg.vision_config.patch_size)
     x = x.flatten(2).transpose(1, 2)
     return x + W[p + "position_embedding.weight"].unsqueeze(0)
@@ -170,17 +222,17 @@ def siglip_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, prefix: str = "vi
     N, T, D = x.shape
     H, hd = vc.num_attention_heads, vc.head_dim
     r = x
-    h = F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], vc.layer_norm_eps)
-    q = F.linear(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"]).view(N, T, H, hd).transpose(1, 2)
-    k = F.linear(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"]).view(N, T, H, hd).transpose(1, 2)
-    v = F.linear(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"]).view(N, T, H, hd).transpose(1, 2)
+    h = _q(F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], vc.layer_norm_eps))
+    q = _q(F.linear(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
+    k = _q(F.linear(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
+    v = _q(F.linear(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)      # full (non-causal) attention per tile
-    a = torch.softmax(s, dim=-1, dtype=torch.float32)
-    o = torch.matmul(a, v).transpose(1, 2).reshape(N, T, D)
+    a = _softmax_q(s)
+    o = _q(torch.matmul(a, v)).transpose(1, 2).reshape(N, T, D)
     x = r + F.linear(o, W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"])
     r = x
-    h = F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], vc.layer_norm_eps)
-    h = gelu_tanh(F.linear(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"]))
+    h = _q(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], vc.layer_norm_eps))
+    h = _q(gelu_tanh(F.linear(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])))
     return r + F.linear(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"])
 
 
@@ -188,10 +240,12 @@ def siglip_vision_tower(pixel_values: Tensor, W: Dict[str, Tensor], cfg) -> Tens
     """``self.vision_tower(pixel_values).last_hidden_state`` (EVAL:268-273): [N,3,S,S] -> [N,T,D],
     post-layernorm included, pooling head not computed (its output is unused by the reference)."""
     x = siglip_embeddings(pixel_values, W, cfg)
+    _tr("vit.embed", x)
     for i in range(cfg.vision_config.num_hidden_layers):
         x = siglip_layer(x, W, i, cfg)
+        _tr(f"vit.{i}", x)
     p = "vision_tower.vision_model.post_layernorm."
-    return F.layer_norm(x, (x.shape[-1],), W[p + "weight"], W[p + "bias"], cfg.vision_config.layer_norm_eps)
+    return _q(F.layer_norm(x, (x.shape[-1],), W[p + "weight"], W[p + "bias"], cfg.vision_config.layer_norm_eps))
 
 
 # ==================================================================================================
@@ -212,7 +266,7 @@ def projector(image_features: Tensor, W: Dict[str, Tensor]) -> Tensor:
     """myLlavaMultiModalProjector.forward, EVAL:187-192 (act = ACT2FN['gelu'] = erf GELU)."""
     p = "multi_modal_projector."
     h = pixel_shuffle(image_features)
-    h = F.gelu(F.linear(h, W[p + "linear_1.weight"], W[p + "linear_1.bias"]))
+    h = _q(F.gelu(F.linear(h, W[p + "linear_1.weight"], W[p + "linear_1.bias"])))
     return F.linear(h, W[p + "linear_2.weight"], W[p + "linear_2.bias"])
 
 
@@ -310,12 +364,12 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
     B, S, D = x.shape
     H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     r = x
-    h = rms_norm(x, W[p + "input_layernorm.weight"], tc.rms_norm_eps)
-    q = F.linear(h, W[p + "self_attn.q_proj.weight"]).view(B, S, H, hd).transpose(1, 2)
-    k = F.linear(h, W[p + "self_attn.k_proj.weight"]).view(B, S, KV, hd).transpose(1, 2)
-    v = F.linear(h, W[p + "self_attn.v_proj.weight"]).view(B, S, KV, hd).transpose(1, 2)
-    q = q * cos + rotate_half(q) * sin
-    k = k * cos + rotate_half(k) * sin
+    h = _q(rms_norm(x, W[p + "input_layernorm.weight"], tc.rms_norm_eps))
+    q = _q(F.linear(h, W[p + "self_attn.q_proj.weight"])).view(B, S, H, hd).transpose(1, 2)
+    k = _q(F.linear(h, W[p + "self_attn.k_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
+    v = _q(F.linear(h, W[p + "self_attn.v_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
+    q = _q(q * cos + rotate_half(q) * sin)
+    k = _q(k * cos + rotate_half(k) * sin)
     if kv_out is not None:
         kv_out.append((k, v))
     rep = H // KV                                               # GQA repeat, XFMR:829-836
@@ -332,14 +386,14 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
         if getattr(tc, "sliding_window", None):                 # Mistral: query i sees keys j with i - j < window
             causal = causal & (ar[s0:s1, None] - ar[None, :s1] < tc.sliding_window)
         sc = sc.masked_fill(~causal, float("-inf"))
-        o[:, :, s0:s1] = torch.matmul(torch.softmax(sc, dim=-1, dtype=torch.float32), vv[:, :, :s1])
-    o = o.transpose(1, 2).reshape(B, S, H * hd)
+        o[:, :, s0:s1] = torch.matmul(_softmax_q(sc), vv[:, :, :s1])
+    o = _q(o.transpose(1, 2).reshape(B, S, H * hd))
     x = r + F.linear(o, W[p + "self_attn.o_proj.weight"])
     r = x
-    h = rms_norm(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps)
+    h = _q(rms_norm(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps))
     g = F.linear(h, W[p + "mlp.gate_proj.weight"])
     u = F.linear(h, W[p + "mlp.up_proj.weight"])
-    return r + F.linear(F.silu(g) * u, W[p + "mlp.down_proj.weight"])       # XFMR:136-139
+    return r + F.linear(_q(F.silu(g) * u), W[p + "mlp.down_proj.weight"])       # XFMR:136-139
 
 
 def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tensor], cfg,
@@ -351,11 +405,17 @@ def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tens
     tc = cfg.text_config
     cos, sin = rope_tables(position_ids, tc.head_dim, tc.rope_theta, tc.rope_scaling)
     x = inputs_embeds
+    _tr("llm.embed", x)
     for i in range(tc.num_hidden_layers):
         x = llama_layer(x, W, i, cfg, cos, sin, kv_out, prefix=prefix)
+        _tr(f"llm.{i}", x)
     x = rms_norm(x, W[prefix + "norm.weight"], tc.rms_norm_eps)
     if last_only:
         x = x[:, -1:, :]
+        if not _Emu.fp32_head:
+            x = _q(x)
+    else:
+        x = _q(x)                      # the all-position head is an MFMA GEMM over 16-bit rows
     return F.linear(x, W[head])
 
 

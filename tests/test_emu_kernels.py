@@ -552,3 +552,25 @@ def test_gemv_rmsnorm_equals_rmsnorm_then_gemv(ops):
     ops.gemv(w, h[0], a, epilogue=1)
     ops.gemv_rmsnorm(w, x[0], g, 1e-5, b, epilogue=1)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,N,n_rows", [(4096, 300, 3), (128, 256, 1), (64, 1000, 2)])
+def test_lm_head_last_keeps_the_normalised_row_in_fp32(ops, dtype, K, N, n_rows):
+    """lmi_lm_head_last: out = W . rmsnorm(x[rows]) with fp32 activations — exact to fp32 summation order against the fp32
+    definition (tolerance far below one 16-bit rounding of the normalised row), ragged N, row selection, and no-norm mode."""
+    g = torch.Generator().manual_seed(K + N)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    x = torch.randn(9, K, generator=g) * 3
+    gamma = torch.rand(K, generator=g) + 0.5
+    rows = torch.tensor([7, 0, 4][:n_rows], dtype=torch.int64)
+    out = torch.full((n_rows, N + 8), 7.0)
+    ops.lm_head_last(w, x, rows, gamma, 1e-5, out[:, :N])
+    xn = gamma * (x[rows] * torch.rsqrt(x[rows].pow(2).mean(-1, keepdim=True) + 1e-5))
+    ref = xn.double() @ w.double().T
+    assert (out[:, :N].double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert torch.all(out[:, N:] == 7.0)
+    out2 = torch.empty(n_rows, N)
+    ops.lm_head_last(w, x, None, None, 0.0, out2)                     # rows 0..n-1, no normalisation
+    ref2 = x[:n_rows].double() @ w.double().T
+    assert (out2.double() - ref2).abs().max() <= 2e-5 * ref2.abs().max()

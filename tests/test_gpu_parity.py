@@ -1,17 +1,22 @@
-"""-m gpu: the HIP prefill path vs the CPU oracle on identical seeded inputs (sizes the oracle finishes in
-seconds), a full-depth C1 run (27 ViT + 32 LLM layers) against the oracle, and size-independent properties at
-the full C3 size (42 tiles, S = 7187).
+"""-m gpu: the HIP prefill path vs the CPU oracle on identical seeded inputs.
 
-Tolerance (north_star: "logits within 1e-3 fp16").  The oracle is the reference's fp32 CPU arithmetic; the HIP
-path feeds 16-bit operands to the MFMAs (fp32 accumulate, fp32 residual stream), so every GEMM input carries one
-rounding of 2^-11 (fp16) / 2^-8 (bf16) relative.  The asserted bound is on the logit error NORMALISED by the logit
-scale, max|diff| / max|logit|:
-    fp16 compute: <= 2.5e-3   (measured 1.1e-3 at depth 2+2, 1.6e-3 at the full 27+32 layers)
-    bf16 compute: <= 2.0e-2   (3 fewer mantissa bits: measured 7.6e-3 / 1.3e-2)
-i.e. fp16 meets 1e-3 relative at shallow depth and stays within 2x of it through 59 layers; an ABSOLUTE 1e-3 on
-logits of magnitude ~6 is below what one fp16 rounding of the final hidden state alone produces (~1.5e-3), see
-DESIGN.md section 6.  Each test prints max-abs, normalised-max and relative-RMS errors.  Integer / index work is
-bit-exact."""
+  * mid configuration (full width, 2 + 2 layers, S = 566): every intermediate (ViT features, visual tokens, merged embeddings,
+    all-position and last-position logits), greedy continuation, error conventions;
+  * FULL depth and width (27 SigLIP + 32 Llama-3.1-8B layers) on C1 (1 x 336x336, S = 228) and on C2 (1 x 1344x896 -> 7 ViT
+    inputs, S = 1242), fp16 and bf16, last-position logits vs the fp32 oracle and vs the oracle with the kernels' 16-bit
+    hand-over roundings emulated (oracle.emulate_rounding);
+  * the C3 SEQUENCE LENGTH (6 x 1344x896 -> 42 ViT inputs, S = 7187) at reduced depth (2 + 2 full-width layers): the residual
+    stream of every one of the 7187 rows and the logits vs the oracle — the 29-row-tile GEMMs and the 7187-key softmax meet
+    the oracle directly, not only through self-consistency properties (those stay, at the end of the file).
+
+Tolerance (north_star: "logits within 1e-3 fp16").  The oracle is the reference's fp32 CPU arithmetic; the HIP path feeds
+16-bit operands to the MFMAs (fp32 accumulate, fp32 residual stream, fp32 last-token head), so it differs by one rounding of
+2^-11 (fp16) / 2^-8 (bf16) relative at every kernel hand-over.  The error is asserted on the logits NORMALISED by the logit
+scale, max|diff| / max|logit| (an absolute 1e-3 on logits of magnitude ~6 is finer than the fp16 grid of the values themselves).
+The bounds below are the MEASURED errors x 1.2 (profiles/r02_error_growth.txt holds the per-layer table and the predicted
+budget from the rounding-emulating oracle, which the measurements match); fp16 meets the 1e-3 at the depths the reference's
+C1 / C2 cases have where stated, and where it does not the table shows the same excess for the emulated oracle: it is the
+price of 16-bit operands at that depth, not of the kernels.  Integer / index work is bit-exact."""
 import numpy as np
 import pytest
 import torch
@@ -21,7 +26,11 @@ from leopard_amd.synth import synth_image_u8, synth_prompt_ids, synth_state_dict
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-LOGIT_TOL = {torch.float16: 2.5e-3, torch.bfloat16: 2.0e-2}      # on max|diff| / max|logit|
+# max|diff| / max|logit| bounds = measured x 1.2 (see the module docstring; measured values in the comments)
+LOGIT_TOL = {torch.float16: 1.4e-3, torch.bfloat16: 9.5e-3}                       # mid configuration (2 + 2 layers)
+FULL_TOL = {("c1", torch.float16): 1.8e-3, ("c1", torch.bfloat16): 1.6e-2,        # full depth (27 + 32 layers)
+            ("c2", torch.float16): 1.8e-3, ("c2", torch.bfloat16): 1.6e-2}
+EMU_TOL = {torch.float16: 1.0e-3, torch.bfloat16: 8e-3}                           # HIP vs the rounding-emulating oracle
 
 
 def err_stats(got, ref):
@@ -102,35 +111,109 @@ def test_merge_mismatch_raises_before_launch(ops, mid_oracle):
         eng.prefill(ids.to(DEV), torch.from_numpy(u8[:2]).to(DEV))
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_full_depth_c1_vs_oracle(ops, dtype):
-    """BASELINE config C1 at FULL depth and width: one 336x336 image (N=1 tile), 32-token question, S=228;
-    27 SigLIP + 32 Llama-3.1-8B layers.  The oracle runs in fp32 on the host cores from the very same
-    parameter values (generated on the GPU by lmi_fill_synthetic — bit-identical to the numpy generator, see
-    test_fill_synthetic_bit_exact — and copied to the host)."""
+@pytest.fixture(scope="module")
+def full_host_weights(ops):
+    """fp32 host copy of the full-size synthetic parameters (generated on the GPU by lmi_fill_synthetic — bit-identical to the
+    numpy generator, see test_fill_synthetic_bit_exact).  The synthetic values are exactly representable in fp16 AND bf16, so
+    one copy serves both compute types."""
     import psutil
-    from leopard_amd.engine import LeopardEngine
-    from leopard_amd.tiler import siglip_normalize
-    from leopard_amd.weights import EngineWeights, SynthSource
-    from oracle import leopard_oracle as O
+    from leopard_amd.weights import SynthSource
     if psutil.virtual_memory().available < 56 * 2 ** 30:
         pytest.skip("full-depth fp32 oracle needs ~40 GB of host RAM")
     cfg = full_config()
-    u8, ids, plan = sample_inputs(cfg, 1, 336, 336)
-    assert u8.shape[0] == 1 and plan.tiles_per_image == [0]
-    src = SynthSource(cfg, ops, torch.device(DEV), dtype)
-    W = EngineWeights.build(cfg, src, dtype)
+    src = SynthSource(cfg, ops, torch.device(DEV), torch.float16)
+    return {name: src.get(name).float().cpu() for name in src.specs}
+
+
+FULL_CASES = {"c1": (1, 336, 336, 1, 228), "c2": (1, 1344, 896, 7, 1242)}      # images, W, H -> ViT inputs, S
+
+
+@pytest.fixture(scope="module")
+def full_depth_oracle(full_host_weights):
+    """fp32 oracle logits of C1 and C2 at full depth (C2: ~22 TFLOP on the host cores), plus the fp16-rounding-emulating
+    oracle on C1; computed once for both compute types."""
+    from leopard_amd.tiler import siglip_normalize
+    from oracle import leopard_oracle as O
+    cfg = full_config()
+    out = {}
+    for name, (n, w, h, n_vit, S) in FULL_CASES.items():
+        u8, ids, plan = sample_inputs(cfg, n, w, h)
+        assert u8.shape[0] == n_vit
+        pix = torch.from_numpy(siglip_normalize(u8))
+        ref = O.prefill_logits(ids, pix, full_host_weights, cfg, last_only=True)[0, 0]
+        emu = {}
+        if name == "c1":
+            for dt in (torch.float16, torch.bfloat16):
+                with O.emulate_rounding(dt):
+                    emu[dt] = O.prefill_logits(ids, pix, full_host_weights, cfg, last_only=True)[0, 0]
+        out[name] = (u8, ids, S, ref, emu)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["c1", "c2"])
+def test_full_depth_vs_oracle(ops, full_depth_oracle, case, dtype):
+    """BASELINE configs C1 and C2 at FULL depth and width: 27 SigLIP + 32 Llama-3.1-8B layers, last-position logits."""
+    from leopard_amd.engine import LeopardEngine
+    from leopard_amd.weights import EngineWeights, SynthSource
+    cfg = full_config()
+    u8, ids, S, ref, emu = full_depth_oracle[case]
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, torch.device(DEV), dtype), dtype)
     eng = LeopardEngine(cfg, W, ops=ops, device=torch.device(DEV))
     res = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV))
     got = res.logits_last.cpu()
-    assert res.seq_len == 228
-    Wt = {name: src.get(name).float().cpu() for name in src.specs}
-    ref = O.prefill_logits(ids, torch.from_numpy(siglip_normalize(u8)), Wt, cfg, last_only=True)[0, 0]
+    assert res.seq_len == S
     a, n, r = err_stats(got, ref)
-    print(f"[C1 full depth {dtype}] max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}  max|logit| {ref.abs().max():.3f}  "
-          f"argmax equal = {int(got.argmax()) == int(ref.argmax())}")
-    assert n <= LOGIT_TOL[dtype]
+    print(f"[{case} full depth {dtype}] vs fp32 oracle: max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}  "
+          f"max|logit| {ref.abs().max():.3f}  argmax equal = {int(got.argmax()) == int(ref.argmax())}")
+    assert n <= FULL_TOL[(case, dtype)]
     assert int(got.argmax()) == int(ref.argmax())
+    if dtype in emu:
+        a2, n2, r2 = err_stats(got, emu[dtype])
+        ap, np_, rp = err_stats(emu[dtype], ref)
+        print(f"[{case} full depth {dtype}] vs rounding-emulating oracle: normalised-max {n2:.3e} rel-rms {r2:.3e};  "
+              f"predicted budget (emulated vs fp32 oracle): normalised-max {np_:.3e} rel-rms {rp:.3e}")
+        assert n2 <= EMU_TOL[dtype]
+    del eng, W
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def c3_length_oracle():
+    from leopard_amd.tiler import siglip_normalize
+    from oracle import leopard_oracle as O
+    cfg = mid_config()
+    u8, ids, plan = sample_inputs(cfg, 6, 1344, 896)
+    assert u8.shape[0] == 42
+    Wt = O.weights_from_numpy(synth_state_dict_numpy(cfg))
+    otrace = []
+    with O.emulate_rounding(None, trace=otrace):
+        ref, parts = O.prefill_logits(ids, torch.from_numpy(siglip_normalize(u8)), Wt, cfg, last_only=True, return_parts=True)
+    return cfg, u8, ids, ref, parts, dict(otrace)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_c3_sequence_length_vs_oracle(ops, c3_length_oracle, dtype):
+    """The C3 sample (6 x 1344x896 -> 42 ViT inputs, 7098 visual tokens, S = 7187) through 2 + 2 full-width layers against
+    the fp32 oracle: the fp32 residual stream after the last LLM layer on EVERY row (29 GEMM row tiles incl. the 19-row tail,
+    softmax over up to 7187 keys), the ViT features of all 42 tiles, and the last-position logits."""
+    cfg, u8, ids, ref, parts, otrace = c3_length_oracle
+    eng = build_engine(cfg, ops, dtype)
+    trace = {}
+    eng.trace = lambda name, x: trace.__setitem__(name, x.detach().float().cpu().clone())
+    res = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV), keep_parts=True)
+    assert res.seq_len == 7187
+    last = f"llm.{cfg.text_config.num_hidden_layers - 1}"
+    x_abs, x_nrm, x_rms = err_stats(trace[last], otrace[last][0])
+    per_row = (trace[last] - otrace[last][0]).abs().amax(dim=1) / otrace[last][0].abs().max()
+    v_abs, v_nrm, v_rms = err_stats(res.parts["vit"].cpu().view(42, 676, -1), parts["vit"])
+    l_abs, l_nrm, l_rms = err_stats(res.logits_last.cpu(), ref[0, 0])
+    print(f"[C3 length {dtype}] residual stream after the last layer, all 7187 rows: normalised-max {x_nrm:.3e} rel-rms {x_rms:.3e} "
+          f"(worst row {int(per_row.argmax())}); ViT features 42 tiles: {v_nrm:.3e} / {v_rms:.3e}; logits: {l_nrm:.3e} / {l_rms:.3e}")
+    tol = LOGIT_TOL[dtype]
+    assert x_nrm <= 2 * tol and x_rms <= tol          # max over 29 M elements sits further out in the error distribution than max over a row
+    assert v_nrm <= tol and l_nrm <= tol
+    assert int(res.logits_last.argmax()) == int(ref[0, 0].argmax())
 
 
 def test_c3_size_properties(ops):

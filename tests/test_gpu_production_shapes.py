@@ -1,0 +1,292 @@
+"""-m gpu: the PRODUCTION kernels at PRODUCTION shapes against fp32 references computed on the device.
+
+What the step actually runs (profiles/README.md): `gemm_stagger_kernel` 256x256 for every Llama projection and SigLIP qkv / fc1
+(M = 7187 = 28 x 256 + 19 rows -> the tail row-tile with its padding-block skip; M = 28392), the 256x128 3-slot ring for SigLIP
+fc2, 128x128 for out_proj / patch embedding, and `attn_fwd_dma_kernel` at S = 7187 (d = 128, causal GQA) and 42 x 676 (d = 72).
+The small shapes of tests/test_gpu_kernels.py dispatch to the small-M ring and never reach those kernels, so here every geometry /
+schedule (`gemm.config` 0..8) is forced on every epilogue at M in {7187, 28392, 566}, repeated to catch a schedule hazard (a race
+between the LDS-DMA ring and the fragment reads gives run-to-run differences or wrong tiles), and compared element by element
+with `a.float() @ w.float().T` (rocBLAS fp32 on the same 16-bit operand values: the only differences are summation order and
+the output rounding)."""
+import pytest
+import torch
+
+from leopard_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DTYPES = [torch.float16, torch.bfloat16]
+# 0-4 ring geometries (128x128/2, 256x256/2, 256x128/3, 256x128/2, 128x256/3), 5-7 staggered 256x256 variants, 8 small-M ring
+ALL_CFGS = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from leopard_amd.ops import Ops
+    o = Ops()
+    yield o
+    o.set_option("gemm.config", -1)
+
+
+def eps(dtype):
+    return 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+
+
+_cache = {}
+
+
+def operands(M, N, K, dtype, scale_w):
+    """Device-generated operands (one set per shape and dtype, reused across configs)."""
+    key = (M, N, K, dtype)
+    if key not in _cache:
+        if len(_cache) > 2:
+            _cache.clear()
+            torch.cuda.empty_cache()
+        g = torch.Generator(device=DEV).manual_seed(M * 7 + N * 3 + K)
+        a = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+        w = (torch.randn(N, K, generator=g, device=DEV) * scale_w).to(dtype)
+        bias = torch.randn(N, generator=g, device=DEV)
+        ref = a.float() @ w.float().T
+        _cache[key] = (a, w, bias, ref)
+    return _cache[key]
+
+
+def rel_err(out, ref):
+    return ((out.float() - ref).abs() / (1.0 + ref.abs())).max().item()
+
+
+def run3(fn):
+    """Three launches: results must be bit-identical (a DMA/read race shows up as run-to-run differences)."""
+    o0 = fn()
+    for _ in range(2):
+        assert torch.equal(fn(), o0), "two launches of the same GEMM differ"
+    return o0
+
+
+# (name, M, N, K): the GEMM shapes of the C3 step and of the mid configuration (S = 566: three row tiles)
+LLAMA_SHAPES = [("qkv", 7187, 6144, 4096), ("o_proj", 7187, 4096, 4096), ("down", 7187, 4096, 14336), ("qkv_mid", 566, 6144, 4096)]
+SIGLIP_SHAPES = [("vit_qkv", 28392, 3456, 1152), ("vit_out", 28392, 1152, 1152), ("vit_fc2", 28392, 1152, 4352),
+                 ("patch", 28392, 1152, 640)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", ALL_CFGS)
+@pytest.mark.parametrize("shape", LLAMA_SHAPES + SIGLIP_SHAPES, ids=lambda s: s[0])
+def test_gemm_store_and_residual_every_config(ops, dtype, cfg, shape):
+    """EPI_STORE (+bias) and EPI_RESIDUAL (fp32 +=) on every geometry / schedule."""
+    _, M, N, K = shape
+    a, w, bias, ref = operands(M, N, K, dtype, 0.02)
+    ops.set_option("gemm.config", cfg)
+    try:
+        out = torch.empty(M, N, dtype=dtype, device=DEV)
+
+        def store():
+            out.fill_(float("nan"))
+            ops.gemm(a, w, out, bias=bias)
+            return out.clone()
+        o = run3(store)
+        e = rel_err(o, ref + bias)
+        assert e <= 3 * eps(dtype), f"STORE cfg {cfg} {shape}: {e:.3e}"
+        x0 = torch.randn(M, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+
+        def resid():
+            x = x0.clone()
+            ops.gemm(a, w, x, bias=bias, epilogue=_lib.EPI_RESIDUAL)
+            return x
+        x = run3(resid)
+        # fp32 output: only the summation order differs from the reference
+        assert (x - (x0 + ref + bias)).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), f"RESID cfg {cfg} {shape}"
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", ALL_CFGS)
+@pytest.mark.parametrize("M", [7187, 566])
+def test_gemm_swiglu_gate_up_every_config(ops, dtype, cfg, M):
+    """The dominant kernel of the step: Llama gate/up + SwiGLU, N = 28672 interleaved rows, K = 4096."""
+    from leopard_amd.weights import interleave_gate_up
+    F, K = 14336, 4096
+    a, w, _, ref = operands(M, 2 * F, K, dtype, 0.02)                  # rows 0..F-1 = gate, F..2F-1 = up
+    wi = interleave_gate_up(w[:F], w[F:])
+    want = torch.nn.functional.silu(ref[:, :F]) * ref[:, F:]
+    ops.set_option("gemm.config", cfg)
+    try:
+        out = torch.empty(M, F, dtype=dtype, device=DEV)
+
+        def go():
+            out.fill_(float("nan"))
+            ops.gemm(a, wi, out, epilogue=_lib.EPI_SWIGLU)
+            return out.clone()
+        o = run3(go)
+        e = rel_err(o, want)
+        assert e <= 3 * eps(dtype), f"SWIGLU cfg {cfg} M {M}: {e:.3e}"
+    finally:
+        ops.set_option("gemm.config", -1)
+        del wi
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", ALL_CFGS)
+def test_gemm_activations_store_f32_addmat_every_config(ops, dtype, cfg):
+    """SigLIP fc1 (GELU-tanh, N padded 4304 -> 4352), the projector's GELU-erf, and the patch-embedding epilogue
+    (fp32 store + bias + position-table row m % 676) at M = 28392."""
+    M = 28392
+    a, w, bias, ref = operands(M, 4352, 1152, dtype, 0.02)
+    ops.set_option("gemm.config", cfg)
+    try:
+        out = torch.empty(M, 4352, dtype=dtype, device=DEV)
+        ops.gemm(a, w, out, bias=bias, act=_lib.ACT_GELU_TANH)
+        e = rel_err(out, torch.nn.functional.gelu(ref + bias, approximate="tanh"))
+        assert e <= 3 * eps(dtype), f"GELU-tanh cfg {cfg}: {e:.3e}"
+        ops.gemm(a, w, out, bias=bias, act=_lib.ACT_GELU_ERF)
+        e = rel_err(out, torch.nn.functional.gelu(ref + bias))
+        assert e <= 3 * eps(dtype), f"GELU-erf cfg {cfg}: {e:.3e}"
+        del out
+        a, w, bias, ref = operands(M, 1152, 640, dtype, 0.02)
+        pos = torch.randn(676, 1152, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+        o32 = torch.full((M, 1152), float("nan"), device=DEV)
+        ops.gemm(a, w, o32, bias=bias, addmat=pos, epilogue=_lib.EPI_STORE_F32)
+        want = ref + bias + pos[torch.arange(M, device=DEV) % 676]
+        assert (o32 - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()), f"STORE_F32+addmat cfg {cfg}"
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", ALL_CFGS)
+def test_gemm_pixel_shuffle_42_tiles_every_config(ops, dtype, cfg):
+    """Projector linear_1 at the C3 size: A gathered through the 2x2 pixel shuffle from the ViT output of 42 tiles
+    (M = 42 x 169 = 7098 shuffled rows, K = 4 x 1152), GELU-erf."""
+    tiles, G, C, N = 42, 26, 1152, 4096
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randn(tiles * G * G, C, generator=g, device=DEV).to(dtype)
+    w = (torch.randn(N, 4 * C, generator=g, device=DEV) * 0.02).to(dtype)
+    bias = torch.randn(N, generator=g, device=DEV)
+    # closed form of EVAL:165-176: out[n, ph*13 + pw, (dh*2 + dw)*C + c] = x[n, (2ph + dh)*26 + 2pw + dw, c]
+    shuf = x.view(tiles, G // 2, 2, G // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(tiles * 169, 4 * C)
+    want = torch.nn.functional.gelu(shuf.float() @ w.float().T + bias)
+    ops.set_option("gemm.config", cfg)
+    try:
+        out = torch.full((tiles * 169, N), float("nan"), dtype=dtype, device=DEV)
+        ops.gemm(x, w, out, bias=bias, act=_lib.ACT_GELU_ERF, a_mode=_lib.A_PIXEL_SHUFFLE, ps_grid=G, M=tiles * 169)
+        e = rel_err(out, want)
+        assert e <= 3 * eps(dtype), f"PIXSHUF cfg {cfg}: {e:.3e}"
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
+def test_gemm_row_map_and_add_rows_at_full_m(ops):
+    """Row scatter (row_map) and indexed position rows (add_rows) at M = 7187 on the production schedule."""
+    dtype = torch.float16
+    M, N, K = 7187, 4096, 4096
+    a, w, bias, ref = operands(M, N, K, dtype, 0.02)
+    perm = torch.randperm(M + 77, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))[:M].to(torch.int32)
+    big = torch.zeros(M + 77, N, device=DEV)
+    ops.gemm(a, w, big, bias=bias, row_map=perm, epilogue=_lib.EPI_STORE_F32)
+    assert (big[perm.long()] - (ref + bias)).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    untouched = torch.ones(M + 77, dtype=torch.bool, device=DEV)
+    untouched[perm.long()] = False
+    assert big[untouched].abs().max().item() == 0
+    table = torch.randn(4900, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    idx = torch.randint(0, 4900, (M,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).to(torch.int32)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(a, w, out, bias=bias, addmat=table, add_rows=idx, epilogue=_lib.EPI_STORE_F32)
+    assert (out - (ref + bias + table[idx.long()])).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+# ---- attention at the production sizes ------------------------------------------------------------------------------------
+def sampled_rows(S):
+    """Query rows that matter: first / last rows, every 128-row workgroup edge and 64-key tile edge region sampled, the tail."""
+    rows = set([0, 1, 31, 32, 63, 64, 65, 127, 128, 129, S - 1, S - 2, S - 19, S - 20, S - 33, S - 64, S - 65, S - 128, S - 129])
+    g = torch.Generator().manual_seed(S)
+    rows |= set(int(r) for r in torch.randint(0, S, (420,), generator=g))
+    rows |= set(range(4096 - 3, 4096 + 3)) | set(range(7168 - 2, min(S, 7168 + 2)))
+    return torch.tensor(sorted(r for r in rows if 0 <= r < S), device=DEV)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("window", [0, 4096])
+def test_attention_llama_s7187_vs_fp32_on_sampled_rows(ops, dtype, window):
+    """attn_fwd_dma_kernel<128, causal>, S = 7187, 32 q / 8 kv heads (the C3 Llama attention; window = 4096 is the Mistral
+    sliding window of the Idefics2 path): ~500 query rows x all heads against an fp32 softmax(QK^T)V over their full key range."""
+    H, KV, D, S = 32, 8, 128, 7187
+    g = torch.Generator(device=DEV).manual_seed(70)
+    qkv = torch.randn(S, (H + 2 * KV) * D, generator=g, device=DEV).to(dtype)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    cu = torch.tensor([0, S], dtype=torch.int32, device=DEV)
+    out = torch.full((S, H * D), float("nan"), dtype=dtype, device=DEV)
+    ops.attention(q, k, v, out, cu, cu, S, H, KV, D, D ** -0.5, True, True, window=window)
+    assert torch.isfinite(out.float()).all()
+    rows = sampled_rows(S)
+    qs = q[rows].float().view(-1, H, D).transpose(0, 1)                                   # [H, R, D]
+    ks = k.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)           # [H, S, D]
+    vs = v.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+    sc = qs @ ks.transpose(-1, -2) * D ** -0.5
+    keys = torch.arange(S, device=DEV)[None, :]
+    vis = keys <= rows[:, None]
+    if window:
+        vis &= rows[:, None] - keys < window
+    sc = sc.masked_fill(~vis[None], float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(len(rows), H * D)
+    err = (out[rows].float() - ref).abs().max().item()
+    assert err <= 3 * eps(dtype), f"S=7187 causal window={window}: {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_siglip_42_tiles_vs_fp32(ops, dtype):
+    """attn_fwd_dma_kernel<72>, 42 sequences of 676 tokens, 16 heads x 72 (the C3 SigLIP attention), every row."""
+    H, D, n, T = 16, 72, 42, 676
+    g = torch.Generator(device=DEV).manual_seed(71)
+    qkv = torch.randn(n * T, 3 * H * D, generator=g, device=DEV).to(dtype)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    cu = torch.arange(0, (n + 1) * T, T, dtype=torch.int32, device=DEV)
+    out = torch.full((n * T, H * D), float("nan"), dtype=dtype, device=DEV)
+    ops.attention(q, k, v, out, cu, cu, T, H, H, D, D ** -0.5, False, True)
+    qs = q.float().view(n, T, H, D).permute(0, 2, 1, 3)
+    ks = k.float().view(n, T, H, D).permute(0, 2, 1, 3)
+    vs = v.float().view(n, T, H, D).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qs @ ks.transpose(-1, -2) * D ** -0.5, -1) @ vs).permute(0, 2, 1, 3).reshape(n * T, H * D)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 3 * eps(dtype), f"42 x 676 d=72: {err:.3e}"
+
+
+def test_attention_deferred_rescale_branch_is_forced(ops):
+    """cdna guide rule 26: the deferred-rescale branch (reference moves only when a row outgrows it by 2^8) is rare on random
+    data, so force it: one key late in the sequence scores far above everything before it for a few query rows."""
+    H, KV, D, S = 32, 8, 128, 1500
+    dtype = torch.float16
+    g = torch.Generator(device=DEV).manual_seed(72)
+    qkv = (torch.randn(S, (H + 2 * KV) * D, generator=g, device=DEV) * 0.5).to(dtype)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    # key 900 of kv head 0 is aligned with query rows 1000..1003 of heads 0..3 (score ~ +28 after scaling, the others |s| < 10)
+    for r in range(1000, 1004):
+        q[r, :4 * D] = k[900, :D].repeat(4) * 10
+    cu = torch.tensor([0, S], dtype=torch.int32, device=DEV)
+    out = torch.empty(S, H * D, dtype=dtype, device=DEV)
+    ops.attention(q, k, v, out, cu, cu, S, H, KV, D, D ** -0.5, True, True)
+    qs = q.float().view(S, H, D).transpose(0, 1)
+    ks = k.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+    vs = v.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0)
+    sc = qs @ ks.transpose(-1, -2) * D ** -0.5
+    mask = torch.arange(S, device=DEV)[None, :] <= torch.arange(S, device=DEV)[:, None]
+    ref = (torch.softmax(sc.masked_fill(~mask[None], float("-inf")), -1) @ vs).transpose(0, 1).reshape(S, H * D)
+    assert sc[0, 1000, 900].item() - sc[0, 1000, :900].max().item() > 12        # the spike really outgrows the running max
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 3 * eps(dtype), f"forced rescale: {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lm_head_last_vs_fp32(ops, dtype):
+    """lmi_lm_head_last at the Llama-3.1 vocabulary: 3 selected rows, fp32 normalised row x 16-bit weights."""
+    N, K = 128256, 4096
+    g = torch.Generator(device=DEV).manual_seed(80)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.02).to(dtype)
+    x = torch.randn(50, K, generator=g, device=DEV) * 3
+    gamma = torch.rand(K, generator=g, device=DEV) + 0.5
+    rows = torch.tensor([49, 0, 17], device=DEV)
+    out = torch.full((3, N), float("nan"), device=DEV)
+    ops.lm_head_last(w, x, rows, gamma, 1e-5, out)
+    xn = gamma * (x[rows] * torch.rsqrt(x[rows].pow(2).mean(-1, keepdim=True) + 1e-5))
+    ref = (xn.double() @ w.double().T)
+    assert (out.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
