@@ -38,7 +38,8 @@ enum {
     LMI_EPI_STORE = 0,    /* out[T]   = act(acc + bias)                                   */
     LMI_EPI_RESIDUAL = 1, /* out[f32] += acc + bias            (residual stream update)   */
     LMI_EPI_STORE_F32 = 2,/* out[f32] = acc + bias + addmat[row % add_period]             */
-    LMI_EPI_SWIGLU = 3    /* out[T][:, N/2] = silu(gate) * up, W rows interleaved [32 gate | 32 up] */
+    LMI_EPI_SWIGLU = 3,   /* out[T][:, N/2] = silu(gate) * up, W rows interleaved [32 gate | 32 up] */
+    LMI_EPI_QKV_ROPE = 4  /* q | k | v projection + RoPE + KV-cache append (lmi_rmsnorm_rope only) */
 };
 enum { LMI_ACT_NONE = 0, LMI_ACT_GELU_TANH = 1, LMI_ACT_GELU_ERF = 2 };
 enum { LMI_A_PLAIN = 0, LMI_A_PIXEL_SHUFFLE = 1 };
@@ -105,6 +106,33 @@ int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx
 int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
              const int* row_map, int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
              int ps_grid, int dtype, void* stream);
+
+/* RMSNorm folded into the GEMMs around it (north_star "fused RMSNorm + RoPE"; RMSNorm = megatron/legacy/model/rms_norm.py:26-31,
+ * call sites megatron_patch/model/llava/transformer.py:1208-1340).  lmi_gemm restricted to plain A, plus:
+ *   producer (epilogue LMI_EPI_RESIDUAL, norm_out != null): after x += acc + bias it also writes
+ *       norm_out[m, n]    = T(x[m, n] * norm_gamma[n])            (the next RMSNorm's gain applied, its row scale still missing)
+ *       rowsq_out[m, n/64] = sum of x[m, 64*(n/64) .. +63]^2       (N/64 partials per row; no atomics: bit-reproducible)
+ *   consumer (any epilogue, rowsq_in != null): accumulator row m is multiplied by
+ *       rstd[m] = rsqrt(sum_j rowsq_in[m, j] / norm_dim + norm_eps)  before bias / activation / SwiGLU,
+ *   which completes the norm:  (x * gamma) . W^T * rstd == (gamma * x * rstd) . W^T.  One 16-bit rounding of the operand, as
+ *   with lmi_rmsnorm, but no norm launch and no separate pass over the fp32 stream. */
+int lmi_gemm_ex(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
+                const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, const float* norm_gamma, float* rowsq_out,
+                int ld_norm, int dtype, void* stream);
+
+/* SURVEY.md 8(b) "lmi_rmsnorm_rope" — the q | k | v projection of a Llama / Mistral layer with the RMSNorm's row scale, the
+ * rotary embedding and the KV-cache append all in the GEMM's epilogue (RoPE: rotary_pos_embedding.py:197-239 rotate-half;
+ * call site megatron_patch/model/llava/transformer.py:838-856):
+ *     qkv[m] = [ RoPE(q), RoPE(k), v ]   with  (q | k | v) = rstd[m] * (A[m] . Wqkv^T),
+ * rstd from rowsq_in as in lmi_gemm_ex (rowsq_in null: A is already normalised, e.g. by lmi_rmsnorm for the first layer).
+ * The rotation acts on the fp32 accumulators: q and k are rounded to T once, not twice.
+ * Wqkv: [(n_q + 2 n_kv) * 128, K]; the 128 rows of every q and k head must be stored in the order
+ * d = 0..31, 64..95, 32..63, 96..127 (leopard_amd.weights.rope_permute_rows), so that the 64 output columns a wave owns hold 32
+ * first-half elements and their rotate-half partners; the epilogue restores the natural order on store.  cos/sin: fp32
+ * [M, 64] per packed row.  k_cache / v_cache (nullable): rotated K and V also go to cache rows cache_pos0 + m.  head_dim = 128. */
+int lmi_rmsnorm_rope(const void* A, const void* Wqkv, void* qkv, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_table,
+                     const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads,
+                     int head_dim, int K, int lda, int ldw, int ldo, int dtype, void* stream);
 
 /* Variable-length FlashAttention-2 forward over packed sequences (SigLIP: non-causal, head_dim 72, one
  * sequence per tile; Llama / Mistral: causal GQA, head_dim 128, optional sliding window; Idefics2 perceiver: head_dim 96,

@@ -149,6 +149,9 @@ int dispatch_gemm(const GemmArgs& a, int epi, int act, int amode, void* stream) 
         case LMI_EPI_SWIGLU:
             if (act == LMI_ACT_NONE) return launch_gemm<T, EPI_SWIGLU_T, ACT_NONE, AMODE_PLAIN>(a, stream);
             break;
+        case LMI_EPI_QKV_ROPE:
+            if (act == LMI_ACT_NONE) return launch_gemm<T, EPI_QKV_ROPE_T, ACT_NONE, AMODE_PLAIN>(a, stream);
+            break;
     }
     return fail(LMI_EINVAL, "lmi_gemm: unsupported epilogue/act combination (%d, %d)", epi, act);
 }
@@ -403,37 +406,87 @@ int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx
                    (norm_impl<bf16_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm")));
 }
 
-int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
-             const int* row_map,
-             int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
-             int ps_grid, int dtype, void* stream) {
-    if (!A || !W || !out) return fail(LMI_EINVAL, "lmi_gemm: null pointer");
+// everything lmi_gemm / lmi_gemm_ex / lmi_rmsnorm_rope share: argument checks, buffer extents, dispatch
+struct GemmExtras {
+    const float* rowsq_in = nullptr; int rowsq_parts = 0; int norm_dim = 0; float norm_eps = 0.f;
+    void* norm_out = nullptr; const float* norm_gamma = nullptr; float* rowsq_out = nullptr; int ld_norm = 0;
+    const float* rope_cos = nullptr; const float* rope_sin = nullptr; void* k_cache = nullptr; void* v_cache = nullptr;
+    int ld_cache = 0, cache_pos0 = 0, rope_q = 0, rope_k = 0;
+};
+static int gemm_entry(const char* who, const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
+                      const int* row_map, int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
+                      int ps_grid, int dtype, void* stream, const GemmExtras& x) {
+    if (!A || !W || !out) return fail(LMI_EINVAL, "%s: null pointer", who);
     if (M < 0 || N <= 0 || K <= 0 || (N % 128) || (K % GEMM_BK))
-        return fail(LMI_EINVAL, "lmi_gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+        return fail(LMI_EINVAL, "%s: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", who, M, N, K);
     if ((lda & 7) || (ldw & 7) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out) ||
         (bias && !aligned16(bias)) || (addmat && !aligned16(addmat)))
-        return fail(LMI_EINVAL, "lmi_gemm: pointers must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
-    if (addmat && !add_rows && add_period <= 0) return fail(LMI_EINVAL, "lmi_gemm: addmat needs add_period > 0 or add_rows");
+        return fail(LMI_EINVAL, "%s: pointers must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4", who);
+    if (addmat && !add_rows && add_period <= 0) return fail(LMI_EINVAL, "%s: addmat needs add_period > 0 or add_rows", who);
     if (a_mode == LMI_A_PIXEL_SHUFFLE) {
         if (ps_grid <= 0 || (ps_grid & 1) || (K & 3) || ((K / 4) % GEMM_BK) || (M % ((ps_grid / 2) * (ps_grid / 2))))
-            return fail(LMI_EINVAL, "lmi_gemm: pixel-shuffle needs even grid, (K/4) %% 64 == 0, M %% (G/2)^2 == 0");
+            return fail(LMI_EINVAL, "%s: pixel-shuffle needs even grid, (K/4) %% 64 == 0, M %% (G/2)^2 == 0", who);
     } else if (a_mode != LMI_A_PLAIN) {
-        return fail(LMI_EINVAL, "lmi_gemm: bad a_mode %d", a_mode);
+        return fail(LMI_EINVAL, "%s: bad a_mode %d", who, a_mode);
     }
+    if (x.rowsq_in && (x.rowsq_parts <= 0 || x.norm_dim <= 0 || !aligned16(x.rowsq_in)))
+        return fail(LMI_EINVAL, "%s: rowsq_in needs rowsq_parts > 0, norm_dim > 0 and 16-byte alignment", who);
+    if (x.norm_out && (epilogue != LMI_EPI_RESIDUAL || !x.norm_gamma || !x.rowsq_out || (x.ld_norm & 7) || x.ld_norm < N || row_map ||
+                       !aligned16(x.norm_out) || !aligned16(x.norm_gamma)))
+        return fail(LMI_EINVAL, "%s: norm_out needs the RESIDUAL epilogue, norm_gamma, rowsq_out, ld_norm %% 8 == 0 and no row_map", who);
     if (M == 0) return LMI_OK;
     GemmArgs a;
     a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.add_rows = add_rows; a.row_map = row_map;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
+    a.norm_out = x.norm_out; a.norm_gamma = x.norm_gamma; a.rowsq_out = x.rowsq_out; a.ld_norm = x.ld_norm;
+    a.rowsq_in = x.rowsq_in; a.rowsq_parts = x.rowsq_parts; a.norm_dim = x.norm_dim; a.norm_eps = x.norm_eps;
+    a.rope_cos = x.rope_cos; a.rope_sin = x.rope_sin; a.k_cache = x.k_cache; a.v_cache = x.v_cache;
+    a.ld_cache = x.ld_cache; a.cache_pos0 = x.cache_pos0; a.rope_q = x.rope_q; a.rope_k = x.rope_k;
     // extents for the buffer resources the LDS-DMA reads through (32-bit offsets)
     const long a_rows = (a_mode == LMI_A_PIXEL_SHUFFLE) ? (long)(M / ((ps_grid / 2) * (ps_grid / 2))) * ps_grid * ps_grid : (long)M;
     const long a_cols = (a_mode == LMI_A_PIXEL_SHUFFLE) ? K / 4 : K;
     const long a_bytes = a_rows > 0 ? ((a_rows - 1) * lda + a_cols) * 2 : 0, w_bytes = ((long)(N - 1) * ldw + K) * 2;
     if (a_bytes >= (1L << 32) || w_bytes >= (1L << 32))
-        return fail(LMI_EINVAL, "lmi_gemm: operand extent >= 4 GiB (A %ld, W %ld bytes)", a_bytes, w_bytes);
+        return fail(LMI_EINVAL, "%s: operand extent >= 4 GiB (A %ld, W %ld bytes)", who, a_bytes, w_bytes);
     a.a_bytes = (unsigned)a_bytes; a.w_bytes = (unsigned)w_bytes;
-    if (M == 0) return LMI_OK;
     LMI_DISPATCH_T(dtype, dispatch_gemm<f16_t>(a, epilogue, act, a_mode, stream),
                    dispatch_gemm<bf16_t>(a, epilogue, act, a_mode, stream));
+}
+
+int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
+             const int* row_map,
+             int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
+             int ps_grid, int dtype, void* stream) {
+    if (epilogue == LMI_EPI_QKV_ROPE) return fail(LMI_EINVAL, "lmi_gemm: the q|k|v + RoPE epilogue is reached through lmi_rmsnorm_rope");
+    return gemm_entry("lmi_gemm", A, W, out, bias, addmat, add_rows, row_map, M, N, K, lda, ldw, ldo, add_period, epilogue, act, a_mode, ps_grid,
+                      dtype, stream, GemmExtras());
+}
+
+int lmi_gemm_ex(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
+                const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, const float* norm_gamma, float* rowsq_out,
+                int ld_norm, int dtype, void* stream) {
+    if (epilogue == LMI_EPI_QKV_ROPE) return fail(LMI_EINVAL, "lmi_gemm_ex: the q|k|v + RoPE epilogue is reached through lmi_rmsnorm_rope");
+    GemmExtras x;
+    x.rowsq_in = rowsq_in; x.rowsq_parts = rowsq_parts; x.norm_dim = norm_dim; x.norm_eps = norm_eps;
+    x.norm_out = norm_out; x.norm_gamma = norm_gamma; x.rowsq_out = rowsq_out; x.ld_norm = ld_norm;
+    return gemm_entry("lmi_gemm_ex", A, W, out, bias, nullptr, nullptr, nullptr, M, N, K, lda, ldw, ldo, 0, epilogue, act, LMI_A_PLAIN, 0, dtype,
+                      stream, x);
+}
+
+int lmi_rmsnorm_rope(const void* A, const void* Wqkv, void* qkv, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_table,
+                     const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads,
+                     int head_dim, int K, int lda, int ldw, int ldo, int dtype, void* stream) {
+    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_rmsnorm_rope: head_dim %d (only 128: a wave's 64 columns hold half a head)", head_dim);
+    if (!cos_table || !sin_table || n_q_heads <= 0 || n_kv_heads <= 0 || ((k_cache != nullptr) != (v_cache != nullptr)) ||
+        (k_cache && ((ld_cache & 7) || !aligned16(k_cache) || !aligned16(v_cache))) || (ldo & 7) || !aligned16(cos_table) || !aligned16(sin_table))
+        return fail(LMI_EINVAL, "lmi_rmsnorm_rope: bad argument");
+    GemmExtras x;
+    x.rowsq_in = rowsq_in; x.rowsq_parts = rowsq_parts; x.norm_dim = K; x.norm_eps = norm_eps;
+    x.rope_cos = cos_table; x.rope_sin = sin_table; x.k_cache = k_cache; x.v_cache = v_cache; x.ld_cache = ld_cache; x.cache_pos0 = cache_pos0;
+    x.rope_q = n_q_heads * head_dim; x.rope_k = n_kv_heads * head_dim;
+    const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
+    return gemm_entry("lmi_rmsnorm_rope", A, Wqkv, qkv, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldw, ldo, 0, LMI_EPI_QKV_ROPE, LMI_ACT_NONE,
+                      LMI_A_PLAIN, 0, dtype, stream, x);
 }
 
 int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,

@@ -31,7 +31,7 @@
 
 namespace lmi {
 
-enum { EPI_STORE_T = 0, EPI_RESID_F32 = 1, EPI_STORE_F32 = 2, EPI_SWIGLU_T = 3 };
+enum { EPI_STORE_T = 0, EPI_RESID_F32 = 1, EPI_STORE_F32 = 2, EPI_SWIGLU_T = 3, EPI_QKV_ROPE_T = 4 };
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
 enum { AMODE_PLAIN = 0, AMODE_PIXSHUF = 1 };
 
@@ -50,6 +50,30 @@ struct GemmArgs {
     int group_m;          // row-tiles per L2 group in the XCD-aware tile order
     int order;            // 0 = each XCD owns a contiguous slab of the grouped order; 1 = XCDs take 32-tile chunks round-robin
     unsigned a_bytes, w_bytes;   // extents of A and W (buffer resources of the LDS-DMA; both < 4 GiB)
+    // ---- RMSNorm folded into the GEMMs around it (Llama / Mistral layers) ---------------------------------------------------
+    // producer (EPI_RESID_F32): besides x += acc, write norm_out[m, n] = T(x[m, n] * norm_gamma[n]) — the NEXT RMSNorm's gain
+    // applied, its row scale still missing — and rowsq_out[m, n / 64] = sum of x[m, n..n+63]^2 (one partial per wave column
+    // range: no atomics, bit-reproducible).  consumer (any epilogue): rowsq_in != null -> the accumulator row m is multiplied
+    // by rstd[m] = rsqrt(sum_j rowsq_in[m, j] / norm_dim + norm_eps) first, which completes the RMSNorm the producer started:
+    // (x * gamma) . W^T * rstd == (gamma * x * rstd) . W^T.
+    void* norm_out;
+    const float* norm_gamma;
+    float* rowsq_out;
+    int ld_norm;
+    const float* rowsq_in;
+    int rowsq_parts;             // partials per row of rowsq_in (= norm_dim / 64)
+    int norm_dim;
+    float norm_eps;
+    // ---- EPI_QKV_ROPE_T: q | k | v projection with RoPE and the KV-cache append in the epilogue ------------------------------
+    // W rows of every q / k head are stored in the order d = [0..31, 64..95, 32..63, 96..127] (weights.rope_permute_rows) so that
+    // a wave's 64 output columns hold 32 "first half" elements and their 32 rotate-half partners; the epilogue un-permutes on
+    // store.  cos / sin: fp32 [M, head_dim / 2] per packed row.  Columns [0, rope_q) are q heads, [rope_q, rope_q + rope_k)
+    // k heads, the rest v (copied; appended to v_cache).  k_cache / v_cache rows cache_pos0 + m (nullable).
+    const float* rope_cos;
+    const float* rope_sin;
+    void* k_cache;
+    void* v_cache;
+    int ld_cache, cache_pos0, rope_q, rope_k;
 };
 
 constexpr int GEMM_BK = 64;
@@ -134,6 +158,28 @@ LMI_DEV bool gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, in
 // guarantees that no other wave still reads k-tiles from `stage`.
 // `put(mi, stage)` writes rows mi*32 .. mi*32+31 of the wave tile into the image (it depends on the MFMA shape's accumulator layout).
 template <int WTN> struct GemmImage { static constexpr int RS = WTN * 4 + 16; };   // LDS row stride of the fp32 image
+
+// rstd of row m from the producer's partial sums of squares.  The LPR lanes that share an output row split the partials
+// between them and meet with xor-shuffles (LPR is a power of two and the lanes of a row are consecutive), so every lane of
+// the row ends up with the same, order-deterministic sum.
+template <int LPR>
+LMI_DEV float gemm_row_rstd(const GemmArgs& p, int m, int lane) {
+    const float* part = p.rowsq_in + (long)m * p.rowsq_parts;
+    float s = 0.f;
+    const int li = lane % LPR;
+    if ((p.rowsq_parts % (4 * LPR)) == 0) {
+        const int per = p.rowsq_parts / LPR;                                 // contiguous floats per lane, a multiple of 4
+        for (int j = 0; j < per; j += 4) {
+            const f32x4 v = *(const f32x4*)(part + li * per + j);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    } else {
+        for (int j = li; j < p.rowsq_parts; j += LPR) s += part[j];
+    }
+#pragma unroll
+    for (int msk = 1; msk < LPR; msk <<= 1) s += shfl_xor(s, msk);
+    return 1.0f / sqrtf(s / (float)p.norm_dim + p.norm_eps);
+}
 template <typename T, int EPI, int ACT, typename C, typename Put>
 LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, int wn, int lane, char* stage) {
     typedef typename vec_of<T>::x8 T8;
@@ -141,18 +187,20 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
     static_assert(32 * RS <= C::SMEM / (C::NT / 64), "per-wave LDS slice too small for the epilogue image");
     const int nw0 = n0 + wn * C::WTN;                                   // first column of this wave
     if (nw0 >= p.N) return;                                             // N % 128 == 0 and WTN | 128: all or nothing
-    constexpr int OUT_COLS = (EPI == EPI_SWIGLU_T) ? C::WTN / 2 : C::WTN;
+    constexpr bool PAIRED = (EPI == EPI_SWIGLU_T || EPI == EPI_QKV_ROPE_T);   // a lane reads two 8-column pieces 32 columns apart
+    constexpr int OUT_COLS = PAIRED ? C::WTN / 2 : C::WTN;
     constexpr int LPR = OUT_COLS / 8, RPI = 64 / LPR, ITERS = 32 / RPI; // lanes per row, rows per instruction
     const int r_in = lane / LPR;
     // 8 lanes per 64-column row (every production geometry, plain epilogues): rotating the lanes' column groups by one on
     // rows 2, 3, 6, 7 of an instruction makes each of ds_read_b128's four lane groups hit 16 distinct 16-byte slots (with
     // lane -> column fixed, rows two apart share slots: 2-way conflicts, 4.5 % of the ring kernels' LDS cycles by PMC).
     // A row is still covered by 8 consecutive lanes, so stores stay whole 128/256-byte row segments.
-    const int oc = ((LPR == 8 && EPI != EPI_SWIGLU_T) ? ((lane + 7 * ((r_in >> 1) & 1)) & 7) : (lane % LPR)) * 8;
-    // source columns of this lane in the image: plain = oc..oc+7; SwiGLU = gate block, up block 32 columns further
-    const int sc = (EPI == EPI_SWIGLU_T) ? (oc >> 5) * 64 + (oc & 31) : oc;
+    const int oc = ((LPR == 8 && !PAIRED) ? ((lane + 7 * ((r_in >> 1) & 1)) & 7) : (lane % LPR)) * 8;
+    // source columns of this lane in the image: plain = oc..oc+7; SwiGLU = gate block, up block 32 columns further;
+    // RoPE = first-half block, rotate-half partner block 32 columns further
+    const int sc = PAIRED ? (oc >> 5) * 64 + (oc & 31) : oc;
     f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
-    if (EPI != EPI_SWIGLU_T && p.bias) {
+    if (!PAIRED && p.bias) {
         bias0 = *(const f32x4*)(p.bias + nw0 + oc);
         bias1 = *(const f32x4*)(p.bias + nw0 + oc + 4);
     }
@@ -162,13 +210,68 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
         if (mb >= p.M) break;
         put(mi, stage);
         wave_lds_fence();
+        if (EPI == EPI_QKV_ROPE_T) {
+            // wave-uniform: which of q | k | v this wave's 64 columns belong to, and which half-block of its head
+            const bool is_v = nw0 >= p.rope_q + p.rope_k, is_k = !is_v && nw0 >= p.rope_q;
+            const int hb = (nw0 >> 6) & 1;                              // 64-column block inside the 128-wide head
+            const int hbase = nw0 & ~127;                               // first column of the head
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int row = it * RPI + r_in, m = mb + row;
+                const int mc = imin(m, p.M - 1);
+                const char* src = stage + row * RS + sc * 4;
+                f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 16);
+                f32x4 b0 = *(const f32x4*)(src + 128), b1 = *(const f32x4*)(src + 144);
+                if (p.rowsq_in) {
+                    const float rstd = gemm_row_rstd<LPR>(p, mc, lane);
+                    a0 *= rstd; a1 *= rstd; b0 *= rstd; b1 *= rstd;
+                }
+                T8 o1, o2;
+                int c1, c2;                                             // destination columns of the two 8-wide pieces
+                if (is_v) {                                             // v: natural order, plain copy
+                    c1 = nw0 + oc; c2 = c1 + 32;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o1[e] = (T)a0[e]; o1[4 + e] = (T)a1[e]; o2[e] = (T)b0[e]; o2[4 + e] = (T)b1[e]; }
+                } else {                                                // q / k: rotate-half RoPE on the fp32 accumulators
+                    const int d1 = hb * 32 + oc;                        // 0..63: element of the first half; partner d1 + 64
+                    c1 = hbase + d1; c2 = c1 + 64;
+                    const float* cs = p.rope_cos + (long)mc * 64 + d1;
+                    const float* sn = p.rope_sin + (long)mc * 64 + d1;
+                    const f32x4 cs0 = *(const f32x4*)cs, cs1 = *(const f32x4*)(cs + 4);
+                    const f32x4 sn0 = *(const f32x4*)sn, sn1 = *(const f32x4*)(sn + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o1[e] = (T)(a0[e] * cs0[e] - b0[e] * sn0[e]);
+                        o1[4 + e] = (T)(a1[e] * cs1[e] - b1[e] * sn1[e]);
+                        o2[e] = (T)(b0[e] * cs0[e] + a0[e] * sn0[e]);
+                        o2[4 + e] = (T)(b1[e] * cs1[e] + a1[e] * sn1[e]);
+                    }
+                }
+                if (m < p.M) {
+                    T* orow_p = (T*)p.out + (long)m * p.ldo;
+                    *(T8*)(orow_p + c1) = o1;
+                    *(T8*)(orow_p + c2) = o2;
+                    if ((is_k || is_v) && p.k_cache) {
+                        T* crow = (T*)(is_k ? p.k_cache : p.v_cache) + (long)(p.cache_pos0 + m) * p.ld_cache - (is_k ? p.rope_q : p.rope_q + p.rope_k);
+                        *(T8*)(crow + c1) = o1;
+                        *(T8*)(crow + c2) = o2;
+                    }
+                }
+            }
+            wave_lds_fence();
+            continue;
+        }
         if (EPI == EPI_SWIGLU_T) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int row = it * RPI + r_in, m = mb + row;
                 const char* src = stage + row * RS + sc * 4;
-                const f32x4 g0 = *(const f32x4*)src, g1 = *(const f32x4*)(src + 16);
-                const f32x4 u0 = *(const f32x4*)(src + 128), u1 = *(const f32x4*)(src + 144);
+                f32x4 g0 = *(const f32x4*)src, g1 = *(const f32x4*)(src + 16);
+                f32x4 u0 = *(const f32x4*)(src + 128), u1 = *(const f32x4*)(src + 144);
+                if (p.rowsq_in) {
+                    const float rstd = gemm_row_rstd<LPR>(p, imin(m, p.M - 1), lane);
+                    g0 *= rstd; g1 *= rstd; u0 *= rstd; u1 *= rstd;
+                }
                 T8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -191,8 +294,14 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
             const int mc = imin(mb + row, p.M - 1);                       // clamped: loads are unconditional, stores masked
             orow[it] = p.row_map ? (long)p.row_map[mc] : (long)mc;
             const char* src = stage + row * RS + sc * 4;
-            v0[it] = *(const f32x4*)src + bias0;
-            v1[it] = *(const f32x4*)(src + 16) + bias1;
+            v0[it] = *(const f32x4*)src;
+            v1[it] = *(const f32x4*)(src + 16);
+            if (p.rowsq_in) {
+                const float rstd = gemm_row_rstd<LPR>(p, mc, lane);
+                v0[it] *= rstd; v1[it] *= rstd;
+            }
+            v0[it] += bias0;
+            v1[it] += bias1;
             if (p.addmat) {                                               // SigLIP position table (patch-embed GEMM only)
                 const float* arow = p.addmat + (long)(p.add_rows ? p.add_rows[mc] : mc % p.add_period) * p.N + nw0 + oc;
                 v0[it] += *(const f32x4*)arow;
@@ -211,6 +320,15 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v0[it][e] = act_apply(v0[it][e], ACT); v1[it][e] = act_apply(v1[it][e], ACT); }
             }
+            if (EPI == EPI_RESID_F32) { v0[it] += old0[it]; v1[it] += old1[it]; }
+            float sq = 0.f;
+            if (EPI == EPI_RESID_F32 && p.norm_out) {
+                // sum of squares of this wave's 64 columns of the updated row: the 8 lanes of a row are consecutive; every lane
+                // takes part (rows past M carry clamped duplicates and are not stored)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sq += v0[it][e] * v0[it][e] + v1[it][e] * v1[it][e];
+                sq += shfl_xor(sq, 1); sq += shfl_xor(sq, 2); sq += shfl_xor(sq, 4);
+            }
             if (mb + it * RPI + r_in >= p.M) continue;
             if (EPI == EPI_STORE_T) {
                 T8 o;
@@ -219,9 +337,17 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 *(T8*)((T*)p.out + orow[it] * p.ldo + nw0 + oc) = o;
             } else {
                 float* drow = (float*)p.out + orow[it] * p.ldo + nw0 + oc;
-                if (EPI == EPI_RESID_F32) { v0[it] += old0[it]; v1[it] += old1[it]; }
                 *(f32x4*)drow = v0[it];
                 *(f32x4*)(drow + 4) = v1[it];
+                if (EPI == EPI_RESID_F32 && p.norm_out) {
+                    // the next RMSNorm, started here: gain applied and rounded; its row scale is finished by the consumer GEMM
+                    const f32x4 g0 = *(const f32x4*)(p.norm_gamma + nw0 + oc), g1 = *(const f32x4*)(p.norm_gamma + nw0 + oc + 4);
+                    T8 hn;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hn[e] = (T)(v0[it][e] * g0[e]); hn[4 + e] = (T)(v1[it][e] * g1[e]); }
+                    *(T8*)((T*)p.norm_out + orow[it] * p.ld_norm + nw0 + oc) = hn;
+                    if ((lane & 7) == 0) p.rowsq_out[orow[it] * (long)(p.N >> 6) + (nw0 >> 6)] = sq;
+                }
             }
         }
     }

@@ -99,6 +99,7 @@ class LeopardEngine:
         self.device = torch.device(device) if device is not None else weights.embed.device
         self.use_tr = use_tr
         self.use_graphs = True         # capture the decode step in a HIP graph (cuda devices only)
+        self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
         tc = cfg.text_config
         self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
@@ -260,18 +261,45 @@ class LeopardEngine:
         max_len = max(int(l) for l in seq_lens)
         if self.trace:
             self.trace("llm.embed", x)
-        for i, L in enumerate(W.llm_layers):
-            ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
-            ops.gemm(h, L.qkv_w, qkv)
-            ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
-            ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
-                          True, self.use_tr, window=tc.sliding_window or 0)
-            self._row_parallel(att, L.o_w, x, tmp)
-            ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
-            ops.gemm(h, L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
-            self._row_parallel(gu, L.down_w, x, tmp)
-            if self.trace:
-                self.trace(f"llm.{i}", x)
+        # Fused schedule (one rank, head_dim 128): the RMSNorms and the RoPE ride in the GEMM epilogues.  Each residual GEMM
+        # (o_proj, down_proj) also emits T(x * gamma_next) and per-row partial sums of squares; the GEMM that consumes them
+        # (gate/up, next layer's qkv) applies rstd to its accumulator rows; the qkv GEMM rotates q / k and appends K / V to the
+        # cache in its epilogue.  Only the very first norm of the stack is a launch of its own.
+        fused = self.fuse_norm_rope and self.tp_size == 1 and hd == 128 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None
+        if fused:
+            parts = D // 64
+            sq_a = self._empty(S, parts, dtype=torch.float32)       # partials feeding gate/up
+            sq_b = self._empty(S, parts, dtype=torch.float32)       # partials feeding the next layer's qkv
+            n_layers = len(W.llm_layers)
+            for i, L in enumerate(W.llm_layers):
+                if i == 0:
+                    ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
+                ops.rmsnorm_rope(h, L.qkv_w_rope, qkv, None if i == 0 else sq_b, tc.rms_norm_eps, cos, sin,
+                                 cache.k[i] if cache else None, cache.v[i] if cache else None, 0, H, KV, hd)
+                ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
+                              True, self.use_tr, window=tc.sliding_window or 0)
+                ops.gemm_ex(att, L.o_w, x, epilogue=_lib.EPI_RESIDUAL, norm_out=h, norm_gamma=L.post_norm, rowsq_out=sq_a)
+                ops.gemm_ex(h, L.gu_w, gu, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq_a, norm_dim=D, norm_eps=tc.rms_norm_eps)
+                if i + 1 < n_layers:
+                    ops.gemm_ex(gu, L.down_w, x, epilogue=_lib.EPI_RESIDUAL, norm_out=h, norm_gamma=W.llm_layers[i + 1].in_norm,
+                                rowsq_out=sq_b)
+                else:
+                    ops.gemm(gu, L.down_w, x, epilogue=_lib.EPI_RESIDUAL)
+                if self.trace:
+                    self.trace(f"llm.{i}", x)
+        else:
+            for i, L in enumerate(W.llm_layers):
+                ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
+                ops.gemm(h, L.qkv_w, qkv)
+                ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
+                ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
+                              True, self.use_tr, window=tc.sliding_window or 0)
+                self._row_parallel(att, L.o_w, x, tmp)
+                ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
+                ops.gemm(h, L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
+                self._row_parallel(gu, L.down_w, x, tmp)
+                if self.trace:
+                    self.trace(f"llm.{i}", x)
         if cache is not None:
             cache.length = S
         return self._lm_head(x, last_rows, all_logits)

@@ -170,3 +170,31 @@ class Ops:
         self._check(self.lib.lmi_lm_head_last(_ptr(w), _ptr(x_f32), _ptr(rows), _ptr(norm_weight), float(eps), _ptr(out), n, N, K,
                                               w.stride(0), x_f32.stride(0), out.stride(0), _DT[w.dtype], self._stream(out)))
         return out
+
+    def gemm_ex(self, a, w, out, bias=None, epilogue=EPI_STORE, act=ACT_NONE, rowsq_in=None, norm_dim=0, norm_eps=0.0, norm_out=None,
+                norm_gamma=None, rowsq_out=None):
+        """lmi_gemm with the RMSNorm folded in: consumer side (rowsq_in: [M, parts] fp32 partial sums of squares -> rows scaled
+        by rstd) and / or producer side (RESIDUAL epilogue: norm_out = T(x * norm_gamma), rowsq_out [M, N/64])."""
+        N, K = w.shape
+        M = a.shape[0]
+        parts = 0 if rowsq_in is None else rowsq_in.shape[1]
+        if rowsq_in is not None:
+            assert rowsq_in.dtype == torch.float32 and rowsq_in.is_contiguous() and rowsq_in.shape[0] >= M
+        if norm_out is not None:
+            assert rowsq_out is not None and rowsq_out.dtype == torch.float32 and rowsq_out.is_contiguous() and rowsq_out.shape == (M, N // 64)
+        self._check(self.lib.lmi_gemm_ex(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), M, N, K, a.stride(0), w.stride(0), out.stride(0), epilogue, act,
+                                         _ptr(rowsq_in), parts, int(norm_dim), float(norm_eps), _ptr(norm_out), _ptr(norm_gamma), _ptr(rowsq_out),
+                                         0 if norm_out is None else norm_out.stride(0), _DT[w.dtype], self._stream(out)))
+        return out
+
+    def rmsnorm_rope(self, a, w_qkv_rope, qkv, rowsq_in, eps, cos, sin, k_cache, v_cache, cache_pos0, n_q_heads, n_kv_heads, head_dim):
+        """lmi_rmsnorm_rope: qkv = [RoPE(q), RoPE(k), v] of rstd * (a @ w^T), K / V appended to the cache rows cache_pos0..;
+        w_qkv_rope in weights.rope_permute_rows order; rowsq_in None = a is already normalised."""
+        M, K = a.shape[0], w_qkv_rope.shape[1]
+        parts = 0 if rowsq_in is None else rowsq_in.shape[1]
+        ldc = 0 if k_cache is None else k_cache.stride(0)
+        assert qkv.shape[1] == (n_q_heads + 2 * n_kv_heads) * head_dim == w_qkv_rope.shape[0]
+        self._check(self.lib.lmi_rmsnorm_rope(_ptr(a), _ptr(w_qkv_rope), _ptr(qkv), _ptr(rowsq_in), parts, float(eps), _ptr(cos), _ptr(sin),
+                                              _ptr(k_cache), _ptr(v_cache), ldc, int(cache_pos0), M, n_q_heads, n_kv_heads, head_dim, K,
+                                              a.stride(0), w_qkv_rope.stride(0), qkv.stride(0), _DT[w_qkv_rope.dtype], self._stream(qkv)))
+        return qkv

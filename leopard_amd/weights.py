@@ -72,6 +72,16 @@ def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return torch.stack([gate.view(F // 32, 32, K), up.view(F // 32, 32, K)], dim=1).reshape(2 * F, K).contiguous()
 
 
+def rope_permute_rows(w: torch.Tensor, head_dim: int = 128) -> torch.Tensor:
+    """Row order of the q / k projection weights for lmi_rmsnorm_rope: inside every head the rows d = 0..127 are stored as
+    [0..31, 64..95, 32..63, 96..127], so that each 64-column slice of the GEMM output that one wave owns holds 32 first-half
+    elements next to their rotate-half partners (d, d + 64).  The kernel's epilogue restores the natural order on store."""
+    assert head_dim == 128 and w.shape[0] % head_dim == 0
+    idx = torch.cat([torch.arange(0, 32), torch.arange(64, 96), torch.arange(32, 64), torch.arange(96, 128)]).to(w.device)
+    n = w.shape[0] // head_dim
+    return w.view(n, head_dim, -1)[:, idx].reshape(w.shape).contiguous()
+
+
 @dataclass
 class VitLayerW:
     ln1_w: torch.Tensor; ln1_b: torch.Tensor
@@ -90,6 +100,7 @@ class LlmLayerW:
     post_norm: torch.Tensor
     gu_w: torch.Tensor
     down_w: torch.Tensor
+    qkv_w_rope: torch.Tensor = None        # qkv_w with the q / k rows in lmi_rmsnorm_rope's order (head_dim 128 only)
 
 
 @dataclass
@@ -178,9 +189,12 @@ class EngineWeights:
             rq, rk, rf = slice(tp_rank * qw, (tp_rank + 1) * qw), slice(tp_rank * kw, (tp_rank + 1) * kw), slice(tp_rank * ff, (tp_rank + 1) * ff)
             qkv_w = torch.cat([expect(p + "self_attn.q_proj.weight", (full_q, Dt))[rq], expect(p + "self_attn.k_proj.weight", (full_kv, Dt))[rk],
                                expect(p + "self_attn.v_proj.weight", (full_kv, Dt))[rk]], dim=0).contiguous()
+            qkv_rope = None
+            if tc.head_dim == 128:
+                qkv_rope = torch.cat([rope_permute_rows(qkv_w[:qw + kw]), qkv_w[qw + kw:]], dim=0).contiguous()
             W.llm_layers.append(LlmLayerW(
                 in_norm=g(p + "input_layernorm.weight").float().contiguous(),
-                qkv_w=qkv_w,
+                qkv_w=qkv_w, qkv_w_rope=qkv_rope,
                 o_w=expect(p + "self_attn.o_proj.weight", (Dt, full_q))[:, rq].contiguous(),
                 post_norm=g(p + "post_attention_layernorm.weight").float().contiguous(),
                 gu_w=interleave_gate_up(expect(p + "mlp.gate_proj.weight", (tc.intermediate_size, Dt))[rf],

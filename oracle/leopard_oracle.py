@@ -58,6 +58,8 @@ class _Emu:
     dtype = None          # None = no emulation
     trace = None          # list or None
     fp32_head = True      # the HIP path feeds the last-token lm_head the fp32 normalised row (lmi_lm_head_last)
+    fused = True          # production Llama schedule (lmi_gemm_ex / lmi_rmsnorm_rope): the RMSNorm operand is rounded as
+                          # T(x * gamma) BEFORE the row scale, and q / k are rounded once, after the rotation
 
 
 def _q(x: Tensor) -> Tensor:
@@ -357,6 +359,14 @@ def rms_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
     return w * (x * torch.rsqrt(v + eps))
 
 
+def _rms_norm_q(x: Tensor, w: Tensor, eps: float, first: bool) -> Tensor:
+    """rms_norm followed by the hand-over rounding of the HIP path (identity without emulate_rounding)."""
+    if _Emu.dtype is None or not _Emu.fused or first:
+        return _q(rms_norm(x, w, eps))
+    v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+    return _q(x * w) * torch.rsqrt(v + eps)          # producer epilogue rounds x * gamma; the consumer applies rstd in fp32
+
+
 def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: Tensor,
                 kv_out: Optional[list] = None, prefix: str = "language_model.model.") -> Tensor:
     tc = cfg.text_config
@@ -364,9 +374,10 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
     B, S, D = x.shape
     H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     r = x
-    h = _q(rms_norm(x, W[p + "input_layernorm.weight"], tc.rms_norm_eps))
-    q = _q(F.linear(h, W[p + "self_attn.q_proj.weight"])).view(B, S, H, hd).transpose(1, 2)
-    k = _q(F.linear(h, W[p + "self_attn.k_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
+    pre = (lambda t: t) if _Emu.fused else _q          # unfused schedule: q / k are also rounded before the rotation
+    h = _rms_norm_q(x, W[p + "input_layernorm.weight"], tc.rms_norm_eps, first=(i == 0))
+    q = pre(F.linear(h, W[p + "self_attn.q_proj.weight"])).view(B, S, H, hd).transpose(1, 2)
+    k = pre(F.linear(h, W[p + "self_attn.k_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
     v = _q(F.linear(h, W[p + "self_attn.v_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
     q = _q(q * cos + rotate_half(q) * sin)
     k = _q(k * cos + rotate_half(k) * sin)
@@ -390,7 +401,7 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
     o = _q(o.transpose(1, 2).reshape(B, S, H * hd))
     x = r + F.linear(o, W[p + "self_attn.o_proj.weight"])
     r = x
-    h = _q(rms_norm(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps))
+    h = _rms_norm_q(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps, first=False)
     g = F.linear(h, W[p + "mlp.gate_proj.weight"])
     u = F.linear(h, W[p + "mlp.up_proj.weight"])
     return r + F.linear(_q(F.silu(g) * u), W[p + "mlp.down_proj.weight"])       # XFMR:136-139

@@ -290,3 +290,98 @@ def test_lm_head_last_vs_fp32(ops, dtype):
     xn = gamma * (x[rows] * torch.rsqrt(x[rows].pow(2).mean(-1, keepdim=True) + 1e-5))
     ref = (xn.double() @ w.double().T)
     assert (out.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+# ---- RMSNorm / RoPE fused into the GEMM epilogues (lmi_gemm_ex, lmi_rmsnorm_rope) at the C3 shapes ----------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [-1, 1, 2, 5, 7])
+@pytest.mark.parametrize("K", [4096, 14336])
+def test_gemm_ex_residual_norm_producer_m7187(ops, dtype, cfg, K):
+    """o_proj (K = 4096) / down_proj (K = 14336) at M = 7187: x += a.w^T plus the second output T(x * gamma) and the 64 per-row
+    partial sums of squares; x must equal the plain residual epilogue bit for bit."""
+    M, N = 7187, 4096
+    a, w, _, ref = operands(M, N, K, dtype, 0.02)
+    g = torch.Generator(device=DEV).manual_seed(91)
+    x0 = torch.randn(M, N, generator=g, device=DEV)
+    gamma = torch.rand(N, generator=g, device=DEV) + 0.5
+    ops.set_option("gemm.config", cfg)
+    try:
+        x = x0.clone()
+        h = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+        sq = torch.full((M, N // 64), float("nan"), device=DEV)
+        ops.gemm_ex(a, w, x, epilogue=_lib.EPI_RESIDUAL, norm_out=h, norm_gamma=gamma, rowsq_out=sq)
+        x2 = x0.clone()
+        ops.gemm(a, w, x2, epilogue=_lib.EPI_RESIDUAL)
+        assert torch.equal(x, x2)
+        assert (x - (x0 + ref)).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+        hx = x * gamma
+        assert ((h.float() - hx).abs() / (hx.abs() + 1e-6)).max().item() <= eps(dtype)          # one rounding of x * gamma
+        sq_ref = x.double().pow(2).view(M, N // 64, 64).sum(-1)
+        assert ((sq.double() - sq_ref).abs() / sq_ref).max().item() <= 1e-5
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [-1, 1, 5, 7])
+def test_gemm_ex_swiglu_consumer_m7187(ops, dtype, cfg):
+    """gate/up + SwiGLU with the RMSNorm row scale applied to the accumulators (rowsq_in), M = 7187, N = 28672."""
+    from leopard_amd.weights import interleave_gate_up
+    M, F, K = 7187, 14336, 4096
+    a, w, _, ref = operands(M, 2 * F, K, dtype, 0.02)
+    wi = interleave_gate_up(w[:F], w[F:])
+    g = torch.Generator(device=DEV).manual_seed(92)
+    sq = (torch.rand(M, K // 64, generator=g, device=DEV) + 0.5) * 64
+    rstd = torch.rsqrt(sq.sum(-1, keepdim=True) / K + 1e-5)
+    want = torch.nn.functional.silu(ref[:, :F] * rstd) * (ref[:, F:] * rstd)
+    ops.set_option("gemm.config", cfg)
+    try:
+        out = torch.full((M, F), float("nan"), dtype=dtype, device=DEV)
+        ops.gemm_ex(a, wi, out, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq, norm_dim=K, norm_eps=1e-5)
+        e = rel_err(out, want)
+        assert e <= 3 * eps(dtype), f"SWIGLU + row scale cfg {cfg}: {e:.3e}"
+    finally:
+        ops.set_option("gemm.config", -1)
+        del wi
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [-1, 1, 2, 5, 7])
+@pytest.mark.parametrize("with_norm", [False, True])
+def test_rmsnorm_rope_qkv_s7187(ops, dtype, cfg, with_norm):
+    """lmi_rmsnorm_rope at the C3 Llama shape: S = 7187, 32 q + 8 kv heads x 128, K = 4096; llama3-scaled tables at positions
+    0..S-1; q / k rotated on the fp32 accumulators, K / V appended to the cache."""
+    from leopard_amd.config import RopeScaling
+    from leopard_amd.engine import llama3_inv_freq
+    from leopard_amd.weights import rope_permute_rows
+    S, nq, nkv, D, K = 7187, 32, 8, 128, 4096
+    N = (nq + 2 * nkv) * D
+    a, w, _, ref = operands(S, N, K, dtype, 0.02)
+    w_rope = torch.cat([rope_permute_rows(w[:(nq + nkv) * D]), w[(nq + nkv) * D:]], 0).contiguous()
+    inv = llama3_inv_freq(D, 5e5, RopeScaling()).to(DEV)
+    ang = torch.arange(S, device=DEV, dtype=torch.float32)[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    sq, rstd = None, 1.0
+    if with_norm:
+        g = torch.Generator(device=DEV).manual_seed(93)
+        sq = (torch.rand(S, K // 64, generator=g, device=DEV) + 0.5) * 64
+        rstd = torch.rsqrt(sq.sum(-1, keepdim=True) / K + 1e-5)
+    acc = (ref * rstd).view(S, nq + 2 * nkv, D)
+    rot = torch.cat((-acc[..., D // 2:], acc[..., :D // 2]), -1)
+    c2, s2 = torch.cat([cos, cos], -1)[:, None], torch.cat([sin, sin], -1)[:, None]
+    want = acc.clone()
+    want[:, :nq + nkv] = acc[:, :nq + nkv] * c2 + rot[:, :nq + nkv] * s2
+    want = want.view(S, N)
+    ops.set_option("gemm.config", cfg)
+    try:
+        qkv = torch.full((S, N), float("nan"), dtype=dtype, device=DEV)
+        kc = torch.zeros(S + 5, nkv * D, dtype=dtype, device=DEV)
+        vc = torch.zeros_like(kc)
+        ops.rmsnorm_rope(a, w_rope, qkv, sq, 1e-5, cos, sin, kc, vc, 2, nq, nkv, D)
+        e = rel_err(qkv, want)
+        assert e <= 3 * eps(dtype), f"qkv + rope cfg {cfg} norm {with_norm}: {e:.3e}"
+        assert torch.equal(kc[2:2 + S], qkv[:, nq * D:(nq + nkv) * D]) and torch.equal(vc[2:2 + S], qkv[:, (nq + nkv) * D:])
+        assert kc[:2].abs().max().item() == 0 and kc[2 + S:].abs().max().item() == 0
+    finally:
+        ops.set_option("gemm.config", -1)
+        del w_rope
