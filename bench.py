@@ -87,7 +87,24 @@ class GemmTimer:
             timer.bytes += (M + w.shape[0]) * w.shape[1] * w.element_size() + out.numel() * out.element_size()
             return r
         ops.gemm = gemm
+        # the folded-norm / RoPE variants are GEMMs of the same family: lmi_gemm_ex(a, w, out, ...), lmi_rmsnorm_rope(a, w, qkv, ...)
+        self._inner_ex, self._inner_rope = ops.gemm_ex, ops.rmsnorm_rope
+
+        def timed(fn):
+            def call(a, w, out, *args, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
+                r = fn(a, w, out, *args, **kw)
+                e1.record(torch.cuda.current_stream())
+                timer.records.append((2.0 * a.shape[0] * w.shape[0] * w.shape[1], e0, e1))
+                timer.bytes += (a.shape[0] + w.shape[0]) * w.shape[1] * w.element_size() + out.numel() * out.element_size()
+                return r
+            return call
+        ops.gemm_ex, ops.rmsnorm_rope = timed(ops.gemm_ex), timed(ops.rmsnorm_rope)
         return inner
+
+    def unwrap(self, ops, inner):
+        ops.gemm, ops.gemm_ex, ops.rmsnorm_rope = inner, self._inner_ex, self._inner_rope
 
     def summary(self):
         torch.cuda.synchronize()
@@ -298,6 +315,7 @@ def main():
                          "per step on all ranks: tile-sharded vision encode + all-gather, tensor-parallel LLM with two all-reduces "
                          "per layer (strong scaling, single-sample latency)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (lmi_set_option), e.g. gemm.wide=7 for A/B runs")
+    ap.add_argument("--no-fuse", action="store_true", help="A/B: separate RMSNorm / RoPE launches instead of the fused GEMM epilogues")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -333,6 +351,7 @@ def main():
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype, tp_rank=rank if tp else 0, tp_size=world if tp else 1)
     torch.cuda.synchronize()
     eng = LeopardEngine(cfg, W, ops=ops, device=dev)
+    eng.fuse_norm_rope = not args.no_fuse
     load_s = time.perf_counter() - t0
 
     class Ctx:
@@ -433,7 +452,7 @@ def main():
                 ctxs[0].cache.length = 0
                 eng.prefill(ctxs[0].ids, ctxs[0].tiles, cache=ctxs[0].cache)
         gflops, gms, n = timer.summary()
-        ops.gemm = inner
+        timer.unwrap(ops, inner)
         per_launch_flops = gflops / n
         avg_ms = gms / n
         achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12

@@ -95,6 +95,12 @@ int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int
 int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx, int ldo, float eps, int dtype,
                 void* stream);
 
+/* Residual update + RMSNorm on the rows a rank owns (sequence-parallel tensor parallelism; the exchange pattern of
+ * Megatron-LM-240603/megatron/core/tensor_parallel/mappings.py:107-145): x[M, ldx] fp32 += delta[M, ldd] (the reduce-scattered
+ * partial products, delta_dtype = LMI_F32 or dtype), then out[M, ldo] T = w * (x * rsqrt(mean(x^2) + eps)).  out null: add only. */
+int lmi_add_rmsnorm(float* x, const void* delta, int delta_dtype, const float* w, void* out, int M, int D, int ldx, int ldd, int ldo,
+                    float eps, int dtype, void* stream);
+
 /* out = epilogue(A[M,K] . W[N,K]^T): every nn.Linear / conv-as-GEMM on the path —
  * SigLIP patch-embed, q/k/v/out_proj, fc1 (+gelu_tanh), fc2; projector linear_1 (+gelu_erf, A gathered through
  * the 2x2 pixel shuffle of EVAL:165-176) and linear_2 (EVAL:187-192); Llama qkv / o_proj / gate+up (+SwiGLU,

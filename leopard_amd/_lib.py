@@ -29,6 +29,7 @@ SIGNATURES = {
     "lmi_resample_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "lmi_layernorm": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "lmi_rmsnorm": [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "lmi_add_rmsnorm": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "lmi_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_gemm_ex": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _P, _P, _I, _I, _P],
     "lmi_rmsnorm_rope": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

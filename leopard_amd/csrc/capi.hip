@@ -87,8 +87,8 @@ int launch_gemm_cfg(const GemmArgs& a, void* stream) {
     int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
     if (a.order == 1) tiles = (tiles + 255) / 256 * 256;
     static std::atomic<uint64_t> attr_done{0};
-    allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE, C>, C::SMEM, attr_done);
-    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
+    allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE, C>, C::SMEM_TOTAL, attr_done);
+    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM_TOTAL, stream, a);
     return check_launch("lmi_gemm");
 }
 
@@ -97,8 +97,8 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
     int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
     if (a.order == 1) tiles = (tiles + 255) / 256 * 256;
     static std::atomic<uint64_t> attr_done{0};
-    allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>, C::SMEM, attr_done);
-    LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>), dim3(tiles), dim3(C::NT), C::SMEM, stream, a);
+    allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>, C::SMEM_TOTAL, attr_done);
+    LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>), dim3(tiles), dim3(C::NT), C::SMEM_TOTAL, stream, a);
     return check_launch("lmi_gemm");
 }
 
@@ -246,6 +246,15 @@ int norm_impl(const float* x, const float* w, const float* b, void* out, int M, 
     if (D <= 1536) LMI_LAUNCH((norm_kernel<T, RMS, 3>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
     else LMI_LAUNCH((norm_kernel<T, RMS, 8>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
     return check_launch(what);
+}
+
+template <typename T, typename DT>
+int add_rmsnorm_impl(float* x, const void* delta, const float* w, void* out, int M, int D, int ldx, int ldd, int ldo, float eps,
+                            void* stream) {
+    const int grid = (M + 3) / 4;
+    if (D <= 1536) LMI_LAUNCH((add_rmsnorm_kernel<T, DT, 3>), dim3(grid), dim3(256), 0, stream, x, (const DT*)delta, w, (T*)out, M, D, ldx, ldd, ldo, eps);
+    else LMI_LAUNCH((add_rmsnorm_kernel<T, DT, 8>), dim3(grid), dim3(256), 0, stream, x, (const DT*)delta, w, (T*)out, M, D, ldx, ldd, ldo, eps);
+    return check_launch("lmi_add_rmsnorm");
 }
 
 template <typename T>
@@ -429,8 +438,8 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     } else if (a_mode != LMI_A_PLAIN) {
         return fail(LMI_EINVAL, "%s: bad a_mode %d", who, a_mode);
     }
-    if (x.rowsq_in && (x.rowsq_parts <= 0 || x.norm_dim <= 0 || !aligned16(x.rowsq_in)))
-        return fail(LMI_EINVAL, "%s: rowsq_in needs rowsq_parts > 0, norm_dim > 0 and 16-byte alignment", who);
+    if (x.rowsq_in && (x.rowsq_parts <= 0 || (x.rowsq_parts & 3) || x.norm_dim <= 0 || !aligned16(x.rowsq_in)))
+        return fail(LMI_EINVAL, "%s: rowsq_in needs rowsq_parts > 0 and a multiple of 4, norm_dim > 0 and 16-byte alignment", who);
     if (x.norm_out && (epilogue != LMI_EPI_RESIDUAL || !x.norm_gamma || !x.rowsq_out || (x.ld_norm & 7) || x.ld_norm < N || row_map ||
                        !aligned16(x.norm_out) || !aligned16(x.norm_gamma)))
         return fail(LMI_EINVAL, "%s: norm_out needs the RESIDUAL epilogue, norm_gamma, rowsq_out, ld_norm %% 8 == 0 and no row_map", who);
@@ -451,6 +460,21 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     a.a_bytes = (unsigned)a_bytes; a.w_bytes = (unsigned)w_bytes;
     LMI_DISPATCH_T(dtype, dispatch_gemm<f16_t>(a, epilogue, act, a_mode, stream),
                    dispatch_gemm<bf16_t>(a, epilogue, act, a_mode, stream));
+}
+
+int lmi_add_rmsnorm(float* x, const void* delta, int delta_dtype, const float* w, void* out, int M, int D, int ldx, int ldd, int ldo,
+                    float eps, int dtype, void* stream) {
+    if (!x || !delta || (out && !w) || M < 0 || D <= 0 || (D & 7) || D > 4096 || (ldx & 3) || (ldd & 7) || (out && (ldo & 7)) ||
+        !aligned16(x) || !aligned16(delta) || (out && !aligned16(out)) || (w && !aligned16(w)))
+        return fail(LMI_EINVAL, "lmi_add_rmsnorm: bad argument (M=%d D=%d; D %% 8 == 0, D <= 4096)", M, D);
+    if (dtype != LMI_F16 && dtype != LMI_BF16) return fail(LMI_EINVAL, "lmi_add_rmsnorm: dtype must be LMI_F16 or LMI_BF16");
+    if (delta_dtype != LMI_F32 && delta_dtype != dtype) return fail(LMI_EINVAL, "lmi_add_rmsnorm: delta_dtype must be LMI_F32 or dtype");
+    if (M == 0) return LMI_OK;
+    if (dtype == LMI_F16)
+        return delta_dtype == LMI_F32 ? add_rmsnorm_impl<f16_t, float>(x, delta, w, out, M, D, ldx, ldd, ldo, eps, stream)
+                                      : add_rmsnorm_impl<f16_t, f16_t>(x, delta, w, out, M, D, ldx, ldd, ldo, eps, stream);
+    return delta_dtype == LMI_F32 ? add_rmsnorm_impl<bf16_t, float>(x, delta, w, out, M, D, ldx, ldd, ldo, eps, stream)
+                                  : add_rmsnorm_impl<bf16_t, bf16_t>(x, delta, w, out, M, D, ldx, ldd, ldo, eps, stream);
 }
 
 int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,

@@ -161,6 +161,59 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sequence-parallel residual update (tensor-parallel LLM): x[row] += delta[row] (the reduce-scattered partial
+// products of o_proj / down_proj, 16-bit or fp32), x written back, then out[row] = w * (x * rstd) as norm_kernel<RMS> does.
+// out == nullptr: the add only.  One wave per row, row in registers.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename DT, int MAXV>
+__global__ void __launch_bounds__(256) add_rmsnorm_kernel(float* x, const DT* delta, const float* w, T* out, int M, int D, int ldx,
+                                                          int ldd, int ldo, float eps) {
+    typedef typename vec_of<T>::x8 T8;
+    typedef typename vec_of<DT>::x8 D8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float* xr = x + (long)row * ldx;
+    const DT* dr = delta + (long)row * ldd;
+    const int nvec = D >> 3;
+    f32x4 v[MAXV][2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            const D8 d = *(const D8*)(dr + c * 8);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                v[i][h] = *(const f32x4*)(xr + c * 8 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][h][e] += (float)d[4 * h + e];
+                *(f32x4*)(xr + c * 8 + 4 * h) = v[i][h];
+                s += v[i][h][0] * v[i][h][0] + v[i][h][1] * v[i][h][1] + v[i][h][2] * v[i][h][2] + v[i][h][3] * v[i][h][3];
+            }
+        }
+    }
+    if (!out) return;                                    // wave-uniform
+    s = wave_sum(s);
+    const float rstd = 1.0f / sqrtf(s / (float)D + eps);
+    T* orow = out + (long)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nvec) {
+            T8 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 ww = *(const f32x4*)(w + c * 8 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * h + e] = (T)(ww[e] * (v[i][h][e] * rstd));
+            }
+            *(T8*)(orow + c * 8) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // RoPE (rotate-half, cos/sin tables [S, D/2] fp32 built by the host from position_ids and the llama3-scaled
 // inverse frequencies) applied in place to the q and k heads of the packed qkv rows; optionally writes the
 // rotated K and the V rows into the KV cache [S_cache, n_kv*D] at row cache_pos0 + s.

@@ -90,6 +90,7 @@ struct GemmCfg {
     static constexpr int G = A_PASSES + W_PASSES;              // LDS-DMA instructions per thread per k-tile
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int SMEM = STAGES * STAGE_BYTES;
+    static constexpr int SMEM_TOTAL = SMEM + BM * 4;             // + the row scales of a folded RMSNorm (gemm_tile_rstd)
     static constexpr int D = STAGES - 1;                       // prefetch distance in k-tiles (>= 1)
     static_assert(STAGES >= 2, "ring needs at least two slots");
     static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows vs threads");
@@ -159,29 +160,47 @@ LMI_DEV bool gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, in
 // `put(mi, stage)` writes rows mi*32 .. mi*32+31 of the wave tile into the image (it depends on the MFMA shape's accumulator layout).
 template <int WTN> struct GemmImage { static constexpr int RS = WTN * 4 + 16; };   // LDS row stride of the fp32 image
 
-// rstd of row m from the producer's partial sums of squares.  The LPR lanes that share an output row split the partials
-// between them and meet with xor-shuffles (LPR is a power of two and the lanes of a row are consecutive), so every lane of
-// the row ends up with the same, order-deterministic sum.
-template <int LPR>
-LMI_DEV float gemm_row_rstd(const GemmArgs& p, int m, int lane) {
-    const float* part = p.rowsq_in + (long)m * p.rowsq_parts;
-    float s = 0.f;
-    const int li = lane % LPR;
-    if ((p.rowsq_parts % (4 * LPR)) == 0) {
-        const int per = p.rowsq_parts / LPR;                                 // contiguous floats per lane, a multiple of 4
-        for (int j = 0; j < per; j += 4) {
-            const f32x4 v = *(const f32x4*)(part + li * per + j);
-            s += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-    } else {
-        for (int j = li; j < p.rowsq_parts; j += LPR) s += part[j];
-    }
+// Row scales of the folded RMSNorm for the BM rows of a tile, computed ONCE per workgroup in the kernel prologue (under the
+// latency of the first LDS-DMA pieces) into a BM-float LDS array behind the k-tile ring; the epilogue then reads one float
+// per row.  rstd[r] = rsqrt(sum_j rowsq_in[m0 + r, j] / norm_dim + eps).  The summation order is fixed — four quarter sums
+// of contiguous partials, ((q0 + q1) + (q2 + q3)) — whatever the tile geometry (NT / BM = 2 or 4 threads share a row), so a
+// row's scale does not depend on the geometry chosen for the problem size or on where the row sits in a packed batch.
+template <typename C>
+LMI_DEV void gemm_tile_rstd(const GemmArgs& p, int m0, int tid, float* rstd_lds) {
+    constexpr int TPR = C::NT / C::BM;                                       // threads per row: 2 or 4
+    static_assert(TPR == 2 || TPR == 4, "threads per tile row");
+    const int r = tid / TPR, sub = tid % TPR;
+    const float* part = p.rowsq_in + (long)imin(m0 + r, p.M - 1) * p.rowsq_parts;
+    const int qlen = p.rowsq_parts >> 2;                                     // partials per quarter (rowsq_parts % 4 == 0 is checked by the launcher)
+    float q[4 / TPR];
 #pragma unroll
-    for (int msk = 1; msk < LPR; msk <<= 1) s += shfl_xor(s, msk);
-    return 1.0f / sqrtf(s / (float)p.norm_dim + p.norm_eps);
+    for (int i = 0; i < 4 / TPR; ++i) {
+        const float* src = part + (sub * (4 / TPR) + i) * qlen;
+        float acc = 0.f;
+        if ((qlen & 3) == 0) {
+            for (int j = 0; j < qlen; j += 4) {
+                const f32x4 v = *(const f32x4*)(src + j);
+                acc += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        } else {
+            for (int j = 0; j < qlen; ++j) acc += src[j];
+        }
+        q[i] = acc;
+    }
+    float s;
+    if (TPR == 2) {
+        s = q[0] + q[1 % (4 / TPR)];                                         // (q0 + q1) resp. (q2 + q3)
+        s += shfl_xor(s, 1);
+    } else {
+        s = q[0];
+        s += shfl_xor(s, 1);                                                 // (q0 + q1), (q2 + q3)
+        s += shfl_xor(s, 2);
+    }
+    if (sub == 0) rstd_lds[r] = 1.0f / sqrtf(s / (float)p.norm_dim + p.norm_eps);
 }
+
 template <typename T, int EPI, int ACT, typename C, typename Put>
-LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, int wn, int lane, char* stage) {
+LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, int wn, int lane, char* stage, const float* rstd_lds) {
     typedef typename vec_of<T>::x8 T8;
     constexpr int RS = GemmImage<C::WTN>::RS;
     static_assert(32 * RS <= C::SMEM / (C::NT / 64), "per-wave LDS slice too small for the epilogue image");
@@ -195,7 +214,9 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
     // rows 2, 3, 6, 7 of an instruction makes each of ds_read_b128's four lane groups hit 16 distinct 16-byte slots (with
     // lane -> column fixed, rows two apart share slots: 2-way conflicts, 4.5 % of the ring kernels' LDS cycles by PMC).
     // A row is still covered by 8 consecutive lanes, so stores stay whole 128/256-byte row segments.
-    const int oc = ((LPR == 8 && !PAIRED) ? ((lane + 7 * ((r_in >> 1) & 1)) & 7) : (lane % LPR)) * 8;
+    // (not in producer mode: there the 8 lanes of a row sum their squares with a fixed shuffle tree, and the pairing of column
+    // groups in that tree must not depend on the row's position — bit-identical partials wherever a row sits in a packed batch)
+    const int oc = ((LPR == 8 && !PAIRED && !(EPI == EPI_RESID_F32 && p.norm_out)) ? ((lane + 7 * ((r_in >> 1) & 1)) & 7) : (lane % LPR)) * 8;
     // source columns of this lane in the image: plain = oc..oc+7; SwiGLU = gate block, up block 32 columns further;
     // RoPE = first-half block, rotate-half partner block 32 columns further
     const int sc = PAIRED ? (oc >> 5) * 64 + (oc & 31) : oc;
@@ -223,7 +244,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 16);
                 f32x4 b0 = *(const f32x4*)(src + 128), b1 = *(const f32x4*)(src + 144);
                 if (p.rowsq_in) {
-                    const float rstd = gemm_row_rstd<LPR>(p, mc, lane);
+                    const float rstd = rstd_lds[wm * C::WTM + mi * 32 + row];
                     a0 *= rstd; a1 *= rstd; b0 *= rstd; b1 *= rstd;
                 }
                 T8 o1, o2;
@@ -269,7 +290,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 f32x4 g0 = *(const f32x4*)src, g1 = *(const f32x4*)(src + 16);
                 f32x4 u0 = *(const f32x4*)(src + 128), u1 = *(const f32x4*)(src + 144);
                 if (p.rowsq_in) {
-                    const float rstd = gemm_row_rstd<LPR>(p, imin(m, p.M - 1), lane);
+                    const float rstd = rstd_lds[wm * C::WTM + mi * 32 + row];
                     g0 *= rstd; g1 *= rstd; u0 *= rstd; u1 *= rstd;
                 }
                 T8 o;
@@ -297,7 +318,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
             v0[it] = *(const f32x4*)src;
             v1[it] = *(const f32x4*)(src + 16);
             if (p.rowsq_in) {
-                const float rstd = gemm_row_rstd<LPR>(p, mc, lane);
+                const float rstd = rstd_lds[wm * C::WTM + mi * 32 + row];
                 v0[it] *= rstd; v1[it] *= rstd;
             }
             v0[it] += bias0;
@@ -446,6 +467,8 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     GemmStager<AMODE, C> stager;
     stager.init(p, m0, n0, tid, smem, wave);
     auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
+    float* rstd_lds = (float*)(smem + C::SMEM);
+    if (p.rowsq_in) { gemm_tile_rstd<C>(p, m0, tid, rstd_lds); lds_write_drain(); }   // visible after the first barrier
 
     f32x16 acc[C::NI][C::MI];
 #pragma unroll
@@ -496,7 +519,7 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 
     raw_barrier();                                                 // every wave is done reading k-tiles: LDS is free
     gemm_epilogue<T, EPI, ACT, C>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
-                                  smem + wave * (C::SMEM / (C::NT / 64)));
+                                  smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -530,6 +553,8 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     GemmStager<AMODE, C> stager;
     stager.init(p, m0, n0, tid, smem, wave);
     auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
+    float* rstd_lds = (float*)(smem + C::SMEM);
+    if (p.rowsq_in) { gemm_tile_rstd<C>(p, m0, tid, rstd_lds); lds_write_drain(); }   // visible after the first barrier
 
     f32x16 acc[C::NI][C::MI];
 #pragma unroll
@@ -600,7 +625,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     if (grp == 0) raw_barrier();                                   // balance the barrier count
     // past its last barrier a wave knows that every other wave has finished its last LOAD segment: LDS is free
     gemm_epilogue<T, EPI, ACT, C>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
-                                  smem + wave * (C::SMEM / (C::NT / 64)));
+                                  smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds);
 }
 
 }  // namespace lmi

@@ -74,6 +74,8 @@ LMI_DEV void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, vo
 }
 
 LMI_DEV void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+// this wave's LDS writes have completed (before a raw s_barrier that publishes them to the other waves)
+LMI_DEV void lds_write_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Between a wave's LDS writes and its reads of what OTHER lanes of the same wave wrote.  The hardware needs nothing (the DS
 // operations of a wave execute in order); the empty asm only stops the compiler from reordering across it.
@@ -187,6 +189,7 @@ inline int lane_id() { return threadIdx.x & 63; }
 inline int wave_id() { return (int)(threadIdx.x >> 6); }
 template <int N> inline void wait_vmcnt_barrier() { __syncthreads(); }
 inline void raw_barrier() { __syncthreads(); }
+inline void lds_write_drain() {}
 inline void wave_lds_fence() { hipemu::wave_sync(); }
 
 template <typename V8>

@@ -1,25 +1,38 @@
-"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / gloo on CPU.
+"""Multi-GPU plumbing: one process per GPU.
 
 How the path shards:
   * by SAMPLE — the reference's own scheme (run_eval_llava_siglip_multiimg.sh:9-11 + eval_utils.split_shard): replicas,
     no data-path collective.  ``shard_records`` is that split; bench.py uses ``barrier`` / ``max_over_ranks`` only.
-  * by ViT INPUT (tile) inside one sample: the 676-token tile sequences are independent through the tower and the
-    projector, so rank r encodes a contiguous, balanced slice of the tiles and ONE all-gather of the projected visual
-    tokens [N_r*169, 4096] restores the full, correctly ordered set on every rank (``encode_images_sharded``).
+  * ONE sample on all ranks (north_star: "shard the per-image ViT encodes and LLM tensor-parallel across the 8 GPUs"):
+      - the 676-token ViT inputs are independent through the tower and the projector: rank r encodes a balanced contiguous
+        slice of them and ONE all-gather of the projected visual tokens restores the full set (``encode_images_sharded``);
+      - the LLM runs tensor-parallel with SEQUENCE-PARALLEL norms (the Megatron exchange pattern,
+        Megatron-LM-240603/megatron/core/tensor_parallel/mappings.py:107-145, layers.py:387-454): the fp32 residual stream is
+        sharded by rows; per half layer  RMSNorm(local rows) -> all-gather (16-bit) -> column-parallel GEMM -> ... -> row-parallel
+        GEMM -> reduce-scatter (16-bit) -> residual add on the local rows  (LeopardEngine._llm_prefill_tp).
+
+Transports (``Comm``): on GPUs the data path uses RCCL through the C ABI (``RcclComm`` over lmi_comm_init / lmi_allgather /
+lmi_reduce_scatter / lmi_allreduce, stream-ordered, so collectives can run on a side stream under the next GEMM); the
+128-byte RCCL unique id travels over torch.distributed (backend "nccl" = RCCL), which also carries the barriers of bench.py.
+``TorchComm`` drives the same algorithms over any torch.distributed group — gloo in the CPU tests (emulated kernels) and in the
+functional 2-processes-on-one-GPU test.  There is NO silent fallback: if RCCL cannot come up on a GPU job, ``init`` raises.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
     """Initialise the default process group from the torchrun environment.  Returns (rank, world).
-    backend None = RCCL ("nccl") when a GPU is present, with gloo as the fallback if RCCL cannot come up: the data path has
-    no collective (sample sharding), so the group only carries the barrier and the max-over-ranks timing reduce."""
+    backend None = RCCL ("nccl") when a GPU is present, gloo otherwise.  A failing RCCL initialisation is an error (a job that
+    reports N ranks must have N RCCL ranks); pass backend="gloo" explicitly for CPU runs / the one-GPU functional test."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
@@ -27,20 +40,20 @@ def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -
         os.environ.setdefault("MASTER_PORT", "29500")
         want = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if want == "nccl":
-            try:
-                kw = {"device_id": device} if device is not None else {}
-                dist.init_process_group("nccl", rank=rank, world_size=world, **kw)
-                probe = torch.zeros(1, device=device if device is not None else "cuda")
-                dist.all_reduce(probe)                              # force communicator creation now, not in the timed region
-                torch.cuda.synchronize()
-            except Exception as e:                                  # pragma: no cover  (needs a multi-GPU node)
-                print(f"[leopard_amd.dist] RCCL init failed on rank {rank} ({e!r}); falling back to gloo", flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+            kw = {"device_id": device} if device is not None else {}
+            dist.init_process_group("nccl", rank=rank, world_size=world, **kw)
+            probe = torch.ones(1, device=device if device is not None else "cuda")
+            dist.all_reduce(probe)                                  # force communicator creation now, not in the timed region
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"RCCL all-reduce over {world} ranks returned {probe.item()}")
         else:
             dist.init_process_group(want, rank=rank, world_size=world)
     return rank, world
+
+
+def backend_name() -> str:
+    return dist.get_backend() if dist.is_initialized() else "none"
 
 
 def _reduce_device(device):
@@ -82,14 +95,167 @@ def tile_slices(n_tiles: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# transports
+# ------------------------------------------------------------------------------------------------------------------------------
+class Comm:
+    """Collectives of the one-sample-on-all-ranks path.  ``stream`` (a torch.cuda.Stream or None = current) is where the
+    collective is enqueued; ``sent_bytes`` accumulates the payload this rank contributed (comm_bytes_per_step in bench.py)."""
+    rank: int = 0
+    world: int = 1
+    backend: str = "none"
+    sent_bytes: int = 0
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor, stream=None): raise NotImplementedError
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, stream=None): raise NotImplementedError
+    def all_reduce(self, t: torch.Tensor, stream=None): raise NotImplementedError
+    def broadcast(self, t: torch.Tensor, root: int, stream=None): raise NotImplementedError
+    def ranks_seen(self) -> int: return self.world
+
+
+class TorchComm(Comm):
+    """torch.distributed default group (gloo: CPU tests and the two-processes-on-one-GPU functional test; also usable with
+    "nccl").  A gloo group reduces host tensors, so device tensors are staged through the host — functional checks only."""
+
+    def __init__(self):
+        assert dist.is_initialized()
+        self.rank, self.world, self.backend = dist.get_rank(), dist.get_world_size(), dist.get_backend()
+        self.sent_bytes = 0
+
+    def _host_staged(self, t):
+        return self.backend == "gloo" and t.device.type == "cuda"
+
+    def all_gather(self, out, inp, stream=None):
+        self.sent_bytes += inp.numel() * inp.element_size()
+        if self._host_staged(inp):
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, inp.cpu().contiguous())
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, inp)
+
+    def reduce_scatter(self, out, inp, stream=None):
+        self.sent_bytes += inp.numel() * inp.element_size()
+        if self._host_staged(inp):
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.reduce_scatter_tensor(h, inp.cpu().contiguous())
+            out.copy_(h)
+        else:
+            dist.reduce_scatter_tensor(out, inp)
+
+    def all_reduce(self, t, stream=None):
+        self.sent_bytes += t.numel() * t.element_size()
+        if self._host_staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def broadcast(self, t, root, stream=None):
+        if self._host_staged(t):
+            h = t.cpu()
+            dist.broadcast(h, src=root)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=root)
+
+
+_LMI_DT = {torch.float16: _lib.LMI_F16, torch.bfloat16: _lib.LMI_BF16, torch.float32: _lib.LMI_F32}
+
+
+class RcclComm(Comm):
+    """RCCL communicator owned by libleopard_amd.so (lmi_comm_init): collectives are plain stream-ordered C-ABI calls on raw
+    device pointers.  The unique id is created by rank 0 and broadcast over the torch.distributed group (the bootstrap)."""
+    backend = "rccl (lmi_comm)"
+
+    def __init__(self, lib=None, device: Optional[torch.device] = None):
+        assert dist.is_initialized(), "bootstrap group missing: call leopard_amd.dist.init() first"
+        self.lib = lib if lib is not None else _lib.load()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.sent_bytes = 0
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            self._check(self.lib.lmi_comm_unique_id(uid))
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
+        t = t.to(self.device) if dist.get_backend() != "gloo" else t
+        dist.broadcast(t, src=0)
+        uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+        handle = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        self._check(self.lib.lmi_comm_init(self.rank, self.world, uid, C.byref(handle)))
+        self.handle = handle
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libleopard_amd comm error {rc}: {self.lib.lmi_last_error().decode()}")
+
+    def _s(self, stream):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return C.c_void_p(s.cuda_stream)
+
+    def ranks_seen(self) -> int:
+        return int(self.lib.lmi_comm_size(self.handle))
+
+    def all_gather(self, out, inp, stream=None):
+        assert inp.is_contiguous() and out.is_contiguous() and out.numel() == inp.numel() * self.world and out.dtype == inp.dtype
+        self.sent_bytes += inp.numel() * inp.element_size()
+        self._check(self.lib.lmi_allgather(self.handle, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), inp.numel(),
+                                           _LMI_DT[inp.dtype], self._s(stream)))
+
+    def reduce_scatter(self, out, inp, stream=None):
+        assert inp.is_contiguous() and out.is_contiguous() and inp.numel() == out.numel() * self.world and out.dtype == inp.dtype
+        self.sent_bytes += inp.numel() * inp.element_size()
+        self._check(self.lib.lmi_reduce_scatter(self.handle, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(),
+                                                _LMI_DT[inp.dtype], self._s(stream)))
+
+    def all_reduce(self, t, stream=None):
+        assert t.is_contiguous()
+        self.sent_bytes += t.numel() * t.element_size()
+        self._check(self.lib.lmi_allreduce(self.handle, C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), t.numel(), _LMI_DT[t.dtype],
+                                           self._s(stream)))
+
+    def broadcast(self, t, root, stream=None):
+        assert t.is_contiguous()
+        self._check(self.lib.lmi_broadcast(self.handle, C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), t.numel(), _LMI_DT[t.dtype],
+                                           int(root), self._s(stream)))
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self.lib.lmi_comm_destroy(self.handle)
+            self.handle = None
+
+
+_COMM: Optional[Comm] = None
+
+
+def get_comm(device=None, lib=None) -> Optional[Comm]:
+    """The communicator of the one-sample-on-all-ranks path: RCCL through the C ABI when the bootstrap group is "nccl",
+    the torch.distributed group otherwise (gloo: CPU / functional tests).  None on a single rank."""
+    global _COMM
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    if _COMM is None:
+        _COMM = RcclComm(lib=lib, device=device) if dist.get_backend() == "nccl" else TorchComm()
+    return _COMM
+
+
+def reset_comm():
+    global _COMM
+    if isinstance(_COMM, RcclComm):
+        _COMM.destroy()
+    _COMM = None
+
+
 def encode_images_sharded(engine, tiles: torch.Tensor) -> torch.Tensor:
-    """Vision tower + projector with the tiles split across the ranks of the default group, then ONE all-gather of
-    the projected visual tokens.  Every rank returns the full fp32 [N*tokens_per_tile, D] tensor in tile order —
-    bit-identical to ``engine.encode_images(tiles)`` because tiles are independent sequences."""
-    world = world_size()
-    if world == 1:
+    """Vision tower + projector with the ViT inputs split across the ranks, then ONE all-gather of the projected visual
+    tokens.  Every rank returns the full fp32 [N*tokens_per_tile, D] tensor in tile order — bit-identical to
+    ``engine.encode_images(tiles)`` because tiles are independent sequences."""
+    comm = get_comm(tiles.device if tiles.is_cuda else None, getattr(engine.ops, "lib", None)) if engine.comm is None else engine.comm
+    if comm is None:
         return engine.encode_images(tiles)
-    rank = dist.get_rank()
+    world, rank = comm.world, comm.rank
     slices = tile_slices(tiles.shape[0], world)
     lo, hi = slices[rank]
     tpt = engine.cfg.tokens_per_tile
@@ -99,25 +265,6 @@ def encode_images_sharded(engine, tiles: torch.Tensor) -> torch.Tensor:
     if hi > lo:
         mine[:(hi - lo) * tpt] = engine.encode_images(tiles[lo:hi].contiguous())
     gathered = torch.empty(world * max_rows, D, dtype=torch.float32, device=tiles.device)
-    if dist.get_backend() == "gloo" and tiles.device.type == "cuda":            # fallback group: stage through the host
-        host = torch.empty(world * max_rows, D, dtype=torch.float32)
-        dist.all_gather_into_tensor(host, mine.cpu())
-        gathered.copy_(host)
-    else:
-        dist.all_gather_into_tensor(gathered, mine)              # equal-size padded shards, one collective
+    comm.all_gather(gathered, mine)                               # equal-size padded shards, one collective
     parts = [gathered[r * max_rows:r * max_rows + (b - a) * tpt] for r, (a, b) in enumerate(slices)]
     return torch.cat(parts, dim=0)
-
-
-def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
-    """In-place sum over ranks (the tensor-parallel exchange of the LLM: partial o_proj / down_proj products).  RCCL reduces
-    the device tensor on the current stream; gloo (CPU tests) reduces host tensors."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        if dist.get_backend() == "gloo" and t.device.type == "cuda":      # fallback group: stage through the host
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t
-

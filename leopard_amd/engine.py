@@ -92,13 +92,23 @@ class KVCache:
 
 class LeopardEngine:
     def __init__(self, cfg: LeopardConfig, weights: EngineWeights, ops: Optional[Ops] = None, device=None,
-                 use_tr: bool = True):
+                 use_tr: bool = True, comm=None):
         self.cfg, self.W = cfg, weights
         self.ops = ops if ops is not None else Ops()
         self.dtype = weights.dtype
         self.device = torch.device(device) if device is not None else weights.embed.device
         self.use_tr = use_tr
         self.use_graphs = True         # capture the decode step in a HIP graph (cuda devices only)
+        # tensor parallel (weights built with tp_size > 1): the communicator of the one-sample-on-all-ranks path (leopard_amd.dist)
+        self.comm = comm
+        if getattr(weights, "tp_size", 1) > 1 and comm is None:
+            from . import dist as D
+            self.comm = D.get_comm(self.device if self.device.type == "cuda" else None, getattr(self.ops, "lib", None))
+            if self.comm is None or self.comm.world != weights.tp_size:
+                raise RuntimeError(f"tensor-parallel weights (tp_size {weights.tp_size}) need an initialised process group of that size")
+        self.tp_chunks = 2             # row chunks per layer under TP: chunk c's collectives overlap chunk c+1's GEMMs
+        self.tp_comm_dtype = None      # dtype of the reduce-scattered partial products: None = the compute type, torch.float32 = exact sums
+        self._comm_stream = None
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
         tc = cfg.text_config
@@ -122,9 +132,8 @@ class LeopardEngine:
         if self.tp_size == 1:
             self.ops.gemm(a, w, x, epilogue=_lib.EPI_RESIDUAL)
             return
-        from . import dist as D
         self.ops.gemm(a, w, tmp, epilogue=_lib.EPI_STORE_F32)
-        D.all_reduce_sum(tmp)
+        self.comm.all_reduce(tmp)
         x.add_(tmp)
 
     def _empty(self, *shape, dtype=None):
@@ -265,7 +274,8 @@ class LeopardEngine:
         # (o_proj, down_proj) also emits T(x * gamma_next) and per-row partial sums of squares; the GEMM that consumes them
         # (gate/up, next layer's qkv) applies rstd to its accumulator rows; the qkv GEMM rotates q / k and appends K / V to the
         # cache in its epilogue.  Only the very first norm of the stack is a launch of its own.
-        fused = self.fuse_norm_rope and self.tp_size == 1 and hd == 128 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None
+        fused = (self.fuse_norm_rope and self.tp_size == 1 and hd == 128 and D % 256 == 0 and W.llm_layers
+                 and W.llm_layers[0].qkv_w_rope is not None)
         if fused:
             parts = D // 64
             sq_a = self._empty(S, parts, dtype=torch.float32)       # partials feeding gate/up
@@ -327,6 +337,10 @@ class LeopardEngine:
     def prefill(self, input_ids: torch.Tensor, tiles: Optional[torch.Tensor], cache: Optional[KVCache] = None,
                 all_logits: bool = False, keep_parts: bool = False, visual_tokens: Optional[torch.Tensor] = None
                 ) -> PrefillResult:
+        if self.tp_size > 1:
+            if all_logits or keep_parts:
+                raise NotImplementedError("all_logits / keep_parts are single-rank diagnostics")
+            return self._prefill_tp(input_ids, tiles, cache, visual_tokens)
         parts = {} if keep_parts else None
         n_tiles = 0
         if visual_tokens is None and tiles is not None and tiles.shape[0] > 0:
@@ -345,6 +359,166 @@ class LeopardEngine:
         S = x.shape[0]
         last, all_ = self.llm_prefill(x, [S], cache=cache, all_logits=all_logits)
         return PrefillResult(logits_last=last[0], seq_len=S, n_tiles=n_tiles, logits_all=all_, parts=parts)
+
+
+    # ------------------------------------------------------------------------------------------------
+    # ONE sample on all ranks (SURVEY.md 8e phases A + B): tile-sharded vision encode + one all-gather, then the
+    # LLM tensor-parallel with sequence-parallel norms.  The fp32 residual stream is sharded by rows: with R ranks and NC row
+    # chunks, chunk c holds global rows [c*R*Sl, (c+1)*R*Sl) and rank r owns rows [c*R*Sl + r*Sl, +Sl) of it.  Per half layer
+    # and chunk:  RMSNorm(own rows) -> all-gather (16-bit, [R*Sl, D]) -> column-parallel GEMM(s) on all rows of the chunk for
+    # this rank's heads / FFN slice -> row-parallel GEMM -> reduce-scatter (16-bit) -> residual add on the own rows.
+    # Collectives go to a side stream; chunk c's exchange runs under chunk c+1's GEMMs.  Causal attention makes the row chunks
+    # independent in the right order: chunk c attends to the K/V rows of chunks <= c, which the cache already holds.
+    # ------------------------------------------------------------------------------------------------
+    def _tp_geometry(self, S: int):
+        R, NC = self.tp_size, max(1, int(self.tp_chunks))
+        Sl = -(-S // (R * NC))
+        Sl = (Sl + 7) // 8 * 8                                  # 16-byte aligned row blocks for the collectives
+        return R, NC, Sl, R * Sl
+
+    def tp_padded_len(self, S: int) -> int:
+        """KV-cache rows a tensor-parallel prefill of S tokens writes (the row chunks are padded to equal size)."""
+        R, NC, Sl, Sc = self._tp_geometry(S)
+        return NC * Sc
+
+    @torch.no_grad()
+    def _prefill_tp(self, input_ids, tiles, cache, visual_tokens):
+        from . import dist as D
+        cfg, ops, W, tc = self.cfg, self.ops, self.W, self.cfg.text_config
+        comm, dev = self.comm, self.device
+        if visual_tokens is None and tiles is not None and tiles.shape[0] > 0:
+            visual_tokens = D.encode_images_sharded(self, tiles)
+        n_tiles = 0 if visual_tokens is None else visual_tokens.shape[0] // cfg.tokens_per_tile
+        ids_host = input_ids.detach().reshape(-1).to("cpu", torch.int64)
+        n_rows = 0 if visual_tokens is None else visual_tokens.shape[0]
+        src = plan_merge(ids_host.numpy(), cfg.image_token_index, n_rows, cfg.tokens_per_tile)
+        S = len(src)
+        R, NC, Sl, Sc = self._tp_geometry(S)
+        rank = comm.rank
+        if cache is None:
+            cache = KVCache(cfg, NC * Sc, self.dtype, dev, tp_size=R)
+        assert cache.length == 0 and cache.capacity >= NC * Sc, "tensor-parallel prefill needs cache capacity >= tp_padded_len(S)"
+        # merged embeddings of the rows this rank owns, chunk by chunk (rows past S: any text row, finite and never used)
+        ids_dev = self._pinned_to_device(ids_host.contiguous()) if input_ids.device != dev else input_ids.reshape(-1).to(torch.int64).contiguous()
+        pad_src = int(np.nonzero(src >= 0)[0][0]) if (src >= 0).any() else 0
+        D_ = tc.hidden_size
+        xs = []
+        for c in range(NC):
+            g0 = c * Sc + rank * Sl
+            loc = np.full(Sl, src[pad_src], dtype=np.int64)
+            n_real = max(0, min(Sl, S - g0))
+            loc[:n_real] = src[g0:g0 + n_real]
+            x = self._empty(Sl, D_, dtype=torch.float32)
+            ops.embed_merge(ids_dev, self._pinned_to_device(torch.from_numpy(loc)), W.embed, visual_tokens, x)
+            xs.append(x)
+        self._llm_layers_tp(xs, S, cache)
+        cache.length = S
+        # last real row -> every rank (fp32, 16 KB), then the column-parallel head: rank r computes its slice of the vocabulary
+        last = S - 1
+        c_l, r_l, l_l = last // Sc, (last % Sc) // Sl, last % Sl
+        xrow = xs[c_l][l_l:l_l + 1].clone() if rank == r_l else self._empty(1, D_, dtype=torch.float32)
+        comm.broadcast(xrow, r_l)
+        Vp = W.lm_head.shape[0]
+        Vl = -(-Vp // R)
+        lo, hi = min(Vp, rank * Vl), min(Vp, (rank + 1) * Vl)
+        mine = torch.zeros(1, Vl, dtype=torch.float32, device=dev)
+        if hi > lo:
+            ops.lm_head_last(W.lm_head[lo:hi], xrow, None, W.final_norm, tc.rms_norm_eps, mine[:, :hi - lo])
+        full = self._empty(R * Vl, dtype=torch.float32)
+        comm.all_gather(full, mine.reshape(-1))
+        return PrefillResult(logits_last=full[:tc.vocab_size], seq_len=S, n_tiles=n_tiles)
+
+    def _llm_layers_tp(self, xs, S: int, cache: KVCache):
+        """The sequence-parallel layer loop over the row chunks ``xs`` (fp32 [Sl, D] each, updated in place)."""
+        ops, W, tc, comm = self.ops, self.W, self.cfg.text_config, self.comm
+        R, NC, Sl, Sc = self._tp_geometry(S)
+        (H, KV), hd, D_ = self._llm_heads(), tc.head_dim, tc.hidden_size
+        qw, kw = H * hd, KV * hd
+        dev, T = self.device, self.dtype
+        cdt = self.tp_comm_dtype or T
+        on_gpu = dev.type == "cuda" and not ops.emulated
+        if on_gpu and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        cs = self._comm_stream if on_gpu else None
+        ms = torch.cuda.current_stream(dev) if on_gpu else None
+
+        def to_comm():                 # everything enqueued on the compute stream so far happens-before what follows on the comm stream
+            if on_gpu:
+                cs.wait_stream(ms)
+
+        def done():                    # marker on the comm stream for the compute stream to wait on
+            if not on_gpu:
+                return None
+            e = torch.cuda.Event()
+            e.record(cs)
+            return e
+
+        def wait(e):
+            if e is not None:
+                ms.wait_event(e)
+        pos = torch.arange(NC * Sc)
+        cos, sin = self.rope_tables(pos)
+        h_loc = [self._empty(Sl, D_) for _ in range(NC)]
+        h_full = [self._empty(Sc, D_) for _ in range(NC)]
+        part = [self._empty(Sc, D_, dtype=cdt) for _ in range(NC)]
+        red = [self._empty(Sl, D_, dtype=cdt) for _ in range(NC)]
+        qkv = self._empty(Sc, qw + 2 * kw)
+        att = self._empty(Sc, qw)
+        gu = self._empty(Sc, W.llm_ff)
+        cu_q = torch.tensor([0, Sc], dtype=torch.int32, device=dev)
+        cu_k = [torch.tensor([0, (c + 1) * Sc], dtype=torch.int32, device=dev) for c in range(NC)]
+        scale = hd ** -0.5
+        epi_part = _lib.EPI_STORE if cdt == T else _lib.EPI_STORE_F32
+        fused_rope = self.fuse_norm_rope and hd == 128 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None
+        n_layers = len(W.llm_layers)
+        ev = [None] * NC
+        for li, L in enumerate(W.llm_layers):
+            # ---- attention half ----------------------------------------------------------------------------------------
+            for c in range(NC):
+                if li == 0:
+                    ops.rmsnorm(xs[c], L.in_norm, h_loc[c], tc.rms_norm_eps)
+                to_comm()
+                comm.all_gather(h_full[c], h_loc[c], cs)
+                ev[c] = done()
+            for c in range(NC):
+                wait(ev[c])
+                kc, vc = cache.k[li], cache.v[li]
+                if fused_rope:
+                    ops.rmsnorm_rope(h_full[c], L.qkv_w_rope, qkv, None, tc.rms_norm_eps, cos[c * Sc:(c + 1) * Sc], sin[c * Sc:(c + 1) * Sc],
+                                     kc, vc, c * Sc, H, KV, hd)
+                else:
+                    ops.gemm(h_full[c], L.qkv_w, qkv)
+                    ops.rope_qk(qkv, H, KV, hd, cos[c * Sc:(c + 1) * Sc], sin[c * Sc:(c + 1) * Sc], kc, vc, c * Sc)
+                ops.attention(qkv[:, :qw], kc[:(c + 1) * Sc], vc[:(c + 1) * Sc], att, cu_q, cu_k[c], Sc, H, KV, hd, scale, True,
+                              self.use_tr, window=tc.sliding_window or 0)
+                ops.gemm(att, L.o_w, part[c], epilogue=epi_part)
+                to_comm()
+                comm.reduce_scatter(red[c], part[c], cs)
+                ev[c] = done()
+            # ---- MLP half ----------------------------------------------------------------------------------------------
+            for c in range(NC):
+                wait(ev[c])
+                ops.add_rmsnorm(xs[c], red[c], L.post_norm, h_loc[c], tc.rms_norm_eps)
+                to_comm()
+                comm.all_gather(h_full[c], h_loc[c], cs)
+                ev[c] = done()
+            for c in range(NC):
+                wait(ev[c])
+                ops.gemm(h_full[c], L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
+                ops.gemm(gu, L.down_w, part[c], epilogue=epi_part)
+                to_comm()
+                comm.reduce_scatter(red[c], part[c], cs)
+                ev[c] = done()
+            for c in range(NC):
+                wait(ev[c])
+                if li + 1 < n_layers:
+                    ops.add_rmsnorm(xs[c], red[c], W.llm_layers[li + 1].in_norm, h_loc[c], tc.rms_norm_eps)
+                else:
+                    ops.add_rmsnorm(xs[c], red[c], None, None, tc.rms_norm_eps)
+            if self.trace:
+                self.trace(f"llm.{li}", xs)
+        if on_gpu:
+            ms.wait_stream(cs)
 
     @torch.no_grad()
     def prefill_batch(self, samples: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]]):
@@ -413,9 +587,8 @@ class LeopardEngine:
             if not tp:
                 ops.gemv(w, a, st.x[0], epilogue=2)
                 return
-            from . import dist as D
             ops.gemv(w, a, st.part, epilogue=0)
-            D.all_reduce_sum(st.part)
+            self.comm.all_reduce(st.part)
             st.x[0].add_(st.part)
         ops.embed_merge(st.tok, st.src0, W.embed, None, st.x)
         fuse = tc.hidden_size == 4096                 # lmi_gemv_rmsnorm: the norm rides in the projection's launch
@@ -484,7 +657,8 @@ class LeopardEngine:
         ids = input_ids.reshape(1, -1)
         n_img = int((ids == self.cfg.image_token_index).sum())
         S = ids.shape[1] + n_img * (self.cfg.tokens_per_tile - 1)
-        cache = KVCache(self.cfg, S + max_new_tokens, self.dtype, self.device, tp_size=self.tp_size)
+        cap = (self.tp_padded_len(S) if self.tp_size > 1 else S) + max_new_tokens
+        cache = KVCache(self.cfg, cap, self.dtype, self.device, tp_size=self.tp_size)
         res = self.prefill(ids, tiles, cache=cache)
         out = [int(t) for t in ids.reshape(-1).tolist()]
         nxt = int(res.logits_last.argmax())

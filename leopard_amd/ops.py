@@ -198,3 +198,11 @@ class Ops:
                                               _ptr(k_cache), _ptr(v_cache), ldc, int(cache_pos0), M, n_q_heads, n_kv_heads, head_dim, K,
                                               a.stride(0), w_qkv_rope.stride(0), qkv.stride(0), _DT[w_qkv_rope.dtype], self._stream(qkv)))
         return qkv
+
+    def add_rmsnorm(self, x, delta, w, out, eps):
+        """x (fp32, in place) += delta (compute type or fp32); out = rmsnorm(x) * w in the compute type (out None: add only)."""
+        M, D = x.shape
+        dt = _DT[out.dtype] if out is not None else (_DT[delta.dtype] if delta.dtype != torch.float32 else LMI_F16)
+        self._check(self.lib.lmi_add_rmsnorm(_ptr(x), _ptr(delta), _DT[delta.dtype], _ptr(w), _ptr(out), M, D, x.stride(0), delta.stride(0),
+                                             0 if out is None else out.stride(0), float(eps), dt, self._stream(x)))
+        return out

@@ -97,26 +97,38 @@ def _tp_worker(rank, world, port, out):
     assert eng.tp_size == world and eng.W.llm_layers[0].qkv_w.shape[0] == (1 + 2) * 128 and eng.W.llm_layers[0].down_w.shape[1] == 64
     tiles = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
     ids = torch.tensor([[5, 250, 9, 250, 17, 33]])
-    cache = KVCache(cfg, 16, torch.float16, "cpu", tp_size=world)
+    S = ids.shape[1] + 2 * (cfg.tokens_per_tile - 1)
+    cache = KVCache(cfg, eng.tp_padded_len(S) + 4, torch.float16, "cpu", tp_size=world)
     assert cache.k[0].shape[1] == 128                              # this rank's one kv head
     res = eng.prefill(ids, tiles, cache=cache)
+    assert res.seq_len == S and cache.length == S
     step = eng.decode_step(int(res.logits_last.argmax()), cache).clone()
     gen = eng.generate(ids, tiles, max_new_tokens=3, eos_token_id=())
+    # exact-sum exchange (fp32 partial products), one row chunk, unfused rope: same logits up to fp32 summation order
+    eng.tp_comm_dtype, eng.tp_chunks, eng.fuse_norm_rope = torch.float32, 1, False
+    res32 = eng.prefill(ids, tiles)
+    eng.tp_comm_dtype, eng.tp_chunks, eng.fuse_norm_rope = None, 2, True
+    sent = eng.comm.sent_bytes
     ref = None
     if rank == 0:                                                  # the same model on one rank
         one = LeopardEngine(cfg, EngineWeights.build(cfg, src, torch.float16), ops=ops, device="cpu")
         c1 = KVCache(cfg, 16, torch.float16, "cpu")
         r1 = one.prefill(ids, tiles, cache=c1)
         s1 = one.decode_step(int(r1.logits_last.argmax()), c1).clone()
+        one.fuse_norm_rope = False
+        r1u = one.prefill(ids, tiles)
+        one.fuse_norm_rope = True
         ref = (float((res.logits_last - r1.logits_last).abs().max()), float((step - s1).abs().max()),
-               gen.tolist() == one.generate(ids, tiles, max_new_tokens=3, eos_token_id=()).tolist(), float(r1.logits_last.abs().max()))
+               gen.tolist() == one.generate(ids, tiles, max_new_tokens=3, eos_token_id=()).tolist(), float(r1.logits_last.abs().max()),
+               float((res32.logits_last - r1u.logits_last).abs().max()), sent)
     out.put((rank, res.logits_last.tolist(), ref))
     D.barrier()
 
 
 def test_tensor_parallel_llm_two_ranks_gloo():
-    """SURVEY.md 8e phase B on CPU: the LLM sharded over 2 ranks (heads / FFN slices, all-reduce of the partial o_proj and
-    down_proj products) gives every rank the logits of the unsharded model, in prefill, decode and greedy generation."""
+    """SURVEY.md 8e phase B on CPU: the LLM sharded over 2 ranks — heads / FFN slices, sequence-parallel norms, all-gather of the
+    normalised rows, reduce-scatter of the partial o_proj / down_proj products in two row chunks, column-parallel last-token
+    head — gives every rank the logits of the unsharded model, in prefill, decode and greedy generation."""
     mp.set_start_method("spawn", force=True)
     from tests.emu_util import emu_ops
     emu_ops()
@@ -132,5 +144,7 @@ def test_tensor_parallel_llm_two_ranks_gloo():
         assert p.exitcode == 0
     (_, l0, ref), (_, l1, _) = res
     assert l0 == l1                                                # both ranks hold the same, complete logits
-    d_prefill, d_decode, same_tokens, scale = ref
-    assert d_prefill <= 2e-3 * max(1.0, scale) and d_decode <= 2e-3 * max(1.0, scale) and same_tokens
+    d_prefill, d_decode, same_tokens, scale, d_exact, sent = ref
+    assert d_prefill <= 3e-3 * max(1.0, scale) and d_decode <= 3e-3 * max(1.0, scale) and same_tokens
+    assert d_exact <= 2e-4 * max(1.0, scale)                       # fp32 exchange: only the summation order differs
+    assert sent > 0

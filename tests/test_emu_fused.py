@@ -100,7 +100,7 @@ def rope_ref(x, cos, sin):
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 5, 8])
 @pytest.mark.parametrize("with_norm", [False, True])
 def test_rmsnorm_rope_qkv_projection(ops, dtype, cfg, with_norm):
-    S, nq, nkv, D, K = 150, 2, 1, 128, 128
+    S, nq, nkv, D, K = 150, 2, 1, 128, 256
     a = rnd((S, K), dtype, 10)
     wq, wk, wv = rnd((nq * D, K), dtype, 11, 0.1), rnd((nkv * D, K), dtype, 12, 0.1), rnd((nkv * D, K), dtype, 13, 0.1)
     w_nat = torch.cat([wq, wk, wv], 0)
@@ -175,3 +175,36 @@ def test_fused_llm_schedule_matches_unfused():
     Wt = O.weights_from_numpy(synth_state_dict_numpy(cfg))
     ref = O.prefill_logits(ids, torch.from_numpy(siglip_normalize(tiles.numpy())), Wt, cfg)[0]
     assert (rf.logits_all - ref).abs().max().item() <= 4e-3 * scale
+
+
+def test_fused_schedule_is_position_independent():
+    """Packing two sequences into one varlen launch must give each of them exactly the bits of its own launch (the GPU tests
+    assert this at the C3 / C5 sizes): the folded norm's partial sums and row scales may not depend on where a row sits in
+    the packed batch or on the tile geometry chosen for the batch size."""
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    from leopard_amd.engine import LeopardEngine
+    from leopard_amd.weights import EngineWeights, SynthSource
+    ops = emu_ops()
+    cfg = LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16,
+                                   image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                               num_key_value_heads=1, vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    g = torch.Generator().manual_seed(3)
+    xa, xb = torch.randn(37, 256, generator=g), torch.randn(11, 256, generator=g)
+    for cfg_id in (-1, 0, 5):
+        ops.set_option("gemm.config", cfg_id)
+        la, _ = eng.llm_prefill(xa.clone(), [37])
+        lb, _ = eng.llm_prefill(xb.clone(), [11])
+        lab, _ = eng.llm_prefill(torch.cat([xa, xb]), [37, 11])
+        lba, _ = eng.llm_prefill(torch.cat([xb, xa]), [11, 37])
+        assert torch.equal(lab[0], la[0]) and torch.equal(lab[1], lb[0])
+        assert torch.equal(lba[0], lb[0]) and torch.equal(lba[1], la[0])
+        if cfg_id == -1:
+            base = la
+        else:
+            assert torch.equal(la, base)                 # ... nor on the tile geometry
+    ops.set_option("gemm.config", -1)
