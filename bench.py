@@ -297,6 +297,50 @@ def bench_idefics2(args, dev, dtype, rank, world, D):
         print(json.dumps(out), flush=True)
 
 
+def measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler):
+    """ONE sample per step on all ranks (north_star's partitioning): tile-sharded vision encode + one all-gather,
+    sequence-parallel tensor-parallel LLM (all-gather / reduce-scatter per half layer over RCCL, LeopardEngine._llm_layers_tp),
+    column-parallel last-token head.  Same timed region as the headline (tiler -> last-position logits); strong scaling."""
+    from leopard_amd.engine import KVCache, LeopardEngine
+    from leopard_amd.weights import EngineWeights, SynthSource
+    Wt = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype, tp_rank=rank, tp_size=world)
+    eng = LeopardEngine(cfg, Wt, ops=ops, device=dev)
+    eng.fuse_norm_rope = not args.no_fuse
+    u8, ids_np, plan, _, raw = make_sample(cfg, args.images, args.width, args.height, seed=0)       # the SAME sample on every rank
+    raw_dev = [torch.from_numpy(np.ascontiguousarray(r)).to(dev) for r in raw]
+    ids = torch.from_numpy(ids_np).reshape(1, -1)
+    S = ids.shape[1] + u8.shape[0] * (cfg.tokens_per_tile - 1)
+    cache = KVCache(cfg, eng.tp_padded_len(S), dtype, dev, tp_size=world)
+
+    def step():
+        cache.length = 0
+        return eng.prefill(ids, gpu_tiler.tile_sample(raw_dev)[0], cache=cache)
+
+    def barrier():
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    sent0 = eng.comm.sent_bytes
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert res.seq_len == S and torch.isfinite(res.logits_last).all()
+    fl = algorithmic_flops(cfg, u8.shape[0], S)
+    return {"value": round(args.images * args.steps / elapsed, 3), "unit": "images/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "scaling": "strong", "n_gpus": world,
+            "parallelism": f"one sample on {world} ranks: ViT inputs sharded {u8.shape[0]} -> {world} + 1 all-gather; TP{world} LLM with "
+                           f"sequence-parallel norms ({eng.tp_chunks} row chunks, all-gather + reduce-scatter per half layer in "
+                           f"{'fp32' if eng.tp_comm_dtype == torch.float32 else args.dtype}), column-parallel head",
+            "backend": eng.comm.backend, "rccl_ranks": eng.comm.ranks_seen(),
+            "comm_bytes_per_step_per_rank": int((eng.comm.sent_bytes - sent0) / args.steps),
+            "prefill_mfma_frac_of_n_gpus": round(fl["total"] / 1e12 / (elapsed / args.steps) / (MFMA_PEAK_TFLOPS * world), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,12 +356,14 @@ def main():
                     help="independent samples in flight per GPU, each on its own HIP stream (1 = the reference's one-sample-at-a-time loop)")
     ap.add_argument("--parallelism", default="sample", choices=["sample", "tp"],
                     help="N > 1: 'sample' = one sample per rank, no data-path collective (default, weak scaling); 'tp' = ONE sample "
-                         "per step on all ranks: tile-sharded vision encode + all-gather, tensor-parallel LLM with two all-reduces "
-                         "per layer (strong scaling, single-sample latency)")
+                         "per step on all ranks as the headline (strong scaling).  With 'sample' and N > 1 the one-sample-on-all-ranks "
+                         "figure is measured as well and reported under \"tp\" in the same JSON line")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (lmi_set_option), e.g. gemm.wide=7 for A/B runs")
     ap.add_argument("--no-fuse", action="store_true", help="A/B: separate RMSNorm / RoPE launches instead of the fused GEMM epilogues")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-tp", action="store_true", help="N > 1: skip the additional one-sample-on-all-ranks (strong scaling) measurement")
+    ap.add_argument("--tp-timeout", type=float, default=240.0, help="watchdog of the additional tensor-parallel measurement, seconds")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -348,7 +394,24 @@ def main():
         ops.set_option(k, int(v))
     t0 = time.perf_counter()
     tp = args.parallelism == "tp" and world > 1
-    W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype, tp_rank=rank if tp else 0, tp_size=world if tp else 1)
+    from leopard_amd.gpu_tiler import GpuTiler
+    if tp:                                       # headline = ONE sample on all ranks
+        r = measure_tp(args, cfg, ops, dev, dtype, rank, world, D, GpuTiler(ops, dev))
+        out = {"metric": "multi-image prefill images/sec (Leopard-LLaVA, 6x1344x896 per sample)", "value": r["value"], "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"C3: {args.images}x({args.width}x{args.height}) images, one sample per step on all ranks",
+                          "parallelism": r["parallelism"]},
+               "backend": r["backend"], "rccl_ranks": r["rccl_ranks"], "comm_bytes_per_step": r["comm_bytes_per_step_per_rank"] * world,
+               "tp": r}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        D.barrier()
+        D.reset_comm()
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        return
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
     torch.cuda.synchronize()
     eng = LeopardEngine(cfg, W, ops=ops, device=dev)
     eng.fuse_norm_rope = not args.no_fuse
@@ -362,7 +425,7 @@ def main():
     host_tiler_s = gpu_tiler_s = 0.0
     for j in range(args.inflight):
         c = Ctx()
-        u8, ids_np, plan, tiler_s, raw = make_sample(cfg, args.images, args.width, args.height, seed=(0 if tp else rank) * 16 + j)
+        u8, ids_np, plan, tiler_s, raw = make_sample(cfg, args.images, args.width, args.height, seed=rank * 16 + j)
         host_tiler_s = max(host_tiler_s, tiler_s)
         gpu_tiler.tile_sample(raw)                                 # warm (tap tables, allocator)
         torch.cuda.synchronize()
@@ -378,7 +441,7 @@ def main():
         c.ids = torch.from_numpy(ids_np).reshape(1, -1)            # token ids stay host-side, like a tokenizer's output
         c.n_tiles = u8.shape[0]
         c.S = c.ids.shape[1] + c.n_tiles * (cfg.tokens_per_tile - 1)
-        c.cache = KVCache(cfg, c.S, dtype, dev, tp_size=world if tp else 1)
+        c.cache = KVCache(cfg, c.S, dtype, dev)
         c.stream = torch.cuda.Stream(device=dev) if args.inflight > 1 else torch.cuda.current_stream(dev)
         ctxs.append(c)
     n_tiles, S = ctxs[0].n_tiles, ctxs[0].S
@@ -391,10 +454,7 @@ def main():
             with torch.cuda.stream(c.stream):
                 c.cache.length = 0
                 tiles = gpu_tiler.tile_sample(c.raw)[0] if with_tiler else c.tiles
-                if tp:       # every rank encodes its slice of the ViT inputs, one all-gather, then the tensor-parallel LLM
-                    out = eng.prefill(c.ids, None, cache=c.cache, visual_tokens=D.encode_images_sharded(eng, tiles))
-                else:
-                    out = eng.prefill(c.ids, tiles, cache=c.cache)
+                out = eng.prefill(c.ids, tiles, cache=c.cache)
         return out
 
     def barrier():
@@ -421,20 +481,22 @@ def main():
         step(with_tiler=False)
     barrier()
     ms_excl_tiler = D.max_over_ranks(time.perf_counter() - t0, dev) / n_ex * 1e3
-    images_per_s = (1 if tp else world) * args.inflight * args.images * args.steps / elapsed
+    images_per_s = world * args.inflight * args.images * args.steps / elapsed
     fl = algorithmic_flops(cfg, n_tiles, S)
 
     out = {
         "metric": "multi-image prefill images/sec (Leopard-LLaVA, 6x1344x896 per sample)",
         "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"C3: {args.images}x({args.width}x{args.height}) images -> {n_tiles} ViT inputs (364x364), "
                                f"{n_tiles * cfg.tokens_per_tile} visual tokens, S={S}; SigLIP-SO400M/14 (27L) + Llama-3.1-8B (32L) "
                                "prefill to last-token logits, KV cache written; synthetic seeded weights",
-                   "samples_per_rank_per_step": args.inflight, "samples_in_flight_per_gpu": args.inflight, "parallelism": (f"one sample on {world} ranks: tile-sharded ViT + all-gather, TP{world} LLM (2 all-reduces / layer)" if tp
-                                   else f"sample-sharded x{world} (no data-path collective)")},
-        "visual_tokens_per_s": round((1 if tp else world) * args.inflight * n_tiles * cfg.tokens_per_tile * args.steps / elapsed, 1),
+                   "samples_per_rank_per_step": args.inflight, "samples_in_flight_per_gpu": args.inflight,
+                   "parallelism": f"sample-sharded x{world} (the reference's scheme: one process per GPU over dataset shards, no data-path collective)"},
+        "backend": ("rccl (torch.distributed nccl): barrier + timing reduce only" if world > 1 else "none"),
+        "rccl_ranks": (world if world > 1 and D.backend_name() == "nccl" else 0), "comm_bytes_per_step": 0,
+        "visual_tokens_per_s": round(world * args.inflight * n_tiles * cfg.tokens_per_tile * args.steps / elapsed, 1),
         "algorithmic_tflop_per_step": round(args.inflight * fl["total"] / 1e12, 2),
         "prefill_mfma_frac": round(args.inflight * fl["total"] / 1e12 / (elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4),
         "timed_region": "tiler (GPU, from source pixels resident in HBM) -> ViT -> projector -> merge -> LLM prefill -> last-token logits",
@@ -443,7 +505,7 @@ def main():
         "weight_load_s": round(load_s, 1),
     }
 
-    if rank == 0 and not args.no_roofline and not tp:     # (under tp a rank-0-only pass would leave the collectives unmatched)
+    if rank == 0 and not args.no_roofline:
         timer = GemmTimer()
         inner = timer.wrap(ops)
         torch.cuda.synchronize()
@@ -488,12 +550,42 @@ def main():
             "c3_extrapolated": {"value": round(args.images / (fl["total"] / 1e12 / tflops), 5), "unit": "images/s",
                                 "sample": f"2 SigLIP layers x 2 tiles + 1 Llama layer at S=1024 ({t:.2f} s, {tflops:.3f} TFLOP/s), "
                                           "scaled to the C3 sample (140.1 TFLOP) by algorithmic FLOPs"}}
+    if world > 1 and not args.no_tp:
+        # The same sample on ALL ranks (strong scaling), reported beside the replica headline.  It is the part of this program that
+        # no 1-GPU box can exercise, so it runs under a watchdog: whatever happens in it, rank 0 still prints the headline line.
+        import threading
+        done = threading.Event()
+
+        def give_up():
+            if done.is_set():
+                return
+            if rank == 0:
+                out["tp"] = {"error": f"tensor-parallel measurement did not finish within {args.tp_timeout:.0f} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        timer = threading.Timer(args.tp_timeout, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            del eng, W
+            ctxs.clear()
+            torch.cuda.empty_cache()
+            D.barrier()
+            out["tp"] = measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler)
+        except Exception as e:                                      # noqa: BLE001  (reported, not swallowed: the line carries it)
+            out["tp"] = {"error": repr(e)[:500]}
+        done.set()
+        timer.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
-        D.barrier()
-        dist.destroy_process_group()
+        try:
+            D.barrier()
+            D.reset_comm()
+            dist.destroy_process_group()
+        except Exception:                                           # noqa: BLE001  (teardown only; the result line is out)
+            pass
 
 
 if __name__ == "__main__":

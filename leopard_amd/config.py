@@ -105,6 +105,8 @@ class LeopardConfig:
     # converter, hf2megatron_llava.py:1050-1052) -------------------------------------------------
     def to_dict(self) -> dict:
         d = dataclasses.asdict(self)
+        d.pop("use_return_dict")            # a read-only property of HF configs (serialised as "return_dict"): AutoConfig rejects the key
+        d["return_dict"] = self.use_return_dict
         d["model_type"] = "llava"
         return d
 
@@ -124,6 +126,8 @@ class LeopardConfig:
             tcfg.rope_scaling = rs
         top = {k: v for k, v in d.items()
                if k in {f.name for f in dataclasses.fields(cls)} and k not in ("vision_config", "text_config")}
+        if "return_dict" in d:
+            top["use_return_dict"] = bool(d["return_dict"])
         return cls(vision_config=VisionConfig(**{k: v for k, v in vc.items() if k in vkeys}),
                    text_config=tcfg, **top)
 

@@ -260,12 +260,14 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     const float* sn = p.rope_sin + (long)mc * 64 + d1;
                     const f32x4 cs0 = *(const f32x4*)cs, cs1 = *(const f32x4*)(cs + 4);
                     const f32x4 sn0 = *(const f32x4*)sn, sn1 = *(const f32x4*)(sn + 4);
+                    // explicit fma shape (one individually rounded product, one fused multiply-add): left to the compiler, each
+                    // kernel instantiation contracts `a*c - b*s` its own way and a row's bits would depend on the tile geometry
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o1[e] = (T)(a0[e] * cs0[e] - b0[e] * sn0[e]);
-                        o1[4 + e] = (T)(a1[e] * cs1[e] - b1[e] * sn1[e]);
-                        o2[e] = (T)(b0[e] * cs0[e] + a0[e] * sn0[e]);
-                        o2[4 + e] = (T)(b1[e] * cs1[e] + a1[e] * sn1[e]);
+                        o1[e] = (T)__builtin_fmaf(a0[e], cs0[e], -mul_rn(b0[e], sn0[e]));
+                        o1[4 + e] = (T)__builtin_fmaf(a1[e], cs1[e], -mul_rn(b1[e], sn1[e]));
+                        o2[e] = (T)__builtin_fmaf(b0[e], cs0[e], mul_rn(a0[e], sn0[e]));
+                        o2[4 + e] = (T)__builtin_fmaf(b1[e], cs1[e], mul_rn(a1[e], sn1[e]));
                     }
                 }
                 if (m < p.M) {
@@ -347,7 +349,9 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 // sum of squares of this wave's 64 columns of the updated row: the 8 lanes of a row are consecutive; every lane
                 // takes part (rows past M carry clamped duplicates and are not stored)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sq += v0[it][e] * v0[it][e] + v1[it][e] * v1[it][e];
+                for (int e = 0; e < 4; ++e) sq = __builtin_fmaf(v0[it][e], v0[it][e], sq);       // fixed fma chain: same bits in every instantiation
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sq = __builtin_fmaf(v1[it][e], v1[it][e], sq);
                 sq += shfl_xor(sq, 1); sq += shfl_xor(sq, 2); sq += shfl_xor(sq, 4);
             }
             if (mb + it * RPI + r_in >= p.M) continue;
@@ -468,7 +472,6 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     stager.init(p, m0, n0, tid, smem, wave);
     auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
     float* rstd_lds = (float*)(smem + C::SMEM);
-    if (p.rowsq_in) { gemm_tile_rstd<C>(p, m0, tid, rstd_lds); lds_write_drain(); }   // visible after the first barrier
 
     f32x16 acc[C::NI][C::MI];
 #pragma unroll
@@ -488,6 +491,8 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int g = 0; g < C::G; ++g) issue_piece(g, d, d);
         }
+    // folded RMSNorm: the row scales of this tile, computed under the flight of the first k-tiles (visible after the first barrier)
+    if (p.rowsq_in) { gemm_tile_rstd<C>(p, m0, tid, rstd_lds); lds_write_drain(); }
 
     for (int t = 0; t < nt; ++t) {
         // tile t has landed once at most the D-1 younger tiles are outstanding (ring tail: everything)
@@ -554,7 +559,6 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     stager.init(p, m0, n0, tid, smem, wave);
     auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
     float* rstd_lds = (float*)(smem + C::SMEM);
-    if (p.rowsq_in) { gemm_tile_rstd<C>(p, m0, tid, rstd_lds); lds_write_drain(); }   // visible after the first barrier
 
     f32x16 acc[C::NI][C::MI];
 #pragma unroll
@@ -568,6 +572,8 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     const int nt = p.K / GEMM_BK;
 #pragma unroll
     for (int g = 0; g < C::G; ++g) issue_piece(g, 0, 0);
+    // folded RMSNorm: the row scales of this tile, computed under the flight of the first k-tile (visible after the barrier below)
+    if (p.rowsq_in) { gemm_tile_rstd<C>(p, m0, tid, rstd_lds); lds_write_drain(); }
     wait_vmcnt_barrier<0>();
     if (grp == 1) raw_barrier();                                   // waves 4-7 run one barrier behind
 

@@ -100,7 +100,8 @@ def tile_slices(n_tiles: int, world: int) -> List[Tuple[int, int]]:
 # ------------------------------------------------------------------------------------------------------------------------------
 class Comm:
     """Collectives of the one-sample-on-all-ranks path.  ``stream`` (a torch.cuda.Stream or None = current) is where the
-    collective is enqueued; ``sent_bytes`` accumulates the payload this rank contributed (comm_bytes_per_step in bench.py)."""
+    collective is enqueued; ``sent_bytes`` accumulates the bytes this rank puts on its links, counted for the direct (full-mesh)
+    algorithms xGMI favours: all-gather (R-1) x shard, reduce-scatter (R-1)/R x input, all-reduce 2 (R-1)/R x tensor."""
     rank: int = 0
     world: int = 1
     backend: str = "none"
@@ -110,7 +111,11 @@ class Comm:
     def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, stream=None): raise NotImplementedError
     def all_reduce(self, t: torch.Tensor, stream=None): raise NotImplementedError
     def broadcast(self, t: torch.Tensor, root: int, stream=None): raise NotImplementedError
-    def ranks_seen(self) -> int: return self.world
+    def ranks_seen(self) -> int: return 0                       # ranks RCCL itself reports (0: not an RCCL transport)
+
+    def _count(self, kind: str, t: torch.Tensor):
+        b, R = t.numel() * t.element_size(), self.world
+        self.sent_bytes += {"ag": (R - 1) * b, "rs": (R - 1) * b // R, "ar": 2 * (R - 1) * b // R}[kind]
 
 
 class TorchComm(Comm):
@@ -125,8 +130,11 @@ class TorchComm(Comm):
     def _host_staged(self, t):
         return self.backend == "gloo" and t.device.type == "cuda"
 
+    def ranks_seen(self) -> int:
+        return self.world if self.backend == "nccl" else 0
+
     def all_gather(self, out, inp, stream=None):
-        self.sent_bytes += inp.numel() * inp.element_size()
+        self._count("ag", inp)
         if self._host_staged(inp):
             h = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(h, inp.cpu().contiguous())
@@ -135,7 +143,7 @@ class TorchComm(Comm):
             dist.all_gather_into_tensor(out, inp)
 
     def reduce_scatter(self, out, inp, stream=None):
-        self.sent_bytes += inp.numel() * inp.element_size()
+        self._count("rs", inp)
         if self._host_staged(inp):
             h = torch.empty(out.shape, dtype=out.dtype)
             dist.reduce_scatter_tensor(h, inp.cpu().contiguous())
@@ -144,7 +152,7 @@ class TorchComm(Comm):
             dist.reduce_scatter_tensor(out, inp)
 
     def all_reduce(self, t, stream=None):
-        self.sent_bytes += t.numel() * t.element_size()
+        self._count("ar", t)
         if self._host_staged(t):
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -200,19 +208,19 @@ class RcclComm(Comm):
 
     def all_gather(self, out, inp, stream=None):
         assert inp.is_contiguous() and out.is_contiguous() and out.numel() == inp.numel() * self.world and out.dtype == inp.dtype
-        self.sent_bytes += inp.numel() * inp.element_size()
+        self._count("ag", inp)
         self._check(self.lib.lmi_allgather(self.handle, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), inp.numel(),
                                            _LMI_DT[inp.dtype], self._s(stream)))
 
     def reduce_scatter(self, out, inp, stream=None):
         assert inp.is_contiguous() and out.is_contiguous() and inp.numel() == out.numel() * self.world and out.dtype == inp.dtype
-        self.sent_bytes += inp.numel() * inp.element_size()
+        self._count("rs", inp)
         self._check(self.lib.lmi_reduce_scatter(self.handle, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(),
                                                 _LMI_DT[inp.dtype], self._s(stream)))
 
     def all_reduce(self, t, stream=None):
         assert t.is_contiguous()
-        self.sent_bytes += t.numel() * t.element_size()
+        self._count("ar", t)
         self._check(self.lib.lmi_allreduce(self.handle, C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), t.numel(), _LMI_DT[t.dtype],
                                            self._s(stream)))
 

@@ -1,0 +1,38 @@
+"""``PYTHONPATH=<repo>/leopard_amd/hf_shim:<repo> python evaluations/models/llava_multiimg_siglip_anyres.py ...``
+
+Python imports ``sitecustomize`` from sys.path at interpreter start; this one binds the model names the reference's evaluation
+scripts import from ``transformers`` to the HIP engine (leopard_amd.reference_shim).  The rebinding is deferred until
+``transformers`` is actually imported, so interpreters that never touch it (eval_utils.py's scorers) pay nothing."""
+import importlib.abc
+import importlib.util
+import sys
+
+
+class _PatchTransformers(importlib.abc.MetaPathFinder):
+    def find_spec(self, name, path=None, target=None):
+        if name != "transformers":
+            return None
+        sys.meta_path.remove(self)
+        spec = importlib.util.find_spec("transformers")
+        if spec is None or spec.loader is None:
+            return None
+        inner = spec.loader
+
+        class Loader(importlib.abc.Loader):
+            def create_module(self, s):
+                return inner.create_module(s)
+
+            def exec_module(self, module):
+                inner.exec_module(module)
+                from leopard_amd import reference_shim
+                reference_shim.install()
+        spec.loader = Loader()
+        return spec
+
+
+try:
+    from leopard_amd import reference_shim as _rs
+    _rs._scorer_fallbacks()
+    sys.meta_path.insert(0, _PatchTransformers())
+except ImportError:                                  # leopard_amd not importable: leave the interpreter untouched
+    pass

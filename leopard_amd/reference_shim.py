@@ -1,0 +1,185 @@
+"""Run the reference's evaluation scripts UNMODIFIED on the HIP engine.
+
+The scripts (evaluations/models/llava_multiimg_siglip_anyres.py, "EVAL"; evaluations/models/idefics2_multiimg.py, "IDEF") import
+their model classes from ``transformers``:
+
+    EVAL:6-9     from transformers import CLIPImageProcessor, LlavaForConditionalGeneration, SiglipImageProcessor, AutoTokenizer, LlavaConfig
+    EVAL:195-198 class myLlavaForConditionalGeneration(LlavaForConditionalGeneration): __init__ -> super().__init__(config)
+    EVAL:373-376 myLlavaForConditionalGeneration.from_pretrained(ckpt, torch_dtype=torch.float32); .eval(); .to('cuda:0')
+    EVAL:448-452 llava.generate(input_ids, pixel_values=, attention_mask=, pad_token_id=, eos_token_id=[...], max_new_tokens=128, use_cache=True)
+    IDEF:6,23-29 from transformers import AutoProcessor, AutoModelForVision2Seq; .from_pretrained(...).to(device); .generate(**inputs, max_new_tokens=128)
+
+``install()`` rebinds exactly those model names inside the REAL ``transformers`` package (tokenizers and image processors stay
+the third-party ones) to engine-backed classes with the same construction / call surface:
+
+    transformers.LlavaForConditionalGeneration  -> LlavaForConditionalGeneration below (subclassable: the script's subclass and its
+                                                   projector attribute are built, its ``forward`` is never needed: ``generate`` drives the
+                                                   HIP engine directly, the whole forward of EVAL:201-361 happens in libleopard_amd.so)
+    transformers.AutoModelForVision2Seq         -> leopard_amd.idefics2_compat.Idefics2ForConditionalGeneration
+    transformers.AutoProcessor                  -> leopard_amd.idefics2_compat.Idefics2Processor
+
+Two ways to use it, neither edits ``evaluations/``:
+
+    python -m leopard_amd.run_reference_eval evaluations/models/llava_multiimg_siglip_anyres.py -- -c CKPT -d slidevqa -s direct
+    PYTHONPATH=<repo>/leopard_amd/hf_shim:<repo> bash run_eval_llava_siglip_multiimg.sh direct CKPT      # the reference's own launcher
+
+(the second form works because ``hf_shim/sitecustomize.py`` calls ``install()`` at interpreter start).  ``rouge`` and
+``editdistance`` (scorer dependencies, EVAL:13, eval_utils.py) get minimal fallbacks only when they are not installed.
+
+Smoke-run knobs (GPU-less containers / CI only; the product path needs none of them):
+    LEOPARD_AMD_LIB             alternative C-ABI library (the CPU kernel-logic emulator build); implies host tensors
+    LEOPARD_AMD_FORCE_DEVICE    device the model is built on, whatever the script asks for ("cpu" with the emulator)
+    LEOPARD_AMD_MAX_NEW_TOKENS  cap on max_new_tokens
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+_INSTALLED = False
+
+
+def _ops_from_env():
+    lib = os.environ.get("LEOPARD_AMD_LIB")
+    if not lib:
+        return None                                   # product library, loaded lazily by Ops()
+    from . import _lib
+    from .ops import Ops
+    return Ops(lib=_lib.bind(lib), emulated=True)
+
+
+def _device(requested):
+    return os.environ.get("LEOPARD_AMD_FORCE_DEVICE") or requested
+
+
+def _cap_tokens(n):
+    cap = os.environ.get("LEOPARD_AMD_MAX_NEW_TOKENS")
+    return min(int(n), int(cap)) if cap else int(n)
+
+
+def _llava_class():
+    import torch
+    from .checkpoint import CheckpointSource, load_config
+    from .compat import LeopardForConditionalGeneration
+
+    class LlavaForConditionalGeneration(LeopardForConditionalGeneration):
+        """Stands where transformers.LlavaForConditionalGeneration stands in EVAL: ``cls(config)`` construction (so that the
+        script's subclass can add its projector attribute), ``from_pretrained(path, torch_dtype=)``, ``eval()``, ``to(device)``,
+        ``device``, ``generate(...)``, ``forward(...)`` / ``__call__`` with the reference's argument names."""
+        _pending = None
+
+        def __init__(self, config):
+            path, compute_dtype, ops = type(self)._pending or (None, torch.float16, None)
+            if path is None:
+                raise RuntimeError("construct through from_pretrained(checkpoint_dir) — the engine streams the checkpoint's tensors")
+            super().__init__(config, lambda dev, dt: CheckpointSource(path, dev, dt), compute_dtype, ops)
+
+        @classmethod
+        def from_pretrained(cls, path, torch_dtype=torch.float32, compute_dtype=torch.float16, ops=None, **unused):
+            cfg = load_config(path)
+            cls._pending = (path, compute_dtype, ops if ops is not None else _ops_from_env())
+            try:
+                return cls(cfg)
+            finally:
+                cls._pending = None
+
+        def to(self, device):
+            return super().to(_device(device))
+
+        def generate(self, *args, max_new_tokens=128, **kw):
+            return super().generate(*args, max_new_tokens=_cap_tokens(max_new_tokens), **kw)
+
+        # the reference's subclass overrides forward() with EVAL:201-361, which needs HF sub-modules; calls go to the engine
+        def __call__(self, *args, **kw):
+            return LeopardForConditionalGeneration.forward(self, *args, **kw)
+    return LlavaForConditionalGeneration
+
+
+def _idefics2_classes():
+    from . import idefics2_compat as IC
+
+    class AutoModelForVision2Seq(IC.Idefics2ForConditionalGeneration):
+        @classmethod
+        def from_pretrained(cls, path, **kw):
+            kw.setdefault("ops", _ops_from_env())
+            return super().from_pretrained(path, **kw)
+
+        def to(self, device):
+            return super().to(_device(device))
+
+        def generate(self, *args, max_new_tokens=128, **kw):
+            return super().generate(*args, max_new_tokens=_cap_tokens(max_new_tokens), **kw)
+    return IC.Idefics2Processor, AutoModelForVision2Seq
+
+
+def _scorer_fallbacks():
+    """rouge / editdistance are imported at module level by the reference's scripts (EVAL:13, eval_utils.py).  Where they are
+    not installed, stand in with small pure-Python equivalents of the two calls the scorers make."""
+    try:
+        import rouge  # noqa: F401
+    except ImportError:
+        m = types.ModuleType("rouge")
+
+        class Rouge:
+            def __init__(self, *args, **kwargs):
+                pass
+
+            @staticmethod
+            def _lcs(a, b):
+                prev = [0] * (len(b) + 1)
+                for x in a:
+                    cur = [0]
+                    for j, y in enumerate(b):
+                        cur.append(prev[j] + 1 if x == y else max(prev[j + 1], cur[j]))
+                    prev = cur
+                return prev[-1]
+
+            def get_scores(self, hyps, refs, avg=False):
+                if isinstance(hyps, str):
+                    hyps, refs = [hyps], [refs]
+                out = []
+                for h, r in zip(hyps, refs):
+                    ht, rt = h.split(), r.split()
+                    def f(overlap, nh, nr):
+                        p, rc = (overlap / nh if nh else 0.0), (overlap / nr if nr else 0.0)
+                        return {"r": rc, "p": p, "f": (2 * p * rc / (p + rc) if p + rc else 0.0)}
+                    uni = len(set(ht) & set(rt))
+                    out.append({"rouge-1": f(uni, len(set(ht)), len(set(rt))), "rouge-2": f(0, 1, 1),
+                                "rouge-l": f(self._lcs(ht, rt), len(ht), len(rt))})
+                if avg:
+                    keys = out[0].keys() if out else []
+                    return {k: {m_: sum(o[k][m_] for o in out) / len(out) for m_ in ("r", "p", "f")} for k in keys}
+                return out
+        m.Rouge = Rouge
+        sys.modules["rouge"] = m
+    try:
+        import editdistance  # noqa: F401
+    except ImportError:
+        m = types.ModuleType("editdistance")
+
+        def _eval(a, b):
+            prev = list(range(len(b) + 1))
+            for i, x in enumerate(a, 1):
+                cur = [i]
+                for j, y in enumerate(b, 1):
+                    cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+                prev = cur
+            return prev[-1]
+        m.eval = _eval
+        m.distance = _eval
+        sys.modules["editdistance"] = m
+
+
+def install() -> None:
+    """Idempotent.  Imports the real ``transformers`` and rebinds the three model-side names (see the module docstring)."""
+    global _INSTALLED
+    if _INSTALLED:
+        return
+    _INSTALLED = True
+    _scorer_fallbacks()
+    import transformers
+    transformers.LlavaForConditionalGeneration = _llava_class()
+    proc, model = _idefics2_classes()
+    transformers.AutoProcessor = proc
+    transformers.AutoModelForVision2Seq = model

@@ -1,6 +1,8 @@
 """Multi-rank paths on ONE MI355X: two processes share cuda:0 and talk over gloo (RCCL needs one device per rank), which is
-enough to check through the real kernels that the tile-sharded vision encode + all-gather and the tensor-parallel LLM
-(leopard_amd.dist) reproduce the single-rank results."""
+enough to check through the real kernels that the tile-sharded vision encode + all-gather and the sequence-parallel
+tensor-parallel LLM (leopard_amd.dist, LeopardEngine._llm_layers_tp) reproduce the single-rank results; and the
+RCCL entry points of the C ABI (lmi_comm_init / lmi_allgather / lmi_reduce_scatter / lmi_allreduce / lmi_broadcast) on a
+one-rank communicator — all a 1-GPU box can run of RCCL."""
 import os
 import socket
 
@@ -35,9 +37,10 @@ def _worker(rank, world, port, out):
     tiles = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (5, 364, 364, 3), dtype=np.uint8)).to(dev)
     ids = torch.from_numpy(synth_prompt_ids([2, 3], cfg, seed=4)).reshape(1, -1)
     S = ids.shape[1] + 5 * (cfg.tokens_per_tile - 1)
-    cache = KVCache(cfg, S + 8, dtype, dev, tp_size=world)
+    cache = KVCache(cfg, eng.tp_padded_len(S) + 8, dtype, dev, tp_size=world)
     vis = D.encode_images_sharded(eng, tiles)
     res = eng.prefill(ids, None, cache=cache, visual_tokens=vis)
+    assert res.seq_len == S and type(eng.comm).__name__ == "TorchComm" and eng.comm.sent_bytes > 0
     step = eng.decode_step(int(res.logits_last.argmax()), cache).clone()
     ref = None
     if rank == 0:
@@ -70,3 +73,44 @@ def test_tensor_parallel_and_tile_sharding_two_ranks_one_gpu():
     vis_equal, d_prefill, d_decode, same_argmax = ref
     assert vis_equal                                   # tile-sharded encode + all-gather: bit-identical
     assert d_prefill <= 2.5e-3 and d_decode <= 2.5e-3 and same_argmax
+
+
+def _rccl_worker(out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    import torch.distributed as dist
+    from leopard_amd import dist as D
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    comm = D.RcclComm(device=dev)
+    side = torch.cuda.Stream(device=dev)
+    res = {"ranks": comm.ranks_seen(), "backend": comm.backend}
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        x = torch.randn(4096, 64, device=dev).to(dt)
+        ag, rs, ar = torch.empty_like(x), torch.empty_like(x), x.clone()
+        side.wait_stream(torch.cuda.current_stream(dev))
+        comm.all_gather(ag, x, side)                      # one rank: every collective is the identity
+        comm.reduce_scatter(rs, x, side)
+        comm.all_reduce(ar, side)
+        comm.broadcast(ar, 0, side)
+        side.synchronize()
+        res[str(dt)] = bool(torch.equal(ag, x) and torch.equal(rs, x) and torch.equal(ar, x))
+    res["sent"] = comm.sent_bytes                     # one rank: nothing goes on a link
+    comm.destroy()
+    dist.destroy_process_group()
+    out.put(res)
+
+
+def test_rccl_c_abi_single_rank_communicator():
+    """lmi_comm_unique_id / lmi_comm_init / collectives / lmi_comm_destroy through dlopen'ed librccl on the device, on a side
+    stream, in all three exchange dtypes (a child process: the communicator binds the device)."""
+    mp.set_start_method("spawn", force=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert res["ranks"] == 1 and res["backend"].startswith("rccl")
+    assert res["torch.float16"] and res["torch.bfloat16"] and res["torch.float32"] and res["sent"] == 0
