@@ -116,6 +116,17 @@ class LeopardForConditionalGeneration:
         return self.engine.generate(input_ids.to(self.device), tiles, max_new_tokens=max_new_tokens, eos_token_id=eos)
 
 
+    @torch.no_grad()
+    def generate_batch(self, requests: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], eos_token_id=None,
+                       max_new_tokens: int = 128, **unused) -> List[torch.Tensor]:
+        """[(input_ids [1, S_in], pixel_values)] -> [LongTensor [1, S_in + T]]: the batched form of ``generate`` (one packed prefill
+        for all requests, LeopardEngine.generate_batch).  Not a surface of the reference script — its loop is batch 1 — but of
+        leopard_amd.harness.run_inference(batch_size=...)."""
+        eos = eos_token_id if isinstance(eos_token_id, (list, tuple)) else ([] if eos_token_id is None else [eos_token_id])
+        samples = [(ids.to(self.device), self._as_tiles(pix)) for ids, pix in requests]
+        return self.engine.generate_batch(samples, max_new_tokens=max_new_tokens, eos_token_id=eos)
+
+
 def from_pretrained(path: str, torch_dtype=torch.float32, **kw) -> LeopardForConditionalGeneration:
     """Drop-in for ``myLlavaForConditionalGeneration.from_pretrained``."""
     return LeopardForConditionalGeneration.from_pretrained(path, torch_dtype=torch_dtype, **kw)

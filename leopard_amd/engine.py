@@ -110,6 +110,7 @@ class LeopardEngine:
         self.tp_comm_dtype = None      # dtype of the reduce-scattered partial products: None = the compute type, torch.float32 = exact sums
         self._comm_stream = None
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
+        self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
         tc = cfg.text_config
         self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
@@ -259,8 +260,8 @@ class LeopardEngine:
         qw, kw = H * hd, KV * hd
         cu, cos, sin, last_rows, cu_list = self.sequence_geometry(seq_lens)
         assert cu_list[-1] == S
-        if cache is not None:
-            assert len(seq_lens) == 1 and cache.length == 0 and cache.capacity >= S
+        if cache is not None:       # one sequence, or a pool holding the packed rows of several (generate_batch splits it afterwards)
+            assert cache.length == 0 and cache.capacity >= S
         h = self._empty(S, D)
         qkv = self._empty(S, qw + 2 * kw)
         att = self._empty(S, qw)
@@ -610,6 +611,8 @@ class LeopardEngine:
             row_parallel(L.down_w, st.gu[0])
         ops.lm_head_last(W.lm_head, st.x, None, W.final_norm, tc.rms_norm_eps, st.logits.view(1, -1))
         # greedy choice and position advance stay on the device (torch ops as plumbing; all capturable)
+        if self.suppress_tokens is not None:
+            st.logits.index_fill_(0, self.suppress_tokens, float("-inf"))
         torch.argmax(st.logits[:tc.vocab_size], dim=0, keepdim=True, out=st.tok)
         st.pos.add_(1)
         st.cu_k[1:].add_(1)
@@ -650,19 +653,27 @@ class LeopardEngine:
         cache.length += 1
         return st.logits[:self.cfg.text_config.vocab_size]
 
-    @torch.no_grad()
-    def generate(self, input_ids: torch.Tensor, tiles: Optional[torch.Tensor], max_new_tokens: int = 128,
-                 eos_token_id: Sequence[int] = (128001, 128009)) -> torch.Tensor:
-        """Greedy generation (EVAL:448-452): returns LongTensor [1, S_in + T] on the input device."""
-        ids = input_ids.reshape(1, -1)
-        n_img = int((ids == self.cfg.image_token_index).sum())
-        S = ids.shape[1] + n_img * (self.cfg.tokens_per_tile - 1)
-        cap = (self.tp_padded_len(S) if self.tp_size > 1 else S) + max_new_tokens
-        cache = KVCache(self.cfg, cap, self.dtype, self.device, tp_size=self.tp_size)
-        res = self.prefill(ids, tiles, cache=cache)
-        out = [int(t) for t in ids.reshape(-1).tolist()]
-        nxt = int(res.logits_last.argmax())
-        eos = set(int(e) for e in eos_token_id)
+    def _generation_cache(self, need: int) -> KVCache:
+        """ONE KV cache (with its decode state and captured graph) per engine, reused across generate() calls: the eval loop is
+        batch 1 with at most 128 new tokens, and a fresh cache per sample would pay an eager warm-up step, a graph capture and new
+        static buffers every time.  The graph reads the position and the key count from device memory and its launch geometry
+        depends only on the capacity, so resetting ``length`` is all a new prompt needs; a longer prompt grows the cache."""
+        c = getattr(self, "_gen_cache", None)
+        if c is None or c.capacity < need:
+            c = self._gen_cache = KVCache(self.cfg, (need + 2047) // 2048 * 2048, self.dtype, self.device, tp_size=self.tp_size)
+        c.length = 0
+        return c
+
+    def first_token(self, logits_last: torch.Tensor) -> int:
+        """Greedy choice from prefill logits, honouring ``suppress_tokens``."""
+        if self.suppress_tokens is not None:
+            logits_last = logits_last.clone()
+            logits_last.index_fill_(0, self.suppress_tokens, float("-inf"))
+        return int(logits_last.argmax())
+
+    def _greedy_loop(self, prompt_ids: List[int], first: int, cache: KVCache, max_new_tokens: int, eos) -> List[int]:
+        """EVAL:448-452 after the prefill: greedy tokens until eos / max_new_tokens; one captured decode step per token."""
+        out, nxt = list(prompt_ids), int(first)
         st = self._decode_state(cache)
         self._decode_seed(st, cache, nxt)
         for step in range(max_new_tokens):
@@ -672,4 +683,54 @@ class LeopardEngine:
             self._decode_run(st, cache)              # consumes st.tok at st.pos, leaves the next token / position on the device
             cache.length += 1
             nxt = int(st.tok.item())
+        return out
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, tiles: Optional[torch.Tensor], max_new_tokens: int = 128,
+                 eos_token_id: Sequence[int] = (128001, 128009)) -> torch.Tensor:
+        """Greedy generation (EVAL:448-452): returns LongTensor [1, S_in + T] on the input device."""
+        ids = input_ids.reshape(1, -1)
+        n_img = int((ids == self.cfg.image_token_index).sum())
+        S = ids.shape[1] + n_img * (self.cfg.tokens_per_tile - 1)
+        cache = self._generation_cache((self.tp_padded_len(S) if self.tp_size > 1 else S) + max_new_tokens)
+        res = self.prefill(ids, tiles, cache=cache)
+        out = self._greedy_loop([int(t) for t in ids.reshape(-1).tolist()], self.first_token(res.logits_last), cache, max_new_tokens,
+                                set(int(e) for e in eos_token_id))
         return torch.tensor([out], dtype=torch.long, device=input_ids.device)
+
+    @torch.no_grad()
+    def generate_batch(self, samples: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], max_new_tokens: int = 128,
+                       eos_token_id: Sequence[int] = (128001, 128009)) -> List[torch.Tensor]:
+        """Several samples per call (batching with per-sample cu_seqlens instead of one sample per generate()):
+        ONE packed prefill — all ViT inputs through the tower together, all merged sequences in one varlen causal pass that also
+        writes every sample's K/V into a pooled cache — then each sample's K/V rows move to a cache of its own (a device copy)
+        and its greedy continuation runs on the captured decode step.  Results are identical to per-sample ``generate``."""
+        assert self.tp_size == 1, "batched generation is a single-rank feature (replicas scale it out)"
+        tiles = [t for _, t in samples if t is not None and t.shape[0] > 0]
+        visual = None
+        if tiles:
+            all_tiles = torch.cat(tiles, dim=0)
+            visual = self.project(self.vision_tower(all_tiles), all_tiles.shape[0])
+        xs, seq_lens, row = [], [], 0
+        for ids, t in samples:
+            n = 0 if t is None else t.shape[0]
+            vt = None if n == 0 else visual[row * self.cfg.tokens_per_tile:(row + n) * self.cfg.tokens_per_tile]
+            row += n
+            x = self.embed_merge(ids, vt)
+            xs.append(x)
+            seq_lens.append(x.shape[0])
+        pool = KVCache(self.cfg, sum(seq_lens), self.dtype, self.device)
+        last, _ = self.llm_prefill(torch.cat(xs, dim=0), seq_lens, cache=pool)
+        first = [self.first_token(last[j]) for j in range(last.shape[0])]
+        eos = set(int(e) for e in eos_token_id)
+        outs, off = [], 0
+        for (ids, _), S, nxt in zip(samples, seq_lens, first):
+            cache = KVCache(self.cfg, S + max_new_tokens, self.dtype, self.device)
+            for i in range(len(cache.k)):
+                cache.k[i][:S].copy_(pool.k[i][off:off + S])
+                cache.v[i][:S].copy_(pool.v[i][off:off + S])
+            cache.length = S
+            off += S
+            out = self._greedy_loop([int(t) for t in ids.reshape(-1).tolist()], nxt, cache, max_new_tokens, eos)
+            outs.append(torch.tensor([out], dtype=torch.long, device=ids.device))
+        return outs

@@ -144,17 +144,20 @@ def shard_result_path(checkpoint: str, shard: int, setting: str, dataset: str) -
 
 
 def run_inference(records: List[dict], model, tokenizer, setting: str = "direct", scorer: Optional[Callable] = None,
-                  device=None, gpu_tiler=None) -> List[dict]:
-    """The hot loop (EVAL:381-487) over already-sharded records, batch 1, greedy.  ``gpu_tiler`` (a
-    leopard_amd.gpu_tiler.GpuTiler): resize / pad / crop run on the device and the u8 tile stack goes straight to the model
-    (same pixels as the PIL path, bit for bit); without it the reference's host pipeline is used."""
+                  device=None, gpu_tiler=None, batch_size: int = 1) -> List[dict]:
+    """The hot loop (EVAL:381-487) over already-sharded records, greedy.  ``gpu_tiler`` (a leopard_amd.gpu_tiler.GpuTiler):
+    resize / pad / crop run on the device and the u8 tile stack goes straight to the model (same pixels as the PIL path, bit
+    for bit); without it the reference's host pipeline is used.  ``batch_size`` > 1: that many records share
+    ONE packed prefill (``model.generate_batch``: per-sample cu_seqlens keep them apart) instead of the reference's one
+    ``generate`` per record; the rows are the same."""
     import numpy as np
     import torch
     from .tiler import siglip_preprocess
     rows = []
     size = getattr(getattr(getattr(model, "config", None), "vision_config", None), "image_size", TILE)    # 364 for Leopard
-    for rec in records:
-        dev = device if device is not None else model.device
+    dev = device if device is not None else model.device
+
+    def prepare(rec):
         if gpu_tiler is not None:
             s = prepare_sample(rec, setting, pixels=False)
             pixel_values, plan = gpu_tiler.tile_sample([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in s.vit_inputs])
@@ -164,11 +167,23 @@ def run_inference(records: List[dict], model, tokenizer, setting: str = "direct"
             pixel_values = torch.from_numpy(siglip_preprocess(s.vit_inputs, size)).to(dev)
             n_vit = len(s.vit_inputs)
         enc = tokenizer([s.prompt], return_tensors="pt", truncation=True, max_length=MAX_PROMPT_TOKENS)["input_ids"]
-        attn = enc != tokenizer.pad_token_id
-        out = model.generate(enc.to(dev), pixel_values=pixel_values, attention_mask=attn.to(dev),
-                             **generate_kwargs(tokenizer.pad_token_id))
-        response = tokenizer.batch_decode(out[:, enc.shape[1]:], skip_special_tokens=True)[0]
-        rows.append(result_row(rec, s.question, response, n_vit, scorer))
+        return s, pixel_values, n_vit, enc
+
+    for b0 in range(0, len(records), max(1, batch_size)):
+        group = records[b0:b0 + max(1, batch_size)]
+        prepared = [prepare(rec) for rec in group]
+        kw = generate_kwargs(tokenizer.pad_token_id)
+        if len(prepared) == 1 or not hasattr(model, "generate_batch"):
+            outs = []
+            for s, pixel_values, n_vit, enc in prepared:
+                attn = enc != tokenizer.pad_token_id
+                outs.append(model.generate(enc.to(dev), pixel_values=pixel_values, attention_mask=attn.to(dev), **kw))
+        else:
+            outs = model.generate_batch([(enc.to(dev), pixel_values) for _, pixel_values, _, enc in prepared],
+                                        eos_token_id=kw["eos_token_id"], max_new_tokens=kw["max_new_tokens"])
+        for rec, (s, _, n_vit, enc), out in zip(group, prepared, outs):
+            response = tokenizer.batch_decode(out[:, enc.shape[1]:], skip_special_tokens=True)[0]
+            rows.append(result_row(rec, s.question, response, n_vit, scorer))
     return rows
 
 

@@ -126,7 +126,11 @@ def load_idefics2_config(path: str) -> Idefics2Config:
         return cls(**{k: v for k, v in src.items() if k in keys and v is not None and not isinstance(v, dict)})
 
     base = Idefics2Config()
-    vc = dataclasses.replace(base.vision_config, **dataclasses.asdict(pick(VisionConfig, d.get("vision_config")))) if "vision_config" in d else base.vision_config
+    # overlay ONLY the keys the JSON carries onto the Idefics2 defaults (a diff-style saved config omits e.g. image_size = 980;
+    # filling it from VisionConfig's own default, 364, would shrink the 70 x 70 position grid to 26 x 26)
+    vkeys = {f.name for f in dataclasses.fields(VisionConfig)}
+    vc = dataclasses.replace(base.vision_config, **{k: v for k, v in (d.get("vision_config") or {}).items()
+                                                    if k in vkeys and v is not None and not isinstance(v, dict)})
     tc_src = dict(d.get("text_config") or {})
     tc = base.text_config if not tc_src else dataclasses.replace(base.text_config, **{
         k: v for k, v in tc_src.items() if k in {f.name for f in dataclasses.fields(TextConfig)} and k != "rope_scaling" and v is not None})
@@ -143,23 +147,32 @@ class Idefics2ForConditionalGeneration:
     ``.generate(input_ids=, attention_mask=, pixel_values=, pixel_attention_mask=, max_new_tokens=)``."""
 
     def __init__(self, config: Idefics2Config, source_factory, compute_dtype=torch.float16, ops: Optional[Ops] = None,
-                 eos_token_id: Sequence[int] = (2, 32002)):
+                 eos_token_id: Sequence[int] = (2, 32002), bad_words_ids: Optional[Sequence[int]] = None):
         self.config, self._source_factory, self.compute_dtype, self._ops = config, source_factory, compute_dtype, ops
         self.eos_token_id = tuple(int(e) for e in eos_token_id)
+        # stock Idefics2 generation_config suppresses <fake_token_around_image> and <image> (bad_words_ids): never generated
+        self.bad_words_ids = tuple(int(b) for b in (bad_words_ids if bad_words_ids is not None
+                                                    else (config.image_token_id - 1, config.image_token_id)))
+        self.patch_validity = "all"       # see unpad_images; set to "any" to reproduce transformers 4.4x on mixed-size samples
         self._engine: Optional[Idefics2Engine] = None
         self.device = torch.device("cpu")
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype=torch.float16, ops: Optional[Ops] = None, **unused):
+    def from_pretrained(cls, path: str, torch_dtype=torch.float16, ops: Optional[Ops] = None, patch_validity: str = "all", **unused):
         cfg = load_idefics2_config(path)
-        eos = (2, 32002)
+        eos, bad = (2, 32002), None
         gpath = os.path.join(path, "generation_config.json")
         if os.path.exists(gpath):
             with open(gpath) as f:
-                e = json.load(f).get("eos_token_id", eos)
+                g = json.load(f)
+            e = g.get("eos_token_id", eos)
             eos = tuple(e) if isinstance(e, (list, tuple)) else (int(e),)
+            if g.get("bad_words_ids") is not None:
+                bad = [int(w[0]) for w in g["bad_words_ids"] if len(w) == 1]            # single-token bans (all stock Idefics2 has)
         dtype = torch_dtype if torch_dtype in (torch.float16, torch.bfloat16) else torch.float16
-        return cls(cfg, lambda dev, dt: CheckpointSource(path, dev, dt), dtype, ops, eos)
+        m = cls(cfg, lambda dev, dt: CheckpointSource(path, dev, dt), dtype, ops, eos, bad)
+        m.patch_validity = patch_validity
+        return m
 
     def eval(self):
         return self
@@ -170,6 +183,9 @@ class Idefics2ForConditionalGeneration:
             ops = self._ops if self._ops is not None else Ops()
             W = Idefics2Weights.build(self.config, self._source_factory(device, self.compute_dtype), self.compute_dtype)
             self._engine = Idefics2Engine(self.config, W, ops=ops, device=device)
+            vocab = self.config.text_config.vocab_size
+            bad = [b for b in self.bad_words_ids if 0 <= b < vocab]
+            self._engine.suppress_tokens = torch.tensor(bad, dtype=torch.int64, device=device) if bad else None
             self.device = device
         return self
 
@@ -180,10 +196,24 @@ class Idefics2ForConditionalGeneration:
         return self._engine
 
     @staticmethod
-    def unpad_images(pixel_values: torch.Tensor, pixel_attention_mask: Optional[torch.Tensor]) -> List[torch.Tensor]:
-        """[1, n, 3, H, W] (+ mask [1, n, H, W]) -> per-image fp32 [3, h, w]; an image that is entirely padding (all zeros) is
-        dropped, as the third-party model does before its vision tower."""
+    def unpad_images(pixel_values: torch.Tensor, pixel_attention_mask: Optional[torch.Tensor], patch_validity: str = "all",
+                     patch: int = 14) -> List[torch.Tensor]:
+        """[1, n, 3, H, W] (+ mask [1, n, H, W]) -> per-image fp32 [3, h', w']; an image that is entirely padding (all zeros) is
+        dropped, as the third-party model does before its vision tower.
+
+        ``patch_validity`` is the third-party rule for which patches of the padded canvas belong to an image (the tower then runs
+        on exactly those patches, and the NaViT position ids are fractions of THEIR row / column counts):
+          "all"  a patch counts when ALL its pixels are real (`patch mask sum == patch_size**2`: transformers 5.x, the version the
+                 golden fixture tests/golden/idefics2_tiny.npz is pinned to) -> floor(h / P) x floor(w / P) patches, remainder
+                 pixels dropped;
+          "any"  a patch counts when ANY of its pixels is real (`> 0`: the 4.4x releases Leopard-Idefics2 was run with,
+                 requirements.txt:16) -> a partly zero-padded last patch row / column is kept wherever the common canvas has room
+                 for it, i.e. for the smaller images of a mixed-size sample (fixture tests/golden/idefics2_tiny_any.npz).
+        The crop returned here is (rows, cols) = patches x P in both cases, zero padding included under "any"."""
+        if patch_validity not in ("all", "any"):
+            raise ValueError("patch_validity must be 'all' or 'any'")
         imgs = []
+        H, W = pixel_values.shape[-2], pixel_values.shape[-1]
         for i in range(pixel_values.shape[1]):
             x = pixel_values[0, i]
             if pixel_attention_mask is not None:
@@ -191,6 +221,8 @@ class Idefics2ForConditionalGeneration:
                 if not bool(m.any()):
                     continue
                 h, w = int(m.any(dim=1).sum()), int(m.any(dim=0).sum())
+                if patch_validity == "any":
+                    h, w = min(-(-h // patch) * patch, H // patch * patch), min(-(-w // patch) * patch, W // patch * patch)
                 x = x[:, :h, :w]
             elif not bool((x != 0).any()):
                 continue
@@ -205,16 +237,12 @@ class Idefics2ForConditionalGeneration:
         if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
             raise NotImplementedError("padded prompts are not produced by the reference script (batch 1)")
         eng = self.engine
-        images = None if pixel_values is None else self.unpad_images(pixel_values, pixel_attention_mask)
+        images = None if pixel_values is None else self.unpad_images(pixel_values, pixel_attention_mask, self.patch_validity,
+                                                                     self.config.vision_config.patch_size)
         eos = self.eos_token_id if eos_token_id is None else (tuple(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else (int(eos_token_id),))
         ids = input_ids.reshape(1, -1)
-        cache = KVCache(self.config, ids.shape[1] + max_new_tokens, self.compute_dtype, self.device)
+        cache = eng._generation_cache(ids.shape[1] + max_new_tokens)           # one cache + captured decode graph per engine
         res = eng.prefill(ids.to(self.device), images, cache=cache)
-        out = [int(t) for t in ids.reshape(-1).tolist()]
-        nxt = int(res.logits_last.argmax())
-        for step in range(max_new_tokens):
-            out.append(nxt)
-            if nxt in eos or step == max_new_tokens - 1:
-                break
-            nxt = int(eng.decode_step(nxt, cache).argmax())
+        out = eng._greedy_loop([int(t) for t in ids.reshape(-1).tolist()], eng.first_token(res.logits_last), cache, max_new_tokens,
+                               set(int(e) for e in eos))
         return torch.tensor([out], dtype=torch.long, device=input_ids.device)

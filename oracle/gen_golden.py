@@ -504,6 +504,18 @@ def gen_idefics2_tiny():
                     pixel_attention_mask=torch.from_numpy(msk))
     np.savez_compressed(os.path.join(OUT, "idefics2_tiny.npz"), ids=np.array(ids), img_a=img_a, img_b=img_b,
                         logits=out.logits.numpy(), image_hidden_states=out.image_hidden_states.numpy())
+    # The 4.4x patch-validity rule ("a patch belongs to the image when ANY of its pixels is real", `> 0`) on the same two images.
+    # transformers 5.15 implements "ALL pixels real" (`== patch_size**2`); marking the partly padded patches of image b as fully
+    # real in the mask makes the 5.15 model compute exactly what the `> 0` rule computes on the original mask: the same patch
+    # grid (4 x 3 instead of 4 x 2), the same pixels (real columns 28-29 + zero padding), the same fractional position ids.
+    msk_any = msk.copy()
+    msk_any[0, 1, :56, :42] = 1
+    with torch.no_grad():
+        out_any = model(input_ids=ids_t, attention_mask=torch.ones_like(ids_t), pixel_values=torch.from_numpy(pix),
+                        pixel_attention_mask=torch.from_numpy(msk_any))
+    assert not np.allclose(out_any.image_hidden_states.numpy(), out.image_hidden_states.numpy())
+    np.savez_compressed(os.path.join(OUT, "idefics2_tiny_any.npz"), ids=np.array(ids), pixel_values=pix, pixel_attention_mask=msk,
+                        logits=out_any.logits.numpy(), image_hidden_states=out_any.image_hidden_states.numpy())
     # processor size rule sweep (third-party get_resize_output_image_size)
     from transformers.models.idefics2.image_processing_pil_idefics2 import get_resize_output_image_size
     from transformers.image_utils import SizeDict

@@ -208,3 +208,28 @@ def test_fused_schedule_is_position_independent():
         else:
             assert torch.equal(la, base)                 # ... nor on the tile geometry
     ops.set_option("gemm.config", -1)
+
+
+def test_generate_batch_equals_per_sample_generate():
+    """several samples through ONE packed prefill (pooled KV cache, split per sample afterwards) and the captured
+    decode step give exactly the ids of per-sample generate()."""
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    from leopard_amd.engine import LeopardEngine
+    from leopard_amd.weights import EngineWeights, SynthSource
+    ops = emu_ops()
+    cfg = LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16,
+                                   image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                               num_key_value_heads=1, vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    rng = np.random.default_rng(9)
+    samples = [(torch.tensor([[5, 250, 9, 250, 17]]), torch.from_numpy(rng.integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))),
+               (torch.tensor([[8, 3, 250, 44, 45, 46, 47]]), torch.from_numpy(rng.integers(0, 256, (1, 28, 28, 3), dtype=np.uint8))),
+               (torch.tensor([[11, 12, 13]]), None)]
+    batch = eng.generate_batch(samples, max_new_tokens=4, eos_token_id=())
+    for (ids, tiles), got in zip(samples, batch):
+        one = eng.generate(ids, tiles, max_new_tokens=4, eos_token_id=())
+        assert torch.equal(one, got)

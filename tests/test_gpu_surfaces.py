@@ -1,0 +1,188 @@
+"""-m gpu: the eval-script-facing surfaces ON THE DEVICE (SURVEY.md 8 rows b, f1, f4) — the same objects the reference's scripts
+drive (tests/test_reference_cli_unmodified.py runs those scripts themselves in the build container; /root/reference does not
+exist on the GPU box):
+
+  * f1: a sharded safetensors checkpoint AND a sharded pytorch_model-*.bin checkpoint in the converter's key layout ->
+        compat.from_pretrained(...).to('cuda:0') -> forward / generate vs the CPU oracle;
+  * f4: harness.run_inference over jsonl-shaped records with the GPU tiler, with the host (PIL) pipeline and with several
+        records batched into one packed pass — same rows; greedy ids vs the oracle;
+  * f4: the Idefics2 processor + model object (idefics2_compat) on the device vs the Idefics2 oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def small_config():
+    """Full kernel shape rules (ViT width 1152 = 16 x 72, LLM head_dim 128, hidden 256 -> fused norm/rope schedule), tiny depth."""
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    return LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=256, num_hidden_layers=2, num_attention_heads=16,
+                                   image_size=56, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+                               num_key_value_heads=1, vocab_size=512, rope_scaling=RopeScaling()),
+        image_token_index=500)
+
+
+class CharTokenizer:
+    """Local stand-in for the checkpoint's tokenizer (no tokenizer files offline): one id per character, the reference's
+    three special strings as single ids."""
+    pad_token_id = 0
+
+    def __init__(self, image_id):
+        self.special = {"<|reserved_special_token_195|>": image_id, "<|reserved_special_token_20|>": image_id + 1,
+                        "<|reserved_special_token_21|>": image_id + 2}
+
+    def __call__(self, texts, return_tensors="pt", **kw):
+        text, ids, i = texts[0], [], 0
+        while i < len(text):
+            for s, t in self.special.items():
+                if text.startswith(s, i):
+                    ids.append(t)
+                    i += len(s)
+                    break
+            else:
+                ids.append(1 + ord(text[i]) % 400)
+                i += 1
+        return {"input_ids": torch.tensor([ids])}
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join(str(int(t)) for t in row) for row in ids]
+
+
+@pytest.fixture(scope="module")
+def ckpts(tmp_path_factory):
+    from leopard_amd.checkpoint import save_synthetic_checkpoint
+    from leopard_amd.synth import param_specs, synth_array
+    d = tmp_path_factory.mktemp("ckpt_gpu")
+    cfg = small_config()
+    save_synthetic_checkpoint(str(d / "st"), cfg, shard_bytes=8 << 20)
+    # the converter's other container: sharded pytorch_model-*.bin + index
+    os.makedirs(d / "bin")
+    cfg.save(str(d / "bin" / "config.json"))
+    tensors = [(n, torch.from_numpy(synth_array(n, s, k))) for n, s, k in param_specs(cfg)]
+    half = len(tensors) // 2
+    index = {"metadata": {}, "weight_map": {}}
+    for i, part in enumerate((tensors[:half], tensors[half:])):
+        fn = f"pytorch_model-{i + 1:05d}-of-00002.bin"
+        torch.save(dict(part), str(d / "bin" / fn))
+        for n, _ in part:
+            index["weight_map"][n] = fn
+    json.dump(index, open(d / "bin" / "pytorch_model.bin.index.json", "w"))
+    return d, cfg
+
+
+@pytest.fixture(scope="module")
+def oracle_weights(ckpts):
+    from leopard_amd.synth import synth_state_dict_numpy
+    from oracle import leopard_oracle as O
+    return O.weights_from_numpy(synth_state_dict_numpy(ckpts[1]))
+
+
+@pytest.mark.parametrize("kind", ["st", "bin"])
+def test_checkpoint_to_device_generate_vs_oracle(ckpts, oracle_weights, kind):
+    """EVAL:373-375, 448-452 on the device from an on-disk checkpoint."""
+    from leopard_amd import compat
+    from leopard_amd.tiler import siglip_normalize
+    from oracle import leopard_oracle as O
+    d, cfg = ckpts
+    llava = compat.from_pretrained(str(d / kind), torch_dtype=torch.float32)
+    llava.eval()
+    llava.to(DEV)
+    assert llava.device.type == "cuda"
+    S = cfg.vision_config.image_size
+    u8 = np.random.default_rng(4).integers(0, 256, (3, S, S, 3), dtype=np.uint8)
+    images = torch.from_numpy(siglip_normalize(u8)).to(llava.device)
+    input_ids = torch.tensor([[7, 500, 11, 500, 500, 12, 13]]).to(llava.device)
+    attn = (input_ids != 0)
+    out = llava.generate(input_ids, pixel_values=images, attention_mask=attn, pad_token_id=0, eos_token_id=[128001, 128009],
+                         max_new_tokens=6, use_cache=True)
+    ref = O.greedy_generate(input_ids.cpu(), images.cpu(), oracle_weights, cfg, 6, eos_token_id=[128001, 128009])
+    assert out.device.type == "cuda" and torch.equal(out.cpu(), ref)
+    res = llava(input_ids=input_ids, pixel_values=images, attention_mask=attn, use_cache=True, return_dict=True)
+    logits = O.prefill_logits(input_ids.cpu(), images.cpu(), oracle_weights, cfg)
+    assert res.logits.shape == logits.shape
+    assert (res.logits.cpu() - logits).abs().max().item() <= 3e-3 * logits.abs().max().item()
+    # u8 tile stacks (what the GPU tiler hands over) give the same logits as the reference's normalised fp32 pixel_values
+    res8 = llava(input_ids=input_ids, pixel_values=torch.from_numpy(u8).to(DEV), attention_mask=attn, return_dict=True)
+    assert torch.equal(res8.logits, res.logits)
+
+
+def _records(tmp, cfg):
+    from PIL import Image
+    from leopard_amd.synth import synth_image_u8
+    paths = []
+    for i, (w, h) in enumerate([(400, 300), (800, 500), (364, 364), (1344, 896)]):
+        p = str(tmp / f"im{i}.png")
+        Image.fromarray(synth_image_u8(40 + i, w, h)).save(p)
+        paths.append(p)
+    return [{"images_path": paths[:1], "question": "<image> what?", "answers": ["x"], "ques_type": "open-ended", "options": None},
+            {"images_path": paths[1:3], "question": "<image><image> which?", "answers": ["A"], "ques_type": "multiple-choice", "options": ["a", "b"]},
+            {"images_path": paths[3:], "question": "describe <image>", "answers": ["y"], "ques_type": "open-ended", "options": None},
+            {"images_path": paths, "question": "all of them", "answers": ["z"], "ques_type": "open-ended", "options": None}]
+
+
+def test_harness_on_device_gpu_tiler_host_tiler_and_batched(ckpts, oracle_weights, tmp_path, monkeypatch):
+    """harness.run_inference (the counterpart of EVAL:381-487) on the device: the GPU tiler and the host PIL pipeline give the
+    same rows; batching several records into one packed prefill gives the same rows again; the first record's ids == oracle."""
+    from leopard_amd import compat, harness
+    from leopard_amd.gpu_tiler import GpuTiler
+    from oracle import leopard_oracle as O
+    d, cfg = ckpts
+    monkeypatch.setattr(harness, "MAX_NEW_TOKENS", 5)
+    model = compat.from_pretrained(str(d / "st")).to(DEV)
+    tok = CharTokenizer(cfg.image_token_index)
+    recs = _records(tmp_path, cfg)[:3]            # (record 4 has fewer tags than images: the reference's merge rejects it, see below)
+    tiler = GpuTiler(model.engine.ops, DEV, out_size=cfg.vision_config.image_size)
+    rows_gpu = harness.run_inference(recs, model, tok, "direct", gpu_tiler=tiler)
+    rows_host = harness.run_inference(recs, model, tok, "direct")
+    assert rows_gpu == rows_host and len(rows_gpu) == 3
+    assert set(rows_gpu[0]) == {"correct", "chosen", "gold", "raw", "question", "image_type", "multi_img", "correct_anls"}
+    rows_b = harness.run_inference(recs, model, tok, "direct", gpu_tiler=tiler, batch_size=3)
+    assert rows_b == rows_gpu
+    s = harness.prepare_sample(recs[0], "direct")
+    ids = tok([s.prompt])["input_ids"]
+    pix = torch.cat([O.siglip_image_processor(im, size=cfg.vision_config.image_size) for im in s.vit_inputs])
+    ref = O.greedy_generate(ids, pix, oracle_weights, cfg, 5, eos_token_id=[128001, 128009])
+    assert rows_gpu[0]["raw"] == tok.batch_decode(ref[:, ids.shape[1]:])[0]
+    # the reference crashes on a record with fewer <image> tags than images (0 image-token groups, N ViT inputs): same error
+    with pytest.raises(ValueError, match="number of image tokens"):
+        harness.run_inference(_records(tmp_path, cfg)[3:], model, tok, "direct", gpu_tiler=tiler)
+
+
+def test_idefics2_processor_and_model_on_device():
+    """IDEF:22-30, 88-97 on the device: processor tensors -> generate vs the Idefics2 CPU oracle (mixed image sizes)."""
+    from PIL import Image
+    from leopard_amd import idefics2_compat as IC
+    from leopard_amd.idefics2 import Idefics2SynthSource
+    from leopard_amd.ops import Ops
+    from leopard_amd.synth import idefics2_state_dict_numpy, synth_image_u8
+    from oracle import idefics2_oracle as IO
+    from tests.test_emu_idefics2 import micro_idefics2
+    from tests.test_idefics2_compat import ToyTokenizer
+    cfg = micro_idefics2()
+    ops = Ops()
+    model = IC.Idefics2ForConditionalGeneration(cfg, lambda dev, dt: Idefics2SynthSource(cfg, ops, dev, dt), torch.float16, ops,
+                                                eos_token_id=(2,)).to(DEV).eval()
+    proc = IC.Idefics2Processor(ToyTokenizer(), longest_edge=cfg.longest_edge, image_seq_len=cfg.perceiver_config.n_latents)
+    imgs = [Image.fromarray(synth_image_u8(5, 100, 60)), Image.fromarray(synth_image_u8(6, 44, 58))]
+    msgs = [{"role": "user", "content": [{"type": "text", "text": "<image><image>ab"}]}]
+    inputs = proc(text=proc.apply_chat_template(msgs, add_generation_prompt=True), images=imgs, return_tensors="pt")
+    inputs = {k: v.to(DEV) for k, v in inputs.items()}
+    got = model.generate(**inputs, max_new_tokens=4)
+    Wt = IO.weights_from_numpy(idefics2_state_dict_numpy(cfg))
+    images = IC.Idefics2ForConditionalGeneration.unpad_images(inputs["pixel_values"].cpu(), inputs["pixel_attention_mask"].cpu())
+    ids = inputs["input_ids"].cpu()
+    want, cur = [int(t) for t in ids[0]], ids
+    for _ in range(4):
+        nxt = int(IO.prefill_logits(cur, images, Wt, cfg)[0, -1].argmax())
+        want.append(nxt)
+        if nxt == 2:
+            break
+        cur = torch.cat([cur, torch.tensor([[nxt]])], dim=1)
+    assert got.device.type == "cuda" and got[0].tolist() == want

@@ -87,3 +87,24 @@ def test_generate_through_the_surface_matches_oracle():
             break
         cur = torch.cat([cur, torch.tensor([[nxt]])], dim=1)
     assert got[0].tolist() == want
+
+
+def test_patch_validity_any_through_the_surface_matches_oracle():
+    """patch_validity='any' (transformers 4.4x rule): the smaller image keeps its partly padded patch column through the HIP path;
+    first generated token == the oracle on the same crops, and the crops differ from the 'all' rule's."""
+    ops = emu_ops()
+    cfg = micro_idefics2()
+    model = IC.Idefics2ForConditionalGeneration(cfg, lambda dev, dt: Idefics2SynthSource(cfg, ops, dev, dt), torch.float16, ops,
+                                                eos_token_id=(2,)).to("cpu").eval()
+    model.patch_validity = "any"
+    proc = IC.Idefics2Processor(ToyTokenizer(), longest_edge=cfg.longest_edge, image_seq_len=cfg.perceiver_config.n_latents)
+    imgs = [Image.fromarray(synth_image_u8(5, 100, 60)), Image.fromarray(synth_image_u8(6, 44, 58))]      # -> 33 x 56 and 56 x 42 px
+    msgs = [{"role": "user", "content": [{"type": "text", "text": "<image><image>ab"}]}]
+    inputs = proc(text=proc.apply_chat_template(msgs, add_generation_prompt=True), images=imgs, return_tensors="pt")
+    crops_any = model.unpad_images(inputs["pixel_values"], inputs["pixel_attention_mask"], "any", 14)
+    crops_all = model.unpad_images(inputs["pixel_values"], inputs["pixel_attention_mask"], "all", 14)
+    assert [tuple(c.shape) for c in crops_any] != [tuple(c.shape) for c in crops_all]
+    got = model.generate(**inputs, max_new_tokens=1)
+    Wt = IO.weights_from_numpy(idefics2_state_dict_numpy(cfg))
+    want = int(IO.prefill_logits(inputs["input_ids"], crops_any, Wt, cfg)[0, -1].argmax())
+    assert int(got[0, -1]) == want

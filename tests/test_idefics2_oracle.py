@@ -35,3 +35,23 @@ def test_navit_position_ids():
     assert IO.navit_position_ids(2, 4, 4).tolist() == [0, 1, 2, 3, 8, 9, 10, 11]
     ids = IO.navit_position_ids(46, 70, 70)
     assert ids.numel() == 3220 and int(ids.max()) < 4900 and ids[0] == 0
+
+
+def test_patch_validity_any_rule_matches_third_party(golden_dir):
+    """The 4.4x rule (a patch belongs to an image when ANY of its pixels is real): the smaller image of a mixed-size sample keeps a
+    partly zero-padded patch column; fixture generated from the third-party model (oracle/gen_golden.py: the 5.15 model fed the mask
+    that makes its ALL rule coincide with ANY)."""
+    from leopard_amd.idefics2_compat import Idefics2ForConditionalGeneration as M
+    g = np.load(os.path.join(golden_dir, "idefics2_tiny_any.npz"))
+    cfg = idefics2_tiny_config()
+    W = IO.weights_from_numpy(idefics2_state_dict_numpy(cfg))
+    pix, msk = torch.from_numpy(g["pixel_values"]), torch.from_numpy(g["pixel_attention_mask"])
+    ids = torch.from_numpy(g["ids"]).reshape(1, -1)
+    any_imgs = M.unpad_images(pix, msk, "any", cfg.vision_config.patch_size)
+    all_imgs = M.unpad_images(pix, msk, "all", cfg.vision_config.patch_size)
+    assert [tuple(i.shape) for i in all_imgs] == [(3, 42, 56), (3, 58, 30)] and [tuple(i.shape) for i in any_imgs] == [(3, 42, 56), (3, 56, 42)]
+    logits, parts = IO.prefill_logits(ids, any_imgs, W, cfg, return_parts=True)
+    assert np.abs(parts["image_features"].numpy() - g["image_hidden_states"]).max() <= 1e-5
+    assert np.abs(logits.numpy() - g["logits"]).max() <= 1e-5
+    other = np.load(os.path.join(golden_dir, "idefics2_tiny.npz"))
+    assert np.abs(g["logits"] - other["logits"]).max() > 1e-3                 # the two rules really differ on this sample
