@@ -173,19 +173,36 @@ LMI_DEV void gemm_tile_rstd(const GemmArgs& p, int m0, int tid, float* rstd_lds)
     const float* part = p.rowsq_in + (long)imin(m0 + r, p.M - 1) * p.rowsq_parts;
     const int qlen = p.rowsq_parts >> 2;                                     // partials per quarter (rowsq_parts % 4 == 0 is checked by the launcher)
     float q[4 / TPR];
+    if (qlen == 16) {
+        // hidden size 4096 (64 partials per row): every load of this thread is issued before the first add — left as a loop
+        // with a run-time bound, each 16-byte load is a dependent round trip to L2 (~1 us under load, 8 of them per tile)
+        f32x4 v[4 / TPR][4];
 #pragma unroll
-    for (int i = 0; i < 4 / TPR; ++i) {
-        const float* src = part + (sub * (4 / TPR) + i) * qlen;
-        float acc = 0.f;
-        if ((qlen & 3) == 0) {
-            for (int j = 0; j < qlen; j += 4) {
-                const f32x4 v = *(const f32x4*)(src + j);
-                acc += (v[0] + v[1]) + (v[2] + v[3]);
-            }
-        } else {
-            for (int j = 0; j < qlen; ++j) acc += src[j];
+        for (int i = 0; i < 4 / TPR; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = *(const f32x4*)(part + (sub * (4 / TPR) + i) * 16 + j * 4);
+#pragma unroll
+        for (int i = 0; i < 4 / TPR; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);      // same order as the generic path
+            q[i] = acc;
         }
-        q[i] = acc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4 / TPR; ++i) {
+            const float* src = part + (sub * (4 / TPR) + i) * qlen;
+            float acc = 0.f;
+            if ((qlen & 3) == 0) {
+                for (int j = 0; j < qlen; j += 4) {
+                    const f32x4 v = *(const f32x4*)(src + j);
+                    acc += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+            } else {
+                for (int j = 0; j < qlen; ++j) acc += src[j];
+            }
+            q[i] = acc;
+        }
     }
     float s;
     if (TPR == 2) {
@@ -220,6 +237,11 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
     // source columns of this lane in the image: plain = oc..oc+7; SwiGLU = gate block, up block 32 columns further;
     // RoPE = first-half block, rotate-half partner block 32 columns further
     const int sc = PAIRED ? (oc >> 5) * 64 + (oc & 31) : oc;
+    f32x4 gam0 = {0.f, 0.f, 0.f, 0.f}, gam1 = gam0;          // producer mode: the next RMSNorm's gain for this lane's 8 columns
+    if (EPI == EPI_RESID_F32 && p.norm_out) {
+        gam0 = *(const f32x4*)(p.norm_gamma + nw0 + oc);
+        gam1 = *(const f32x4*)(p.norm_gamma + nw0 + oc + 4);
+    }
     f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
     if (!PAIRED && p.bias) {
         bias0 = *(const f32x4*)(p.bias + nw0 + oc);
@@ -366,10 +388,9 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 *(f32x4*)(drow + 4) = v1[it];
                 if (EPI == EPI_RESID_F32 && p.norm_out) {
                     // the next RMSNorm, started here: gain applied and rounded; its row scale is finished by the consumer GEMM
-                    const f32x4 g0 = *(const f32x4*)(p.norm_gamma + nw0 + oc), g1 = *(const f32x4*)(p.norm_gamma + nw0 + oc + 4);
                     T8 hn;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { hn[e] = (T)(v0[it][e] * g0[e]); hn[4 + e] = (T)(v1[it][e] * g1[e]); }
+                    for (int e = 0; e < 4; ++e) { hn[e] = (T)(v0[it][e] * gam0[e]); hn[4 + e] = (T)(v1[it][e] * gam1[e]); }
                     *(T8*)((T*)p.norm_out + orow[it] * p.ld_norm + nw0 + oc) = hn;
                     if ((lane & 7) == 0) p.rowsq_out[orow[it] * (long)(p.N >> 6) + (nw0 >> 6)] = sq;
                 }

@@ -30,7 +30,7 @@ from .config import Idefics2Config
 from .engine import KVCache, LeopardEngine, PrefillResult
 from .ops import Ops
 from .synth import KIND_WEIGHT, idefics2_param_specs, name_seed
-from .weights import LlmLayerW, VitLayerW, _pad1, _pad2, _round_up, interleave_gate_up
+from .weights import LlmLayerW, VitLayerW, _pad1, _pad2, _round_up, build_llm_layers, check_tp_degree, interleave_gate_up
 
 
 class Idefics2SynthSource:
@@ -68,16 +68,24 @@ class Idefics2Weights:
     final_norm: torch.Tensor = None
     lm_head: torch.Tensor = None
     patch_k: int = 0; vit_ff: int = 0; llm_ff: int = 0; q_w_rows: int = 0; kv_rows: int = 0
+    mp_ff: int = 0                           # modality-projection FFN width (never sharded; = the text model's intermediate size)
+    # tensor-parallel shard of the Mistral decoder (BASELINE config 4: "TP=8 LLM over xGMI"); the vision side is replicated and
+    # sharded by IMAGE at run time (Idefics2Engine.encode_images_sharded)
+    llm_heads: int = 0; llm_kv_heads: int = 0; tp_rank: int = 0; tp_size: int = 1
 
     @classmethod
-    def build(cls, cfg: Idefics2Config, source, dtype) -> "Idefics2Weights":
+    def build(cls, cfg: Idefics2Config, source, dtype, tp_rank: int = 0, tp_size: int = 1) -> "Idefics2Weights":
         vc, tc, pc = cfg.vision_config, cfg.text_config, cfg.perceiver_config
         W = cls(cfg=cfg, dtype=dtype)
+        check_tp_degree(tc, tp_size)
+        W.tp_rank, W.tp_size = tp_rank, tp_size
+        W.llm_heads, W.llm_kv_heads = tc.num_attention_heads // tp_size, tc.num_key_value_heads // tp_size
         g = source.get
         v = "model.vision_model."
         W.patch_k = _round_up(vc.patch_dim, 64)
         W.vit_ff = _round_up(vc.intermediate_size, 128)
-        W.llm_ff = tc.intermediate_size
+        W.llm_ff = tc.intermediate_size // tp_size
+        W.mp_ff = tc.intermediate_size
         W.patch_w = _pad2(g(v + "embeddings.patch_embedding.weight").reshape(vc.hidden_size, -1), vc.hidden_size, W.patch_k)
         W.patch_b = _pad1(g(v + "embeddings.patch_embedding.bias"), vc.hidden_size)
         W.pos_emb = g(v + "embeddings.position_embedding.weight").to(torch.float32).contiguous()
@@ -117,15 +125,7 @@ class Idefics2Weights:
         W.perceiver_norm = g(r + "norm.weight").float().contiguous()
         l = "model.text_model."
         W.embed = g(l + "embed_tokens.weight").contiguous()
-        for i in range(tc.num_hidden_layers):
-            p = f"{l}layers.{i}."
-            W.llm_layers.append(LlmLayerW(
-                in_norm=g(p + "input_layernorm.weight").float().contiguous(),
-                qkv_w=torch.cat([g(p + f"self_attn.{n}_proj.weight") for n in "qkv"], dim=0).contiguous(),
-                o_w=g(p + "self_attn.o_proj.weight").contiguous(),
-                post_norm=g(p + "post_attention_layernorm.weight").float().contiguous(),
-                gu_w=interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")),
-                down_w=g(p + "mlp.down_proj.weight").contiguous()))
+        W.llm_layers = build_llm_layers(g, l, tc, tp_rank, tp_size)
         W.final_norm = g(l + "norm.weight").float().contiguous()
         head = g("lm_head.weight")
         W.lm_head = _pad2(head, _round_up(head.shape[0], 128), tc.hidden_size)
@@ -196,7 +196,7 @@ class Idefics2Engine(LeopardEngine):
         tc, pc = cfg.text_config, cfg.perceiver_config
         D, Lt, n_img = tc.hidden_size, pc.n_latents, len(counts)
         P = feats.shape[0]
-        gu = self._empty(P, W.llm_ff)
+        gu = self._empty(P, W.mp_ff)
         ops.gemm(feats, W.mp_gu_w, gu, epilogue=_lib.EPI_SWIGLU)
         ctx = self._empty(P, D, dtype=torch.float32)
         ops.gemm(gu, W.mp_down_w, ctx, epilogue=_lib.EPI_STORE_F32)
@@ -242,10 +242,33 @@ class Idefics2Engine(LeopardEngine):
         feats, counts = self.vision_tower_images(images)
         return self.connector(feats, counts)
 
+    def encode_images_sharded(self, images: Sequence[torch.Tensor]) -> torch.Tensor:
+        """Tensor-parallel runs: the images of the sample are independent through the tower, the modality projection and the
+        perceiver, so rank r encodes images r, r + R, ... and ONE all-gather of the [n_latents, D] results restores the full set
+        on every rank, in image order (bit-identical to ``encode_images``: no arithmetic crosses an image boundary)."""
+        comm = self.comm
+        n, R = len(images), comm.world
+        Lt, D = self.cfg.perceiver_config.n_latents, self.cfg.text_config.hidden_size
+        per = -(-n // R)
+        mine = torch.zeros(per * Lt, D, dtype=torch.float32, device=self.device)
+        own = [images[i] for i in range(comm.rank, n, R)]
+        if own:
+            mine[:len(own) * Lt] = self.encode_images(own)
+        gathered = self._empty(R * per * Lt, D, dtype=torch.float32)
+        comm.all_gather(gathered, mine)
+        g = gathered.view(R, per, Lt, D)
+        return torch.cat([g[i % R, i // R] for i in range(n)], dim=0)
+
     # ---- whole prefill (IDEF:91-95) ------------------------------------------------------------------------------
     @torch.no_grad()
     def prefill(self, input_ids: torch.Tensor, images: Optional[Sequence[torch.Tensor]], cache: Optional[KVCache] = None,
                 all_logits: bool = False, keep_parts: bool = False, visual_tokens: Optional[torch.Tensor] = None) -> PrefillResult:
+        if self.tp_size > 1:                                  # BASELINE config 4: one sample on all ranks (SURVEY.md 8e)
+            if all_logits or keep_parts:
+                raise NotImplementedError("all_logits / keep_parts are single-rank diagnostics")
+            if visual_tokens is None and images is not None and len(images):
+                visual_tokens = self.encode_images_sharded(images)
+            return self._prefill_tp(input_ids, None, cache, visual_tokens)
         parts = {} if keep_parts else None
         if visual_tokens is None and images is not None and len(images):
             visual_tokens = self.encode_images(images)

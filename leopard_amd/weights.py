@@ -103,6 +103,51 @@ class LlmLayerW:
     qkv_w_rope: torch.Tensor = None        # qkv_w with the q / k rows in lmi_rmsnorm_rope's order (head_dim 128 only)
 
 
+
+def build_llm_layers(g, prefix: str, tc, tp_rank: int = 0, tp_size: int = 1) -> List[LlmLayerW]:
+    """The Llama / Mistral decoder layers as the kernels consume them (shared by Leopard-LLaVA and Leopard-Idefics2): q|k|v fused
+    (+ the copy in lmi_rmsnorm_rope's row order), gate/up interleaved, and — for ``tp_size`` > 1 — the Megatron tensor-parallel
+    shard ``tp_rank``: q/k/v and gate/up split by output rows (whole heads / FFN slices), o_proj and down_proj by input columns."""
+    Dt, full_q, full_kv = tc.hidden_size, tc.num_attention_heads * tc.head_dim, tc.num_key_value_heads * tc.head_dim
+    heads, kv_heads, ff = tc.num_attention_heads // tp_size, tc.num_key_value_heads // tp_size, tc.intermediate_size // tp_size
+
+    def expect(name: str, shape) -> torch.Tensor:
+        """A checkpoint whose config.json disagrees with its tensors (the reference converter writes
+        num_key_value_heads = num_attention_heads for non-70b models, hf2megatron_llava.py:1035) must fail here, not
+        slice silently and leave attention reading unwritten K/V columns."""
+        t = g(name)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tuple(t.shape)} does not match the configuration (expected {tuple(shape)}: "
+                             f"hidden {Dt}, {tc.num_attention_heads} q / {tc.num_key_value_heads} kv heads x {tc.head_dim}, "
+                             f"FFN {tc.intermediate_size})")
+        return t
+    layers = []
+    for i in range(tc.num_hidden_layers):
+        p = f"{prefix}layers.{i}."
+        qw, kw = heads * tc.head_dim, kv_heads * tc.head_dim
+        rq, rk, rf = slice(tp_rank * qw, (tp_rank + 1) * qw), slice(tp_rank * kw, (tp_rank + 1) * kw), slice(tp_rank * ff, (tp_rank + 1) * ff)
+        qkv_w = torch.cat([expect(p + "self_attn.q_proj.weight", (full_q, Dt))[rq], expect(p + "self_attn.k_proj.weight", (full_kv, Dt))[rk],
+                           expect(p + "self_attn.v_proj.weight", (full_kv, Dt))[rk]], dim=0).contiguous()
+        qkv_rope = None
+        if tc.head_dim == 128:
+            qkv_rope = torch.cat([rope_permute_rows(qkv_w[:qw + kw]), qkv_w[qw + kw:]], dim=0).contiguous()
+        layers.append(LlmLayerW(
+            in_norm=g(p + "input_layernorm.weight").float().contiguous(),
+            qkv_w=qkv_w, qkv_w_rope=qkv_rope,
+            o_w=expect(p + "self_attn.o_proj.weight", (Dt, full_q))[:, rq].contiguous(),
+            post_norm=g(p + "post_attention_layernorm.weight").float().contiguous(),
+            gu_w=interleave_gate_up(expect(p + "mlp.gate_proj.weight", (tc.intermediate_size, Dt))[rf],
+                                    expect(p + "mlp.up_proj.weight", (tc.intermediate_size, Dt))[rf]),
+            down_w=expect(p + "mlp.down_proj.weight", (Dt, tc.intermediate_size))[:, rf].contiguous()))
+    return layers
+
+
+def check_tp_degree(tc, tp_size: int) -> None:
+    if tp_size > 1 and (tc.num_attention_heads % tp_size or tc.num_key_value_heads % tp_size or (tc.intermediate_size // tp_size) % 64
+                        or tc.intermediate_size % tp_size):
+        raise ValueError(f"tensor parallel degree {tp_size} must divide the head counts ({tc.num_attention_heads}/"
+                         f"{tc.num_key_value_heads}) and leave an FFN slice that is a multiple of 64")
+
 @dataclass
 class EngineWeights:
     cfg: LeopardConfig
@@ -134,10 +179,7 @@ class EngineWeights:
         vc, tc = cfg.vision_config, cfg.text_config
         W = cls(cfg=cfg, dtype=dtype)
         W.tp_rank, W.tp_size = tp_rank, tp_size
-        if tp_size > 1 and (tc.num_attention_heads % tp_size or tc.num_key_value_heads % tp_size or (tc.intermediate_size // tp_size) % 64
-                            or tc.intermediate_size % tp_size):
-            raise ValueError(f"tensor parallel degree {tp_size} must divide the head counts ({tc.num_attention_heads}/"
-                             f"{tc.num_key_value_heads}) and leave an FFN slice that is a multiple of 64")
+        check_tp_degree(tc, tp_size)
         for dim, what in ((vc.hidden_size, "vision hidden"), (tc.hidden_size, "text hidden"),
                           (tc.num_attention_heads * tc.head_dim, "q width"), (tc.num_key_value_heads * tc.head_dim, "kv width")):
             if dim % 128:
@@ -171,35 +213,7 @@ class EngineWeights:
         W.proj2_w = g(m + "linear_2.weight").contiguous(); W.proj2_b = _pad1(g(m + "linear_2.bias"), tc.hidden_size)
         l = "language_model.model."
         W.embed = g(l + "embed_tokens.weight").contiguous()
-        Dt, full_q, full_kv = tc.hidden_size, tc.num_attention_heads * tc.head_dim, tc.num_key_value_heads * tc.head_dim
-
-        def expect(name: str, shape) -> torch.Tensor:
-            """A checkpoint whose config.json disagrees with its tensors (the reference converter writes
-            num_key_value_heads = num_attention_heads for non-70b models, hf2megatron_llava.py:1035) must fail here, not
-            slice silently and leave attention reading unwritten K/V columns."""
-            t = g(name)
-            if tuple(t.shape) != tuple(shape):
-                raise ValueError(f"{name}: shape {tuple(t.shape)} does not match the configuration (expected {tuple(shape)}: "
-                                 f"hidden {Dt}, {tc.num_attention_heads} q / {tc.num_key_value_heads} kv heads x {tc.head_dim}, "
-                                 f"FFN {tc.intermediate_size})")
-            return t
-        for i in range(tc.num_hidden_layers):
-            p = f"{l}layers.{i}."
-            qw, kw, ff = W.llm_heads * tc.head_dim, W.llm_kv_heads * tc.head_dim, W.llm_ff
-            rq, rk, rf = slice(tp_rank * qw, (tp_rank + 1) * qw), slice(tp_rank * kw, (tp_rank + 1) * kw), slice(tp_rank * ff, (tp_rank + 1) * ff)
-            qkv_w = torch.cat([expect(p + "self_attn.q_proj.weight", (full_q, Dt))[rq], expect(p + "self_attn.k_proj.weight", (full_kv, Dt))[rk],
-                               expect(p + "self_attn.v_proj.weight", (full_kv, Dt))[rk]], dim=0).contiguous()
-            qkv_rope = None
-            if tc.head_dim == 128:
-                qkv_rope = torch.cat([rope_permute_rows(qkv_w[:qw + kw]), qkv_w[qw + kw:]], dim=0).contiguous()
-            W.llm_layers.append(LlmLayerW(
-                in_norm=g(p + "input_layernorm.weight").float().contiguous(),
-                qkv_w=qkv_w, qkv_w_rope=qkv_rope,
-                o_w=expect(p + "self_attn.o_proj.weight", (Dt, full_q))[:, rq].contiguous(),
-                post_norm=g(p + "post_attention_layernorm.weight").float().contiguous(),
-                gu_w=interleave_gate_up(expect(p + "mlp.gate_proj.weight", (tc.intermediate_size, Dt))[rf],
-                                        expect(p + "mlp.up_proj.weight", (tc.intermediate_size, Dt))[rf]),
-                down_w=expect(p + "mlp.down_proj.weight", (Dt, tc.intermediate_size))[:, rf].contiguous()))
+        W.llm_layers = build_llm_layers(g, l, tc, tp_rank, tp_size)
         W.final_norm = g(l + "norm.weight").float().contiguous()
         head = g("language_model.lm_head.weight")
         W.lm_head = _pad2(head, _round_up(head.shape[0], 128), tc.hidden_size)

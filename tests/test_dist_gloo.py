@@ -148,3 +148,61 @@ def test_tensor_parallel_llm_two_ranks_gloo():
     assert d_prefill <= 3e-3 * max(1.0, scale) and d_decode <= 3e-3 * max(1.0, scale) and same_tokens
     assert d_exact <= 2e-4 * max(1.0, scale)                       # fp32 exchange: only the summation order differs
     assert sent > 0
+
+
+def _idefics2_tp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from leopard_amd import dist as D
+    from leopard_amd.config import Idefics2Config, PerceiverConfig, TextConfig, VisionConfig
+    from leopard_amd.engine import KVCache
+    from leopard_amd.idefics2 import Idefics2Engine, Idefics2SynthSource, Idefics2Weights
+    from tests.emu_util import emu_ops
+    D.init(backend="gloo")
+    ops = emu_ops()
+    cfg = Idefics2Config(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16,
+                                   image_size=56, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                               num_key_value_heads=2, vocab_size=256, rope_theta=10000.0, rope_scaling=None, sliding_window=9),
+        perceiver_config=PerceiverConfig(n_latents=3, depth=1, n_heads=1, head_dim=96, num_key_value_heads=1),
+        image_token_id=250, longest_edge=56)
+    src = Idefics2SynthSource(cfg, ops, "cpu", torch.float16)
+    eng = Idefics2Engine(cfg, Idefics2Weights.build(cfg, src, torch.float16, tp_rank=rank, tp_size=world), ops=ops, device="cpu")
+    rng = np.random.default_rng(8)
+    imgs = [torch.from_numpy(rng.standard_normal((3, 42, 56)).astype(np.float32)),
+            torch.from_numpy(rng.standard_normal((3, 58, 30)).astype(np.float32)),
+            torch.from_numpy(rng.standard_normal((3, 28, 28)).astype(np.float32))]          # 3 images on 2 ranks: 2 + 1
+    L = cfg.perceiver_config.n_latents
+    ids = torch.tensor([[5, 7] + [250] * L + [9, 11] + [250] * L + [13] + [250] * L + [17, 19]])
+    vis = eng.encode_images_sharded(imgs)
+    res = eng.prefill(ids, imgs)
+    ref = None
+    if rank == 0:
+        one = Idefics2Engine(cfg, Idefics2Weights.build(cfg, src, torch.float16), ops=ops, device="cpu")
+        r1 = one.prefill(ids, imgs)
+        ref = (bool(torch.equal(vis, one.encode_images(imgs))), float((res.logits_last - r1.logits_last).abs().max()),
+               float(r1.logits_last.abs().max()), int(res.logits_last.argmax()) == int(r1.logits_last.argmax()))
+    out.put((rank, res.logits_last.tolist(), ref))
+    D.barrier()
+
+
+def test_idefics2_tensor_parallel_two_ranks_gloo():
+    """BASELINE config 4 (Leopard-Idefics2, TP LLM) on 2 CPU ranks: images sharded round-robin + one all-gather (bit-identical
+    visual tokens), Mistral decoder tensor-parallel with sequence-parallel norms and the sliding window, column-parallel head."""
+    mp.set_start_method("spawn", force=True)
+    from tests.emu_util import emu_ops
+    emu_ops()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_idefics2_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, ref), (_, l1, _) = res
+    assert l0 == l1
+    vis_equal, d, scale, same = ref
+    assert vis_equal and d <= 3e-3 * max(1.0, scale) and same

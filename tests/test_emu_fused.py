@@ -233,3 +233,21 @@ def test_generate_batch_equals_per_sample_generate():
     for (ids, tiles), got in zip(samples, batch):
         one = eng.generate(ids, tiles, max_new_tokens=4, eos_token_id=())
         assert torch.equal(one, got)
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 5])
+def test_gemm_ex_consumer_at_hidden_4096(ops, cfg):
+    """The row-scale prologue's batched-load path (64 partials per row = hidden size 4096), both threads-per-row geometries."""
+    dtype = torch.float16
+    M, N, K = 70, 128, 4096
+    a, w = rnd((M, K), dtype, 21, 0.5), rnd((N, K), dtype, 22, 0.05)
+    sq = (torch.rand(M, K // 64, generator=torch.Generator().manual_seed(23)) + 0.5) * 64
+    ops.set_option("gemm.config", cfg)
+    try:
+        out = torch.empty(M, N, dtype=dtype)
+        ops.gemm_ex(a, w, out, rowsq_in=sq, norm_dim=K, norm_eps=1e-5)
+        rstd = torch.rsqrt(sq.sum(-1, keepdim=True) / K + 1e-5)
+        ref = (a.float() @ w.float().T) * rstd
+        assert ((out.float() - ref).abs() / (1 + ref.abs())).max().item() <= 2 * eps(dtype)
+    finally:
+        ops.set_option("gemm.config", -1)
