@@ -440,6 +440,8 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     }
     if (x.rowsq_in && (x.rowsq_parts <= 0 || (x.rowsq_parts & 3) || x.norm_dim <= 0 || !aligned16(x.rowsq_in)))
         return fail(LMI_EINVAL, "%s: rowsq_in needs rowsq_parts > 0 and a multiple of 4, norm_dim > 0 and 16-byte alignment", who);
+    if (x.rowsq_in && epilogue != LMI_EPI_STORE && epilogue != LMI_EPI_SWIGLU && epilogue != LMI_EPI_QKV_ROPE)
+        return fail(LMI_EINVAL, "%s: rowsq_in (row scale) is supported by the STORE, SWIGLU and q|k|v + RoPE epilogues", who);
     if (x.norm_out && (epilogue != LMI_EPI_RESIDUAL || !x.norm_gamma || !x.rowsq_out || (x.ld_norm & 7) || x.ld_norm < N || row_map ||
                        !aligned16(x.norm_out) || !aligned16(x.norm_gamma)))
         return fail(LMI_EINVAL, "%s: norm_out needs the RESIDUAL epilogue, norm_gamma, rowsq_out, ld_norm %% 8 == 0 and no row_map", who);

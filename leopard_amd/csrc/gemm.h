@@ -90,7 +90,7 @@ struct GemmCfg {
     static constexpr int G = A_PASSES + W_PASSES;              // LDS-DMA instructions per thread per k-tile
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int SMEM = STAGES * STAGE_BYTES;
-    static constexpr int SMEM_TOTAL = SMEM + BM * 4;             // + the row scales of a folded RMSNorm (gemm_tile_rstd)
+    static constexpr int SMEM_TOTAL = SMEM + BM * 4;             // + the row scales of a folded RMSNorm (GemmRowScale)
     static constexpr int D = STAGES - 1;                       // prefetch distance in k-tiles (>= 1)
     static_assert(STAGES >= 2, "ring needs at least two slots");
     static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows vs threads");
@@ -160,61 +160,68 @@ LMI_DEV bool gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, in
 // `put(mi, stage)` writes rows mi*32 .. mi*32+31 of the wave tile into the image (it depends on the MFMA shape's accumulator layout).
 template <int WTN> struct GemmImage { static constexpr int RS = WTN * 4 + 16; };   // LDS row stride of the fp32 image
 
-// Row scales of the folded RMSNorm for the BM rows of a tile, computed ONCE per workgroup in the kernel prologue (under the
-// latency of the first LDS-DMA pieces) into a BM-float LDS array behind the k-tile ring; the epilogue then reads one float
-// per row.  rstd[r] = rsqrt(sum_j rowsq_in[m0 + r, j] / norm_dim + eps).  The summation order is fixed — four quarter sums
-// of contiguous partials, ((q0 + q1) + (q2 + q3)) — whatever the tile geometry (NT / BM = 2 or 4 threads share a row), so a
-// row's scale does not depend on the geometry chosen for the problem size or on where the row sits in a packed batch.
+// Row scales of the folded RMSNorm for the BM rows of a tile: rstd[r] = rsqrt(sum_j rowsq_in[m0 + r, j] / norm_dim + eps), kept in a
+// BM-float LDS array behind the k-tile ring; the epilogue reads one float per row.  Two phases so that the memory latency costs
+// nothing (a tile's prologue and epilogue are exposed: one workgroup per CU): `load` issues this thread's share of the row's
+// partials BEFORE the first LDS-DMA pieces (older VMEM operations complete first, so the counted vmcnt waits of the main loop are
+// unaffected) and holds them in registers through the main loop; `finish`, after the last k-tile, sums them, exchanges with the
+// 1 or 3 other threads of the row and writes the scale to LDS (the caller's next barrier publishes it).
+// The summation order is fixed — four quarter sums of contiguous partials, ((q0 + q1) + (q2 + q3)) — whatever the tile geometry
+// (NT / BM = 2 or 4 threads share a row), so a row's scale does not depend on the geometry chosen for the problem size or on
+// where the row sits in a packed batch.
 template <typename C>
-LMI_DEV void gemm_tile_rstd(const GemmArgs& p, int m0, int tid, float* rstd_lds) {
-    constexpr int TPR = C::NT / C::BM;                                       // threads per row: 2 or 4
+struct GemmRowScale {
+    static constexpr int TPR = C::NT / C::BM;                                // threads per row: 2 or 4
+    static constexpr int QPT = 4 / TPR;                                      // quarters per thread
     static_assert(TPR == 2 || TPR == 4, "threads per tile row");
-    const int r = tid / TPR, sub = tid % TPR;
-    const float* part = p.rowsq_in + (long)imin(m0 + r, p.M - 1) * p.rowsq_parts;
-    const int qlen = p.rowsq_parts >> 2;                                     // partials per quarter (rowsq_parts % 4 == 0 is checked by the launcher)
-    float q[4 / TPR];
-    if (qlen == 16) {
-        // hidden size 4096 (64 partials per row): every load of this thread is issued before the first add — left as a loop
-        // with a run-time bound, each 16-byte load is a dependent round trip to L2 (~1 us under load, 8 of them per tile)
-        f32x4 v[4 / TPR][4];
+    f32x4 v[QPT][4];                                                         // fast path: 16 partials per quarter (hidden size 4096)
+    const float* part;
+    int qlen;
+
+    LMI_DEV void load(const GemmArgs& p, int m0, int tid) {
+        const int r = tid / TPR, sub = tid % TPR;
+        part = p.rowsq_in + (long)imin(m0 + r, p.M - 1) * p.rowsq_parts + sub * QPT * (p.rowsq_parts >> 2);
+        qlen = p.rowsq_parts >> 2;                                           // rowsq_parts % 4 == 0 is checked by the launcher
+        if (qlen == 16) {
 #pragma unroll
-        for (int i = 0; i < 4 / TPR; ++i)
+            for (int i = 0; i < QPT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = *(const f32x4*)(part + (sub * (4 / TPR) + i) * 16 + j * 4);
-#pragma unroll
-        for (int i = 0; i < 4 / TPR; ++i) {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);      // same order as the generic path
-            q[i] = acc;
+                for (int j = 0; j < 4; ++j) v[i][j] = *(const f32x4*)(part + i * 16 + j * 4);
         }
-    } else {
+    }
+    LMI_DEV void finish(const GemmArgs& p, int tid, float* rstd_lds) {
+        float q[QPT];
 #pragma unroll
-        for (int i = 0; i < 4 / TPR; ++i) {
-            const float* src = part + (sub * (4 / TPR) + i) * qlen;
+        for (int i = 0; i < QPT; ++i) {
             float acc = 0.f;
-            if ((qlen & 3) == 0) {
+            if (qlen == 16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+            } else if ((qlen & 3) == 0) {
                 for (int j = 0; j < qlen; j += 4) {
-                    const f32x4 v = *(const f32x4*)(src + j);
-                    acc += (v[0] + v[1]) + (v[2] + v[3]);
+                    const f32x4 w = *(const f32x4*)(part + i * qlen + j);
+                    acc += (w[0] + w[1]) + (w[2] + w[3]);
                 }
             } else {
-                for (int j = 0; j < qlen; ++j) acc += src[j];
+                for (int j = 0; j < qlen; ++j) acc += part[i * qlen + j];
             }
             q[i] = acc;
         }
+        float s;
+        if (TPR == 2) {
+            s = q[0] + q[QPT - 1];                                           // (q0 + q1) resp. (q2 + q3)
+            s += shfl_xor(s, 1);
+        } else {
+            s = q[0];
+            s += shfl_xor(s, 1);                                             // (q0 + q1), (q2 + q3)
+            s += shfl_xor(s, 2);
+        }
+        if (tid % TPR == 0) rstd_lds[tid / TPR] = 1.0f / sqrtf(s / (float)p.norm_dim + p.norm_eps);
+        lds_write_drain();
     }
-    float s;
-    if (TPR == 2) {
-        s = q[0] + q[1 % (4 / TPR)];                                         // (q0 + q1) resp. (q2 + q3)
-        s += shfl_xor(s, 1);
-    } else {
-        s = q[0];
-        s += shfl_xor(s, 1);                                                 // (q0 + q1), (q2 + q3)
-        s += shfl_xor(s, 2);
-    }
-    if (sub == 0) rstd_lds[r] = 1.0f / sqrtf(s / (float)p.norm_dim + p.norm_eps);
-}
+};
+// the epilogues that may finish a folded RMSNorm (the others never carry the row-scale registers)
+template <int EPI> struct GemmCanScale { static constexpr bool value = (EPI == EPI_STORE_T || EPI == EPI_SWIGLU_T || EPI == EPI_QKV_ROPE_T); };
 
 template <typename T, int EPI, int ACT, typename C, typename Put>
 LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, int wn, int lane, char* stage, const float* rstd_lds) {
@@ -265,7 +272,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 const char* src = stage + row * RS + sc * 4;
                 f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 16);
                 f32x4 b0 = *(const f32x4*)(src + 128), b1 = *(const f32x4*)(src + 144);
-                if (p.rowsq_in) {
+                if (GemmCanScale<EPI>::value && p.rowsq_in) {
                     const float rstd = rstd_lds[wm * C::WTM + mi * 32 + row];
                     a0 *= rstd; a1 *= rstd; b0 *= rstd; b1 *= rstd;
                 }
@@ -313,7 +320,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 const char* src = stage + row * RS + sc * 4;
                 f32x4 g0 = *(const f32x4*)src, g1 = *(const f32x4*)(src + 16);
                 f32x4 u0 = *(const f32x4*)(src + 128), u1 = *(const f32x4*)(src + 144);
-                if (p.rowsq_in) {
+                if (GemmCanScale<EPI>::value && p.rowsq_in) {
                     const float rstd = rstd_lds[wm * C::WTM + mi * 32 + row];
                     g0 *= rstd; g1 *= rstd; u0 *= rstd; u1 *= rstd;
                 }
@@ -341,7 +348,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
             const char* src = stage + row * RS + sc * 4;
             v0[it] = *(const f32x4*)src;
             v1[it] = *(const f32x4*)(src + 16);
-            if (p.rowsq_in) {
+            if (GemmCanScale<EPI>::value && p.rowsq_in) {
                 const float rstd = rstd_lds[wm * C::WTM + mi * 32 + row];
                 v0[it] *= rstd; v1[it] *= rstd;
             }
@@ -493,6 +500,9 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     stager.init(p, m0, n0, tid, smem, wave);
     auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
     float* rstd_lds = (float*)(smem + C::SMEM);
+    constexpr bool CAN_SCALE = GemmCanScale<EPI>::value;
+    GemmRowScale<C> row_scale;
+    if (CAN_SCALE && p.rowsq_in) row_scale.load(p, m0, tid);            // folded RMSNorm: partial sums requested ahead of the first DMA pieces
 
     f32x16 acc[C::NI][C::MI];
 #pragma unroll
@@ -512,8 +522,6 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int g = 0; g < C::G; ++g) issue_piece(g, d, d);
         }
-    // folded RMSNorm: the row scales of this tile, computed under the flight of the first k-tiles (visible after the first barrier)
-    if (p.rowsq_in) { gemm_tile_rstd<C>(p, m0, tid, rstd_lds); lds_write_drain(); }
 
     for (int t = 0; t < nt; ++t) {
         // tile t has landed once at most the D-1 younger tiles are outstanding (ring tail: everything)
@@ -543,6 +551,7 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
         }
     }
 
+    if (CAN_SCALE && p.rowsq_in) row_scale.finish(p, tid, rstd_lds);   // published by the barrier below
     raw_barrier();                                                 // every wave is done reading k-tiles: LDS is free
     gemm_epilogue<T, EPI, ACT, C>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
                                   smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds);
@@ -580,6 +589,9 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     stager.init(p, m0, n0, tid, smem, wave);
     auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
     float* rstd_lds = (float*)(smem + C::SMEM);
+    constexpr bool CAN_SCALE = GemmCanScale<EPI>::value;
+    GemmRowScale<C> row_scale;
+    if (CAN_SCALE && p.rowsq_in) row_scale.load(p, m0, tid);            // folded RMSNorm: partial sums requested ahead of the first DMA pieces
 
     f32x16 acc[C::NI][C::MI];
 #pragma unroll
@@ -593,8 +605,6 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     const int nt = p.K / GEMM_BK;
 #pragma unroll
     for (int g = 0; g < C::G; ++g) issue_piece(g, 0, 0);
-    // folded RMSNorm: the row scales of this tile, computed under the flight of the first k-tile (visible after the barrier below)
-    if (p.rowsq_in) { gemm_tile_rstd<C>(p, m0, tid, rstd_lds); lds_write_drain(); }
     wait_vmcnt_barrier<0>();
     if (grp == 1) raw_barrier();                                   // waves 4-7 run one barrier behind
 
@@ -650,6 +660,10 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
         tile(std::false_type{}, std::false_type{}, nt - 1);
     }
     if (grp == 0) raw_barrier();                                   // balance the barrier count
+    if (CAN_SCALE && p.rowsq_in) {                                 // (workgroup-uniform) row scales of the folded RMSNorm -> LDS, one more
+        row_scale.finish(p, tid, rstd_lds);                        // barrier to publish them before any wave's epilogue reads them
+        raw_barrier();
+    }
     // past its last barrier a wave knows that every other wave has finished its last LOAD segment: LDS is free
     gemm_epilogue<T, EPI, ACT, C>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
                                   smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds);
