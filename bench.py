@@ -196,6 +196,7 @@ def bench_c5(args, dev, dtype, rank, world, D):
     ops = Ops()
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
     eng = LeopardEngine(cfg, W, ops=ops, device=dev)
+    eng.graph_encode = args.graph_encode
     tiler = GpuTiler(ops, dev)
     n_samples, n_img = 8, 8
     samples = []
@@ -227,6 +228,7 @@ def bench_c5(args, dev, dtype, rank, world, D):
            "config": {"workload": f"C5 shape: {n_samples} samples x {n_img} x (1344x896) -> {n_tiles} ViT inputs, "
                                   f"{sum(seq_lens)} tokens packed in one varlen pass; SigLIP-SO400M + Llama-3.1-8B prefill to "
                                   "last-token logits; synthetic seeded weights", "parallelism": f"sample-sharded x{world}"},
+           "graph_encode": bool(args.graph_encode),
            "algorithmic_tflop_per_step": round(fl / 1e12, 2),
            "prefill_mfma_frac": round(fl / 1e12 / (elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4)}
     if rank == 0:
@@ -360,6 +362,7 @@ def main():
                          "figure is measured as well and reported under \"tp\" in the same JSON line")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (lmi_set_option), e.g. gemm.wide=7 for A/B runs")
     ap.add_argument("--no-fuse", action="store_true", help="A/B: separate RMSNorm / RoPE launches instead of the fused GEMM epilogues")
+    ap.add_argument("--graph-encode", action="store_true", help="capture the vision encode (ViT + projector) in a HIP graph per ViT-input count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-tp", action="store_true", help="N > 1: skip the additional one-sample-on-all-ranks (strong scaling) measurement")
@@ -415,6 +418,7 @@ def main():
     torch.cuda.synchronize()
     eng = LeopardEngine(cfg, W, ops=ops, device=dev)
     eng.fuse_norm_rope = not args.no_fuse
+    eng.graph_encode = args.graph_encode
     load_s = time.perf_counter() - t0
 
     class Ctx:

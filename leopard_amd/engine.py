@@ -109,6 +109,8 @@ class LeopardEngine:
         self.tp_chunks = 2             # row chunks per layer under TP: chunk c's collectives overlap chunk c+1's GEMMs
         self.tp_comm_dtype = None      # dtype of the reduce-scattered partial products: None = the compute type, torch.float32 = exact sums
         self._comm_stream = None
+        self.graph_encode = False      # capture the vision encode per ViT-input count in a HIP graph (BASELINE config 5)
+        self._encode_graphs: Dict[int, tuple] = {}
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
@@ -226,7 +228,36 @@ class LeopardEngine:
         return vis
 
     def encode_images(self, tiles: torch.Tensor) -> torch.Tensor:
+        if self.graph_encode and self.device.type == "cuda" and not self.ops.emulated and tiles.dtype == torch.uint8:
+            return self._encode_images_graph(tiles)
         return self.project(self.vision_tower(tiles), tiles.shape[0])
+
+    def _encode_images_graph(self, tiles: torch.Tensor) -> torch.Tensor:
+        """BASELINE config 5 ("hipGraph-captured encode"): the vision tower + projector for N ViT inputs is ~200 launches whose
+        shapes depend on N only, so they are captured ONCE per N into a HIP graph over static buffers (u8 tiles in, fp32 visual
+        tokens out) and replayed: one graph launch instead of ~200 stream launches, no per-launch host work.  Results are those
+        of the eager path bit for bit (same kernels, same order).  The returned tensor is the graph's static output buffer:
+        it is overwritten by the next encode of the same N (callers here consume it immediately in embed_merge)."""
+        n = tiles.shape[0]
+        ent = self._encode_graphs.get(n)
+        if ent is None:
+            static_in = torch.empty_like(tiles)
+            static_in.copy_(tiles)
+            side = torch.cuda.Stream(device=self.device)                       # warm-up outside capture (LDS attributes, allocator)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self.project(self.vision_tower(static_in), n)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self.project(self.vision_tower(static_in), n)
+            if len(self._encode_graphs) >= 8:                                  # a handful of distinct N per workload; bound the pools
+                self._encode_graphs.pop(next(iter(self._encode_graphs)))
+            ent = self._encode_graphs[n] = (g, static_in, static_out)
+        g, static_in, static_out = ent
+        static_in.copy_(tiles)
+        g.replay()
+        return static_out
 
     # ------------------------------------------------------------------------------------------------
     # a10: embedding gather + merge

@@ -27,9 +27,12 @@ from leopard_amd.synth import synth_image_u8, synth_prompt_ids, synth_state_dict
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # max|diff| / max|logit| bounds = measured x 1.2 (see the module docstring; measured values in the comments)
-LOGIT_TOL = {torch.float16: 1.4e-3, torch.bfloat16: 9.5e-3}                       # mid configuration (2 + 2 layers)
-FULL_TOL = {("c1", torch.float16): 1.8e-3, ("c1", torch.bfloat16): 1.6e-2,        # full depth (27 + 32 layers)
-            ("c2", torch.float16): 1.8e-3, ("c2", torch.bfloat16): 1.6e-2}
+LOGIT_TOL = {torch.float16: 1.4e-3, torch.bfloat16: 9.5e-3}      # mid configuration, 2 + 2 layers (measured 1.12e-3 / 7.6e-3 on the all-position logits; 5.2e-4 / 4.5e-3 on the last position)
+FULL_TOL = {("c1", torch.float16): 1.85e-3, ("c1", torch.bfloat16): 1.47e-2,      # full depth, 27 + 32 layers (measured 1.48e-3 / 1.17e-2)
+            ("c2", torch.float16): 1.47e-3, ("c2", torch.bfloat16): 1.15e-2}      # (measured 1.18e-3 / 9.2e-3)
+# C3 sequence length, 2 + 2 layers: residual stream max over 29 M elements / rel-rms, ViT features, last-position logits
+C3LEN_TOL = {torch.float16: (1.15e-3, 9.3e-4, 7.3e-4, 6.0e-4),                    # (measured 9.1e-4, 7.4e-4, 5.8e-4, 4.8e-4)
+             torch.bfloat16: (1.0e-2, 7.3e-3, 5.1e-3, 5.4e-3)}                    # (measured 8.0e-3, 5.8e-3, 4.1e-3, 4.3e-3)
 
 
 def err_stats(got, ref):
@@ -214,9 +217,9 @@ def test_c3_sequence_length_vs_oracle(ops, c3_length_oracle, dtype):
     l_abs, l_nrm, l_rms = err_stats(res.logits_last.cpu(), ref[0, 0])
     print(f"[C3 length {dtype}] residual stream after the last layer, all 7187 rows: normalised-max {x_nrm:.3e} rel-rms {x_rms:.3e} "
           f"(worst row {int(per_row.argmax())}); ViT features 42 tiles: {v_nrm:.3e} / {v_rms:.3e}; logits: {l_nrm:.3e} / {l_rms:.3e}")
-    tol = LOGIT_TOL[dtype]
-    assert x_nrm <= 2 * tol and x_rms <= tol          # max over 29 M elements sits further out in the error distribution than max over a row
-    assert v_nrm <= tol and l_nrm <= tol
+    tx_nrm, tx_rms, t_vit, t_logits = C3LEN_TOL[dtype]
+    assert x_nrm <= tx_nrm and x_rms <= tx_rms
+    assert v_nrm <= t_vit and l_nrm <= t_logits
     assert int(res.logits_last.argmax()) == int(ref[0, 0].argmax())
 
 
@@ -299,3 +302,24 @@ def test_c5_size_batch_properties(ops):
         assert torch.equal(logits[i], logits[i % 2])
     one = eng.prefill(ids, tiles)
     assert torch.equal(one.logits_last, logits[0])
+
+
+def test_graph_captured_encode_is_bit_identical(ops):
+    """BASELINE config 5's "hipGraph-captured encode": vision tower + projector replayed from a HIP graph per ViT-input count
+    == the eager launches, bit for bit, for two different counts and fresh pixel data on every replay."""
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    g = torch.Generator().manual_seed(5)
+    for n in (3, 7, 3):
+        tiles = torch.randint(0, 256, (n, 364, 364, 3), generator=g, dtype=torch.uint8).to(DEV)
+        eng.graph_encode = False
+        want = eng.encode_images(tiles).clone()
+        eng.graph_encode = True
+        got = eng.encode_images(tiles)
+        assert torch.equal(got, want)
+    assert sorted(eng._encode_graphs) == [3, 7]
+    u8, ids, _ = sample_inputs(cfg, 1, 800, 500)
+    a = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV)).logits_last.clone()
+    eng.graph_encode = False
+    b = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV)).logits_last
+    assert torch.equal(a, b)
