@@ -4,17 +4,22 @@
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
 
 A "step" is one pass of the hot path over one synthetic sample of BASELINE config C3 — 6 images of 1344x896 ->
-adaptive tiler -> 42 ViT inputs (364x364) -> SigLIP-SO400M (27 layers) -> pixel-shuffle + projector -> 7098
+adaptive tiler (on the GPU) -> 42 ViT inputs (364x364) -> SigLIP-SO400M (27 layers) -> pixel-shuffle + projector -> 7098
 visual tokens merged into a 7187-token sequence -> Llama-3.1-8B prefill (32 layers, KV cache written) ->
-last-position logits.  Inputs (u8 tiles, token ids) are resident in HBM when the timed region starts; weights are
-seeded synthetic values of the real architecture (no checkpoints exist offline).
+last-position logits ("tiler -> logits of last position").  The source pixels (u8 HWC) and the token ids
+are resident in HBM / on the host when the timed region starts; weights are seeded synthetic values of the real
+architecture (no checkpoints exist offline).  `ms_per_step_excl_tiler` times the same step from ready-made tiles.
 
-Multi-GPU: the path shards by SAMPLE exactly as the reference does (run_eval_llava_siglip_multiimg.sh:9-11, one
-process per GPU over dataset shards, no collective on the data path): every rank prefills its own sample, so
-per-GPU work is fixed ("weak" scaling) and the job value is ranks x images / max-over-ranks time.
+Multi-GPU (`--gpus N`, one rank per GPU): the headline shards by SAMPLE exactly as the reference does
+(run_eval_llava_siglip_multiimg.sh:9-11, one process per GPU over dataset shards, no collective on the data path): every
+rank prefills its own sample, per-GPU work is fixed ("weak" scaling), value = ranks x images / max-over-ranks time.  The
+same line also carries `"tp"`: ONE sample per step on all ranks (tile-sharded ViT + all-gather, sequence-parallel
+tensor-parallel LLM over RCCL; strong scaling), measured after the headline under a watchdog; `--parallelism tp` makes
+it the headline.  `backend`, `rccl_ranks` and `comm_bytes_per_step` say what carried the ranks.
 
-One JSON line on rank 0:  metric/value/unit + roofline (dominant kernel = the MFMA GEMM family, HIP-event timed on
-the launch stream) + cpu_baseline (the CPU oracle timed on the host cores on a bounded sample).
+One JSON line on rank 0:  metric/value/unit + roofline (dominant kernel = the MFMA GEMM family incl. its fused norm / RoPE
+epilogues, HIP-event timed on the launch stream; `dominant` = the single largest shape) + cpu_baseline (the CPU oracle's
+end-to-end C1 prefill on the host cores, plus the C3 figure extrapolated from a bounded sample).
 """
 from __future__ import annotations
 
@@ -83,7 +88,7 @@ class GemmTimer:
             e0.record(torch.cuda.current_stream())
             r = inner(a, w, out, *args, **kw)
             e1.record(torch.cuda.current_stream())
-            timer.records.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1))
+            timer.records.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1, (M, w.shape[0], w.shape[1])))
             timer.bytes += (M + w.shape[0]) * w.shape[1] * w.element_size() + out.numel() * out.element_size()
             return r
         ops.gemm = gemm
@@ -96,7 +101,7 @@ class GemmTimer:
                 e0.record(torch.cuda.current_stream())
                 r = fn(a, w, out, *args, **kw)
                 e1.record(torch.cuda.current_stream())
-                timer.records.append((2.0 * a.shape[0] * w.shape[0] * w.shape[1], e0, e1))
+                timer.records.append((2.0 * a.shape[0] * w.shape[0] * w.shape[1], e0, e1, (a.shape[0], w.shape[0], w.shape[1])))
                 timer.bytes += (a.shape[0] + w.shape[0]) * w.shape[1] * w.element_size() + out.numel() * out.element_size()
                 return r
             return call
@@ -111,6 +116,17 @@ class GemmTimer:
         flops = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         return flops, ms, len(self.records)
+
+    def dominant(self):
+        """The (M, N, K) shape with the largest total time: launches, average ms, TFLOP/s."""
+        by = {}
+        for fl, e0, e1, shape in self.records:
+            t = by.setdefault(shape, [0, 0.0, fl])
+            t[0] += 1
+            t[1] += e0.elapsed_time(e1)
+        shape, (n, ms, fl) = max(by.items(), key=lambda kv: kv[1][1])
+        return {"shape_MNK": list(shape), "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(fl / (ms / n * 1e-3) / 1e12, 1),
+                "frac": round(fl / (ms / n * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
 
 
 def kernel_source_hash() -> str:
@@ -518,6 +534,7 @@ def main():
                 ctxs[0].cache.length = 0
                 eng.prefill(ctxs[0].ids, ctxs[0].tiles, cache=ctxs[0].cache)
         gflops, gms, n = timer.summary()
+        dominant = timer.dominant()
         timer.unwrap(ops, inner)
         per_launch_flops = gflops / n
         avg_ms = gms / n
@@ -533,11 +550,11 @@ def main():
                 traffic, traffic_note = round(tj["hbm_bytes_per_launch"]), "profiles/gemm_hbm_traffic.json: " + tj["method"]
             else:
                 traffic_note = f"profiles/gemm_hbm_traffic.json is stale (measured on kernel sources {tj.get('kernel_source_hash')}); refused"
-        out["roofline"] = {"bound": "mfma", "kernel": "lmi::gemm_kernel (all epilogues)", "achieved": round(achieved, 1),
+        out["roofline"] = {"bound": "mfma", "kernel": "lmi::gemm_kernel / gemm_stagger_kernel (all epilogues, incl. the fused RMSNorm / RoPE / KV-append ones)", "achieved": round(achieved, 1),
                            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": traffic_note,
                            "algorithmic_bytes_per_launch": round(timer.bytes / n),
-                           "kernel_source_hash": kernel_source_hash(),
+                           "kernel_source_hash": kernel_source_hash(), "dominant": dominant,
                            "launches_per_step": n // min(args.steps, 2),
                            "avg_launch_ms": round(avg_ms, 4), "gemm_ms_per_step": round(gms / min(args.steps, 2), 2)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
