@@ -140,6 +140,16 @@ int lmi_rmsnorm_rope(const void* A, const void* Wqkv, void* qkv, const float* ro
                      const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads,
                      int head_dim, int K, int lda, int ldw, int ldo, int dtype, void* stream);
 
+/* fp8 MFMA linears (BASELINE config 5: "fp8 MFMA ViT+LLM prefill").  Operands are OCP fp8 e4m3fn bytes (gfx950's format), [M, K]
+ * and [N, K] row-major, K % 128 == 0; the product runs on v_mfma_scale_f32_32x32x64_f8f6f4 (the fp8 path above the 16-bit MFMA
+ * rate on gfx950) with fp32 accumulation and comes out multiplied by 2^scale_exp — the inverse of the power-of-two scales the two
+ * operands were quantised with.  Epilogues as lmi_gemm (STORE [+GELU-tanh], RESIDUAL, STORE_F32, SWIGLU); out_dtype (LMI_F16 /
+ * LMI_BF16) is the type of the 16-bit outputs.  lmi_quantize_fp8 is the hand-over of an activation (fp32 / 16-bit [M, D]) to such
+ * an operand: out = fp8(x * scale), round to nearest even, saturating at +-448. */
+int lmi_quantize_fp8(const void* x, int x_dtype, void* out, int M, int D, int ldx, int ldo, float scale, void* stream);
+int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
+                 int scale_exp, int out_dtype, void* stream);
+
 /* Variable-length FlashAttention-2 forward over packed sequences (SigLIP: non-causal, head_dim 72, one
  * sequence per tile; Llama / Mistral: causal GQA, head_dim 128, optional sliding window; Idefics2 perceiver: head_dim 96,
  * len_q != len_k) — replaces the attention inside self.vision_tower(...)

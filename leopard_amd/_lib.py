@@ -33,6 +33,8 @@ SIGNATURES = {
     "lmi_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_gemm_ex": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _P, _P, _I, _I, _P],
     "lmi_rmsnorm_rope": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_quantize_fp8": [_P, _I, _P, _I, _I, _I, _I, _F, _P],
+    "lmi_gemm_fp8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_attn_varlen_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
     "lmi_rope_qk": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     "lmi_rope_qk_at": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],

@@ -127,6 +127,50 @@ int launch_gemm(const GemmArgs& a, void* stream) {
     }
 }
 
+// ---- fp8 operands (lmi_gemm_fp8): the production geometries only ---------------------------------------------------------------
+template <typename T, int EPI, int ACT, typename C>
+int launch_gemm_fp8_ring(const GemmArgs& a, void* stream) {
+    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    static std::atomic<uint64_t> attr_done{0};
+    allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE_PLAIN, C, fp8_t>, C::SMEM_TOTAL, attr_done);
+    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE_PLAIN, C, fp8_t>), dim3(tiles), dim3(C::NT), C::SMEM_TOTAL, stream, a);
+    return check_launch("lmi_gemm_fp8");
+}
+template <typename T, int EPI, int ACT>
+int launch_gemm_fp8(const GemmArgs& a, void* stream) {
+    switch (choose_gemm_cfg(a)) {
+        case 2: case 3: case 4: return launch_gemm_fp8_ring<T, EPI, ACT, Cfg2>(a, stream);
+        case 5: case 6: case 7: case 1: {
+            const int tiles = ((a.M + Cfg1::BM - 1) / Cfg1::BM) * ((a.N + Cfg1::BN - 1) / Cfg1::BN);
+            static std::atomic<uint64_t> attr_done{0};
+            allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE_PLAIN, Cfg1, 0, fp8_t>, Cfg1::SMEM_TOTAL, attr_done);
+            LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE_PLAIN, Cfg1, 0, fp8_t>), dim3(tiles), dim3(Cfg1::NT), Cfg1::SMEM_TOTAL, stream, a);
+            return check_launch("lmi_gemm_fp8");
+        }
+        case 8: case 9: return launch_gemm_fp8_ring<T, EPI, ACT, CfgS>(a, stream);
+        default: return launch_gemm_fp8_ring<T, EPI, ACT, Cfg0>(a, stream);
+    }
+}
+template <typename T>
+int dispatch_gemm_fp8(const GemmArgs& a, int epi, int act, void* stream) {
+    switch (epi) {
+        case LMI_EPI_STORE:
+            if (act == LMI_ACT_NONE) return launch_gemm_fp8<T, EPI_STORE_T, ACT_NONE>(a, stream);
+            if (act == LMI_ACT_GELU_TANH) return launch_gemm_fp8<T, EPI_STORE_T, ACT_GELU_TANH>(a, stream);
+            break;
+        case LMI_EPI_RESIDUAL:
+            if (act == LMI_ACT_NONE) return launch_gemm_fp8<T, EPI_RESID_F32, ACT_NONE>(a, stream);
+            break;
+        case LMI_EPI_STORE_F32:
+            if (act == LMI_ACT_NONE) return launch_gemm_fp8<T, EPI_STORE_F32, ACT_NONE>(a, stream);
+            break;
+        case LMI_EPI_SWIGLU:
+            if (act == LMI_ACT_NONE) return launch_gemm_fp8<T, EPI_SWIGLU_T, ACT_NONE>(a, stream);
+            break;
+    }
+    return fail(LMI_EINVAL, "lmi_gemm_fp8: unsupported epilogue/act combination (%d, %d)", epi, act);
+}
+
 template <typename T>
 int dispatch_gemm(const GemmArgs& a, int epi, int act, int amode, void* stream) {
     if (amode == LMI_A_PIXEL_SHUFFLE) {
@@ -453,6 +497,7 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     a.rowsq_in = x.rowsq_in; a.rowsq_parts = x.rowsq_parts; a.norm_dim = x.norm_dim; a.norm_eps = x.norm_eps;
     a.rope_cos = x.rope_cos; a.rope_sin = x.rope_sin; a.k_cache = x.k_cache; a.v_cache = x.v_cache;
     a.ld_cache = x.ld_cache; a.cache_pos0 = x.cache_pos0; a.rope_q = x.rope_q; a.rope_k = x.rope_k;
+    a.scale_e8m0 = 0x7f7f7f7f;
     // extents for the buffer resources the LDS-DMA reads through (32-bit offsets)
     const long a_rows = (a_mode == LMI_A_PIXEL_SHUFFLE) ? (long)(M / ((ps_grid / 2) * (ps_grid / 2))) * ps_grid * ps_grid : (long)M;
     const long a_cols = (a_mode == LMI_A_PIXEL_SHUFFLE) ? K / 4 : K;
@@ -513,6 +558,40 @@ int lmi_rmsnorm_rope(const void* A, const void* Wqkv, void* qkv, const float* ro
     const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
     return gemm_entry("lmi_rmsnorm_rope", A, Wqkv, qkv, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldw, ldo, 0, LMI_EPI_QKV_ROPE, LMI_ACT_NONE,
                       LMI_A_PLAIN, 0, dtype, stream, x);
+}
+
+int lmi_quantize_fp8(const void* x, int x_dtype, void* out, int M, int D, int ldx, int ldo, float scale, void* stream) {
+    if (!x || !out || M < 0 || D <= 0 || (D & 7) || (ldx & 7) || (ldo & 15) || !aligned16(x) || !aligned16(out))
+        return fail(LMI_EINVAL, "lmi_quantize_fp8: bad argument (M=%d D=%d ldx=%d ldo=%d; D %% 8 == 0, ldx %% 8 == 0, ldo %% 16 == 0)", M, D, ldx, ldo);
+    if (M == 0) return LMI_OK;
+    const int grid = grid_for((long)M * (D >> 3), 256);
+    uint8_t* o = (uint8_t*)out;
+    if (x_dtype == LMI_F32) LMI_LAUNCH((quantize_fp8_kernel<float>), dim3(grid), dim3(256), 0, stream, (const float*)x, o, M, D, ldx, ldo, scale);
+    else if (x_dtype == LMI_F16) LMI_LAUNCH((quantize_fp8_kernel<f16_t>), dim3(grid), dim3(256), 0, stream, (const f16_t*)x, o, M, D, ldx, ldo, scale);
+    else if (x_dtype == LMI_BF16) LMI_LAUNCH((quantize_fp8_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, o, M, D, ldx, ldo, scale);
+    else return fail(LMI_EINVAL, "lmi_quantize_fp8: x_dtype must be LMI_F32, LMI_F16 or LMI_BF16");
+    return check_launch("lmi_quantize_fp8");
+}
+
+int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
+                 int scale_exp, int out_dtype, void* stream) {
+    if (!A || !W || !out) return fail(LMI_EINVAL, "lmi_gemm_fp8: null pointer");
+    if (M < 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128))
+        return fail(LMI_EINVAL, "lmi_gemm_fp8: need N %% 128 == 0 and K %% 128 == 0 (M=%d N=%d K=%d)", M, N, K);
+    if ((lda & 15) || (ldw & 15) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out) || (bias && !aligned16(bias)))
+        return fail(LMI_EINVAL, "lmi_gemm_fp8: pointers must be 16-byte aligned, lda/ldw multiples of 16, ldo of 4");
+    if (scale_exp < -120 || scale_exp > 120) return fail(LMI_EINVAL, "lmi_gemm_fp8: scale_exp out of range");
+    if (M == 0) return LMI_OK;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.W = W; a.out = out; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
+    const int e = 127 + scale_exp;
+    a.scale_e8m0 = e | (e << 8) | (e << 16) | (e << 24);
+    const long a_bytes = ((long)(M - 1) * lda + K), w_bytes = ((long)(N - 1) * ldw + K);
+    if (a_bytes >= (1L << 32) || w_bytes >= (1L << 32)) return fail(LMI_EINVAL, "lmi_gemm_fp8: operand extent >= 4 GiB");
+    a.a_bytes = (unsigned)a_bytes; a.w_bytes = (unsigned)w_bytes;
+    LMI_DISPATCH_T(out_dtype, dispatch_gemm_fp8<f16_t>(a, epilogue, act, stream), dispatch_gemm_fp8<bf16_t>(a, epilogue, act, stream));
 }
 
 int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,

@@ -444,6 +444,24 @@ __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void*
 }
 
 // ------------------------------------------------------------------------------------------------
+// lmi_quantize_fp8: out[m, d] = fp8_e4m3(x[m, d] * scale) — the hand-over of an activation to an fp8 GEMM operand (static
+// per-tensor power-of-two scale).  8 elements per lane per step (32 / 16 bytes in, 8 bytes out); HBM-bound.
+// ------------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ void __launch_bounds__(256) quantize_fp8_kernel(const TIN* x, uint8_t* out, int M, int D, int ldx, int ldo, float scale) {
+    const int cpr = D >> 3;                                        // 8-element chunks per row
+    const long total = (long)M * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / cpr), c = (int)(i - (long)m * cpr);
+        const TIN* src = x + (long)m * ldx + c * 8;
+        u8x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = to_fp8((float)src[e] * scale);
+        *(u8x8*)(out + (long)m * ldo + c * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // lmi_lm_head_last: logits of a few selected rows of the fp32 residual stream (the last position of every packed sequence
 // in prefill, EVAL:333 restricted to what generate() consumes; the single row of a decode step).  The final RMSNorm is
 // applied in the launch and the normalised row STAYS fp32 — it is never rounded to the 16-bit compute type — so the head

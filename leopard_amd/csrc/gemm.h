@@ -74,6 +74,9 @@ struct GemmArgs {
     void* k_cache;
     void* v_cache;
     int ld_cache, cache_pos0, rope_q, rope_k;
+    // ---- fp8 operands (lmi_gemm_fp8): the accumulators come out multiplied by 2^(scale_e8m0 - 127) (E8M0 block scale of the MFMA,
+    // every byte the same), which undoes the power-of-two scales the operands were quantised with
+    int scale_e8m0;
 };
 
 constexpr int GEMM_BK = 64;
@@ -117,6 +120,26 @@ LMI_DEV float act_apply(float x, int act) {
 
 // byte offset of logical 16-byte chunk `lc` of row `r` inside a [rows][64] 16-bit tile (128-byte rows)
 LMI_DEV int gemm_lds_off(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); }
+
+// MFMA operand fragment of one lane for one k-step, per operand element type TA.  16-bit: 8 elements (16 bytes) of a 16-deep
+// k-step, 4 k-steps per 128-byte k-tile row, v_mfma_f32_32x32x16.  fp8: 32 elements (32 bytes = two swizzled 16-byte chunks) of a
+// 64-deep k-step, 2 k-steps per k-tile (128 k-elements), v_mfma_scale_f32_32x32x64_f8f6f4 — the same LDS image and DMA staging,
+// twice the K per tile at twice the MFMA rate.
+template <typename TA> struct GemmFrag { typedef typename vec_of<TA>::x8 type; static constexpr int KS = 4; };
+template <> struct GemmFrag<fp8_t> { typedef v8i type; static constexpr int KS = 2; };
+template <typename TA>
+LMI_DEV typename GemmFrag<TA>::type gemm_frag_load(const char* tile, int row, int ks, int fh) {
+    if constexpr (sizeof(TA) == 1) {
+        const int c0 = ks * 4 + fh * 2;
+        const u32x4 lo = *(const u32x4*)(tile + gemm_lds_off(row, c0)), hi = *(const u32x4*)(tile + gemm_lds_off(row, c0 + 1));
+        return v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    } else {
+        return *(const typename GemmFrag<TA>::type*)(tile + gemm_lds_off(row, ks * 2 + fh));
+    }
+}
+LMI_DEV f32x16 gemm_mma(f16x8 a, f16x8 b, f32x16 c, int) { return mfma32(a, b, c); }
+LMI_DEV f32x16 gemm_mma(bf16x8 a, bf16x8 b, f32x16 c, int) { return mfma32(a, b, c); }
+LMI_DEV f32x16 gemm_mma(v8i a, v8i b, f32x16 c, int scale_e8m0) { return mfma32_fp8(a, b, c, scale_e8m0); }
 
 // XCD-aware, grouped tile order.  Tiles are linearised in groups of `group_m` row-tiles, row-tile fastest, so that 32
 // consecutive ids form a (group_m x 32/group_m)-tile patch whose current k-tiles one XCD's 4 MiB L2 can hold.  Workgroup b runs on XCD
@@ -411,7 +434,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
 // and swizzled on the source side; loop-invariant 32-bit lane offsets, the k-tile advances a scalar offset.  Tail rows
 // are clamped to the last valid row (their products are masked on store).  In pixel-shuffle mode logical A row m is the
 // 2x2 neighbourhood of ViT tokens of shuffled token m, its K axis the four (dh, dw) segments of C channels.
-template <int AMODE, typename C>
+template <int AMODE, typename C, int ES = 2>          // ES = bytes per operand element (2: f16 / bf16, 1: fp8)
 struct GemmStager {
     BufRsrc a_buf, w_buf;
     unsigned a_src[C::A_PASSES], w_src[C::W_PASSES];
@@ -437,13 +460,13 @@ struct GemmStager {
             } else {
                 arow = am;
             }
-            a_src[ps] = (unsigned)((arow * p.lda + lc * 8) * 2);
+            a_src[ps] = (unsigned)(arow * p.lda * ES + lc * 16);
         }
 #pragma unroll
         for (int ps = 0; ps < C::W_PASSES; ++ps) {
             const int r = ps * C::ROWS_PER_PASS + srow;
             const int lc = pc ^ ((r >> 1) & 7);
-            w_src[ps] = (unsigned)(((long)imin(n0 + r, p.N - 1) * p.ldw + lc * 8) * 2);
+            w_src[ps] = (unsigned)((long)imin(n0 + r, p.N - 1) * p.ldw * ES + lc * 16);
         }
         ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;    // channels per shuffle segment
         ps_grid = p.ps_grid;
@@ -454,16 +477,16 @@ struct GemmStager {
     LMI_DEV void issue(int g, int kt, int slot) const {
         char* base = wave_base + slot * C::STAGE_BYTES;
         if (g < C::A_PASSES) {
-            unsigned a_off = (unsigned)kt * (GEMM_BK * 2);
+            unsigned a_off = (unsigned)kt * 128u;                    // one k-tile = 128 bytes of every row
             if (AMODE == AMODE_PIXSHUF) {
-                const int k0 = kt * GEMM_BK;
+                const int k0 = kt * (128 / ES);
                 const int seg = k0 / ps_c;                           // 0..3 = (dh, dw)
-                a_off = (unsigned)((((seg >> 1) * ps_grid + (seg & 1)) * lda + (k0 - seg * ps_c)) * 2);
+                a_off = (unsigned)((((seg >> 1) * ps_grid + (seg & 1)) * lda + (k0 - seg * ps_c)) * ES);
             }
             glds16_buf(a_buf, a_src[g], a_off, base + g * (C::ROWS_PER_PASS * 128));
         } else {
             const int gw = g - C::A_PASSES;
-            glds16_buf(w_buf, w_src[gw], (unsigned)kt * (GEMM_BK * 2), base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
+            glds16_buf(w_buf, w_src[gw], (unsigned)kt * 128u, base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
         }
     }
 };
@@ -483,10 +506,10 @@ LMI_DEV void gemm_put32(const f32x16 (&acc)[C::NI][C::MI], int mi, int lane, cha
             *(f32x4*)(stage + fr * RS + (ni * 32 + q * 8 + fh * 4) * 4) = v;
         }
 }
-template <typename T, int EPI, int ACT, int AMODE, typename C>
+template <typename T, int EPI, int ACT, int AMODE, typename C, typename TA = T>
 __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
-    typedef typename vec_of<T>::x8 T8;
-    typedef typename vec_of<T>::x4 T4;
+    typedef typename GemmFrag<TA>::type Frag;
+    constexpr int KS = GemmFrag<TA>::KS, ES = (int)sizeof(TA);
     LMI_DYN_SMEM(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = wave_id();
@@ -496,7 +519,7 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     if (!gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn)) return;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
-    GemmStager<AMODE, C> stager;
+    GemmStager<AMODE, C, ES> stager;
     stager.init(p, m0, n0, tid, smem, wave);
     auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
     float* rstd_lds = (float*)(smem + C::SMEM);
@@ -513,7 +536,7 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    const int nt = p.K / GEMM_BK;
+    const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
 
     // ---- prologue: D tiles in flight -----------------------------------------------------------------------------
 #pragma unroll
@@ -534,20 +557,20 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
         const bool do_issue = t_issue < nt;
         const int slot_issue = t_issue % C::STAGES;                  // == slot of tile t-1: free since the barrier
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            T8 af[C::MI], wf[C::NI];
+        for (int ks = 0; ks < KS; ++ks) {
+            Frag af[C::MI], wf[C::NI];
 #pragma unroll
-            for (int i = 0; i < C::MI; ++i) af[i] = *(const T8*)(a_t + gemm_lds_off(wm * C::WTM + i * 32 + fr, ks * 2 + fh));
+            for (int i = 0; i < C::MI; ++i) af[i] = gemm_frag_load<TA>(a_t, wm * C::WTM + i * 32 + fr, ks, fh);
 #pragma unroll
-            for (int i = 0; i < C::NI; ++i) wf[i] = *(const T8*)(w_t + gemm_lds_off(wn * C::WTN + i * 32 + fr, ks * 2 + fh));
+            for (int i = 0; i < C::NI; ++i) wf[i] = gemm_frag_load<TA>(w_t, wn * C::WTN + i * 32 + fr, ks, fh);
             if (do_issue) {
 #pragma unroll
-                for (int g = ks * C::G / 4; g < (ks + 1) * C::G / 4; ++g) issue_piece(g, t_issue, slot_issue);
+                for (int g = ks * C::G / KS; g < (ks + 1) * C::G / KS; ++g) issue_piece(g, t_issue, slot_issue);
             }
 #pragma unroll
             for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < C::MI; ++mi) acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
+                for (int mi = 0; mi < C::MI; ++mi) acc[ni][mi] = gemm_mma(wf[ni], af[mi], acc[ni][mi], p.scale_e8m0);
         }
     }
 
@@ -571,10 +594,13 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 // VAR 0 = as described (production); 1 = without s_setprio; 2 = the LDS-DMA pieces ride between the MFMAs of k-steps 0 / 1
 // instead (1-2 % faster in isolated bursts of one GEMM, 2.4 % slower over the power-capped prefill step).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR>
+template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR, typename TA = T>
 __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     static_assert(C::STAGES == 2 && C::NT == 512, "staggered schedule: 8 waves, 2-slot ring");
-    typedef typename vec_of<T>::x8 T8;
+    typedef typename GemmFrag<TA>::type Frag;
+    // fp8: 2 k-steps of 64 per k-tile (8 MFMAs of 64 cycles each per MFMA segment); all DMA pieces of the next tile go out in
+    // k-step 0's LOAD segment and are drained in k-step 1's: one MFMA segment of flight, as the 16-bit schedule has two of half the length
+    constexpr int KS = GemmFrag<TA>::KS, ES = (int)sizeof(TA), KS_ISSUE = KS / 2;
     LMI_DYN_SMEM(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = wave_id();
@@ -585,7 +611,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     if (!gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn)) return;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
-    GemmStager<AMODE, C> stager;
+    GemmStager<AMODE, C, ES> stager;
     stager.init(p, m0, n0, tid, smem, wave);
     auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
     float* rstd_lds = (float*)(smem + C::SMEM);
@@ -602,7 +628,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    const int nt = p.K / GEMM_BK;
+    const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
 #pragma unroll
     for (int g = 0; g < C::G; ++g) issue_piece(g, 0, 0);
     wait_vmcnt_barrier<0>();
@@ -621,20 +647,20 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
         const char* a_t = smem + (t & 1) * C::STAGE_BYTES;
         const char* w_t = a_t + C::A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             // ---- LOAD segment ---------------------------------------------------------------------------------
-            T8 af[C::MI], wf[C::NI];
+            Frag af[C::MI], wf[C::NI];
 #pragma unroll
             for (int i = 0; i < C::MI; ++i)
-                if (FULL || i < nmi) af[i] = *(const T8*)(a_t + gemm_lds_off(wm * C::WTM + i * 32 + fr, ks * 2 + fh));
+                if (FULL || i < nmi) af[i] = gemm_frag_load<TA>(a_t, wm * C::WTM + i * 32 + fr, ks, fh);
 #pragma unroll
             for (int i = 0; i < C::NI; ++i)
-                if (FULL || nmi > 0) wf[i] = *(const T8*)(w_t + gemm_lds_off(wn * C::WTN + i * 32 + fr, ks * 2 + fh));
-            if (VAR < 2 && ks < 2 && ISSUE) {
+                if (FULL || nmi > 0) wf[i] = gemm_frag_load<TA>(w_t, wn * C::WTN + i * 32 + fr, ks, fh);
+            if (VAR < 2 && ks < KS_ISSUE && ISSUE) {
 #pragma unroll
-                for (int g = ks * C::G / 2; g < (ks + 1) * C::G / 2; ++g) issue_piece(g, t + 1, (t + 1) & 1);
+                for (int g = ks * C::G / KS_ISSUE; g < (ks + 1) * C::G / KS_ISSUE; ++g) issue_piece(g, t + 1, (t + 1) & 1);
             }
-            if (ks == 3) wait_vmcnt_barrier<0>(); else raw_barrier();
+            if (ks == KS - 1) wait_vmcnt_barrier<0>(); else raw_barrier();
             // ---- MFMA segment ---------------------------------------------------------------------------------
             sched_fence();
             if (VAR == 0) setprio_hi();
@@ -642,10 +668,10 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
             for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < C::MI; ++mi) {
-                    if (FULL || mi < nmi) acc[ni][mi] = mfma32(wf[ni], af[mi], acc[ni][mi]);
+                    if (FULL || mi < nmi) acc[ni][mi] = gemm_mma(wf[ni], af[mi], acc[ni][mi], p.scale_e8m0);
                     // the LDS-DMA pieces of tile t+1 ride in the issue slots between the MFMAs of k-steps 0, 1
-                    const int idx = ni * C::MI + mi, g = ks * (C::G / 2) + (idx >> 1);    // compile-time after unrolling
-                    if (DMA_IN_MFMA && ISSUE && ks < 2 && (idx & 1) && (idx >> 1) < C::G / 2) issue_piece(g, t + 1, (t + 1) & 1);
+                    const int idx = ni * C::MI + mi, g = ks * (C::G / KS_ISSUE) + (idx >> 1);    // compile-time after unrolling
+                    if (DMA_IN_MFMA && ISSUE && ks < KS_ISSUE && (idx & 1) && (idx >> 1) < C::G / KS_ISSUE) issue_piece(g, t + 1, (t + 1) & 1);
                 }
             if (VAR == 0) setprio_lo();
             sched_fence();

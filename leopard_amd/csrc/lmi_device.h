@@ -33,6 +33,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// OCP fp8 e4m3fn storage (gfx950's fp8 MFMA format; NOT the MI300 fnuz encoding): operand type of the fp8 GEMM path
+struct fp8_t { uint8_t v; };
+typedef uint8_t u8x8 __attribute__((ext_vector_type(8)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+
 template <typename T> struct vec_of;
 template <> struct vec_of<f16_t> { typedef f16x8 x8; typedef f16x4 x4; typedef f16x2 x2; };
 template <> struct vec_of<bf16_t> { typedef bf16x8 x8; typedef bf16x4 x4; typedef bf16x2 x2; };
@@ -71,6 +76,19 @@ LMI_DEV BufRsrc make_buf(const void* base, unsigned num_records) {
 LMI_DEV void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset,
                                              (int)soffset, 0, 0);
+}
+
+// D[32x32] += A[32x64] * B[64x32] on fp8 e4m3 operands at twice the 16-bit MFMA rate (v_mfma_scale_f32_32x32x64_f8f6f4; the
+// unscaled fp8 MFMA runs at the 16-bit rate).  Lane l supplies A[l&31][32*(l>>5) + j] and B[32*(l>>5) + j][l&31], j = 0..31
+// (32 bytes; layout measured with tools/ubench/mfma_fp8_layout.hip), receives D as mfma32.  The E8M0 block scales are used as
+// ONE power-of-two factor for the whole product: A's scale is 127 (2^0), B's is `scale_b` in every byte (127 + e -> x 2^e).
+LMI_DEV f32x16 mfma32_fp8(v8i a, v8i b, f32x16 c, int scale_b) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, scale_b);
+}
+// fp32 -> fp8 e4m3fn, round to nearest even, saturating at +-448
+LMI_DEV uint8_t to_fp8(float x) {
+    x = fminf(fmaxf(x, -448.0f), 448.0f);
+    return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff);
 }
 
 LMI_DEV void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -188,6 +206,46 @@ LMI_DEV float sub_rn(float a, float b) { float r = a - b; asm volatile("" : "+v"
 inline int lane_id() { return threadIdx.x & 63; }
 inline int wave_id() { return (int)(threadIdx.x >> 6); }
 template <int N> inline void wait_vmcnt_barrier() { __syncthreads(); }
+inline float emu_fp8_decode(uint8_t v) {
+    const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float f;
+    if (e == 0) f = ldexpf((float)m, -9);                        // subnormal: m * 2^-3 * 2^-6
+    else if (e == 15 && m == 7) f = NAN;                         // e4m3fn: the only NaN; no infinities
+    else f = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    return s ? -f : f;
+}
+inline uint8_t to_fp8(float x) {                                 // RNE, saturating at +-448 (same results as v_cvt_pk_fp8_f32 after the clamp)
+    x = fminf(fmaxf(x, -448.0f), 448.0f);
+    const uint8_t sign = __builtin_signbit(x) ? 0x80 : 0;
+    float a = fabsf(x);
+    if (a == 0) return sign;
+    int e;
+    (void)frexpf(a, &e);                                         // a = f * 2^e, f in [0.5, 1)
+    int E = e - 1;                                               // a = 1.xxx * 2^E
+    if (E < -6) E = -6;                                          // subnormal range: fixed scale 2^-6
+    const float q = nearbyintf(ldexpf(a, 3 - E));                // mantissa in units of 2^(E-3), ties to even
+    int mant = (int)q;
+    if (mant >= 16) { mant = 8; E += 1; }                        // rounded up to the next binade
+    if (mant < 8) return sign | (uint8_t)mant;                   // subnormal (E == -6 and mant < 8) or zero
+    return sign | (uint8_t)(((E + 7) << 3) | (mant - 8));
+}
+inline f32x16 mfma32_fp8(v8i a, v8i b, f32x16 c, int scale_b) {
+    struct Slot { uint8_t a[32], b[32]; };
+    Slot* s = (Slot*)hipemu::wave_buf();
+    const int l = lane_id();
+    __builtin_memcpy(s[l].a, &a, 32);
+    __builtin_memcpy(s[l].b, &b, 32);
+    hipemu::wave_sync();
+    const float sc = ldexpf(1.0f, (scale_b & 255) - 127);
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = 0.f;
+        for (int k = 0; k < 64; ++k) acc += emu_fp8_decode(s[row + 32 * (k >> 5)].a[k & 31]) * emu_fp8_decode(s[col + 32 * (k >> 5)].b[k & 31]);
+        c[r] += acc * sc;
+    }
+    hipemu::wave_sync();
+    return c;
+}
 inline void raw_barrier() { __syncthreads(); }
 inline void lds_write_drain() {}
 inline void wave_lds_fence() { hipemu::wave_sync(); }

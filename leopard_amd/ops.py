@@ -206,3 +206,19 @@ class Ops:
         self._check(self.lib.lmi_add_rmsnorm(_ptr(x), _ptr(delta), _DT[delta.dtype], _ptr(w), _ptr(out), M, D, x.stride(0), delta.stride(0),
                                              0 if out is None else out.stride(0), float(eps), dt, self._stream(x)))
         return out
+
+    def quantize_fp8(self, x, out, scale: float):
+        """out (uint8 view of fp8 e4m3fn, [M, D]) = fp8(x * scale); x fp32 / fp16 / bf16 [M, D]."""
+        M, D = x.shape
+        assert out.dtype in (torch.uint8, torch.float8_e4m3fn) and out.shape == x.shape
+        self._check(self.lib.lmi_quantize_fp8(_ptr(x), _DT[x.dtype], _ptr(out), M, D, x.stride(0), out.stride(0), float(scale), self._stream(x)))
+        return out
+
+    def gemm_fp8(self, a8, w8, out, bias=None, epilogue=EPI_STORE, act=ACT_NONE, scale_exp: int = 0):
+        """out = epilogue(2^scale_exp * (a8 @ w8.T)) on fp8 e4m3fn operands (uint8 / float8 tensors [M, K], [N, K])."""
+        N, K = w8.shape
+        M = a8.shape[0]
+        dt = _DT[out.dtype] if out.dtype in (torch.float16, torch.bfloat16) else LMI_F16
+        self._check(self.lib.lmi_gemm_fp8(_ptr(a8), _ptr(w8), _ptr(out), _ptr(bias), M, N, K, a8.stride(0), w8.stride(0), out.stride(0),
+                                          epilogue, act, int(scale_exp), dt, self._stream(out)))
+        return out

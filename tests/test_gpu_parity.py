@@ -325,3 +325,40 @@ def test_graph_captured_encode_is_bit_identical(ops):
     eng.graph_encode = False
     b = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV)).logits_last
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["text_only", "twenty_thumbnails", "one_token", "mixed_sizes"])
+def test_edge_case_samples_vs_oracle(ops, case):
+    """Edge cases of the reference's sample shapes on the device, vs the fp32 oracle (mid configuration):
+    text only (no image tokens, no ViT work); 20 small images (tile budget 50 - 20 spread thin: every image rounds to one
+    natural tile -> thumbnails only, N = 20, EVAL:26-58); a one-token prompt; one sample mixing a 336x336, a portrait and a
+    panorama image (ragged tile counts per image)."""
+    from PIL import Image
+    from leopard_amd.tiler import siglip_normalize, tile_sample, to_u8_tiles
+    from oracle import leopard_oracle as O
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    W = O.weights_from_numpy(synth_state_dict_numpy(cfg))
+    rng = np.random.default_rng(12)
+    if case in ("text_only", "one_token"):
+        ids = torch.from_numpy(rng.integers(0, 7000, (1, 1 if case == "one_token" else 37)))
+        res = eng.prefill(ids.to(DEV), None)
+        emb = torch.nn.functional.embedding(ids.reshape(-1), W["language_model.model.embed_tokens.weight"]).unsqueeze(0)
+        ref = O.llama_forward(emb, torch.arange(ids.shape[1]).unsqueeze(0), W, cfg, last_only=True)[0, 0]
+        assert res.seq_len == ids.shape[1] and res.n_tiles == 0
+    else:
+        sizes = [(300 + 7 * i, 280 + 5 * i) for i in range(20)] if case == "twenty_thumbnails" else [(336, 336), (500, 1400), (1900, 420)]
+        imgs = [Image.fromarray(synth_image_u8(60 + i, w, h)) for i, (w, h) in enumerate(sizes)]
+        vit_inputs, plan = tile_sample(imgs)
+        if case == "twenty_thumbnails":
+            assert plan.tiles_per_image == [0] * 20 and plan.n_vit_inputs == 20
+        else:
+            assert plan.tiles_per_image[0] == 0 and len(set(plan.tiles_per_image)) > 1
+        u8 = to_u8_tiles(vit_inputs)
+        ids = torch.from_numpy(synth_prompt_ids(plan.vit_inputs_per_image, cfg, seed=3)).reshape(1, -1)
+        res = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV))
+        ref = O.prefill_logits(ids, torch.from_numpy(siglip_normalize(u8)), W, cfg, last_only=True)[0, 0]
+        assert res.n_tiles == plan.n_vit_inputs
+    a, n, r = err_stats(res.logits_last.cpu(), ref)
+    print(f"[edge {case}] S={res.seq_len} normalised-max {n:.3e} rel-rms {r:.3e}")
+    assert n <= LOGIT_TOL[torch.float16] and int(res.logits_last.argmax()) == int(ref.argmax())

@@ -385,3 +385,70 @@ def test_rmsnorm_rope_qkv_s7187(ops, dtype, cfg, with_norm):
     finally:
         ops.set_option("gemm.config", -1)
         del w_rope
+
+
+# ---- fp8 linears (lmi_gemm_fp8 / lmi_quantize_fp8, BASELINE config 5) at the C3 shapes --------------------------------------
+F8 = torch.float8_e4m3fn
+
+
+def test_quantize_fp8_matches_torch_bit_for_bit_on_device(ops):
+    g = torch.Generator(device=DEV).manual_seed(95)
+    for dtype in (torch.float32, torch.float16, torch.bfloat16):
+        x = (torch.randn(7187, 4096, generator=g, device=DEV) * torch.logspace(-4, 3, 4096, device=DEV)[None, :]).to(dtype)
+        out = torch.zeros(7187, 4096, dtype=torch.uint8, device=DEV)
+        ops.quantize_fp8(x, out, 4.0)
+        want = (x.float() * 4.0).clamp(-448, 448).to(F8).view(torch.uint8)
+        same = (out == want) | (((out & 0x7F) == 0) & ((want & 0x7F) == 0))
+        assert bool(same.all())
+
+
+@pytest.mark.parametrize("out_dtype", DTYPES)
+@pytest.mark.parametrize("shape", [("qkv", 7187, 6144, 4096), ("o_proj", 7187, 4096, 4096), ("down", 7187, 4096, 14336), ("qkv_mid", 566, 6144, 4096),
+                                   ("vit_qkv", 28392, 3456, 1152), ("vit_out", 28392, 1152, 1152), ("vit_fc2", 28392, 1152, 4352)],
+                         ids=lambda s: s[0])
+def test_gemm_fp8_store_and_residual(ops, out_dtype, shape):
+    """fp8 x fp8 -> fp32 accumulate on every production geometry the chooser picks: products of fp8 values are exact in fp32, so the
+    only difference from the fp32 matmul of the dequantised operands is the summation order (and the output rounding)."""
+    _, M, N, K = shape
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a8 = torch.randn(M, K, generator=g, device=DEV).to(F8)
+    w8 = (torch.randn(N, K, generator=g, device=DEV) * 0.25).to(F8)
+    bias = torch.randn(N, generator=g, device=DEV)
+    ref = (a8.float() @ w8.float().T) * 2.0 ** -5
+    out = torch.full((M, N), float("nan"), dtype=out_dtype, device=DEV)
+
+    def store():
+        out.fill_(float("nan"))
+        ops.gemm_fp8(a8.view(torch.uint8), w8.view(torch.uint8), out, bias=bias, scale_exp=-5)
+        return out.clone()
+    o = run3(store)
+    e = rel_err(o, ref + bias)
+    assert e <= 3 * eps(out_dtype), f"fp8 STORE {shape}: {e:.3e}"
+    x0 = torch.randn(M, N, generator=g, device=DEV)
+    x = x0.clone()
+    ops.gemm_fp8(a8.view(torch.uint8), w8.view(torch.uint8), x, bias=bias, epilogue=_lib.EPI_RESIDUAL, scale_exp=-5)
+    assert (x - (x0 + ref + bias)).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("out_dtype", DTYPES)
+def test_gemm_fp8_swiglu_and_gelu(ops, out_dtype):
+    from leopard_amd.weights import interleave_gate_up
+    M, F, K = 7187, 14336, 4096
+    g = torch.Generator(device=DEV).manual_seed(96)
+    a8 = torch.randn(M, K, generator=g, device=DEV).to(F8)
+    w8 = (torch.randn(2 * F, K, generator=g, device=DEV) * 0.25).to(F8)
+    ref = (a8.float() @ w8.float().T) * 2.0 ** -6
+    want = torch.nn.functional.silu(ref[:, :F]) * ref[:, F:]
+    wi = interleave_gate_up(w8.view(torch.uint8)[:F], w8.view(torch.uint8)[F:])
+    out = torch.full((M, F), float("nan"), dtype=out_dtype, device=DEV)
+    ops.gemm_fp8(a8.view(torch.uint8), wi, out, epilogue=_lib.EPI_SWIGLU, scale_exp=-6)
+    assert rel_err(out, want) <= 3 * eps(out_dtype)
+    del ref, want, wi, w8, a8
+    M, N, K = 28392, 4352, 1152
+    a8 = torch.randn(M, K, generator=g, device=DEV).to(F8)
+    w8 = (torch.randn(N, K, generator=g, device=DEV) * 0.25).to(F8)
+    bias = torch.randn(N, generator=g, device=DEV)
+    ref = (a8.float() @ w8.float().T) * 2.0 ** -4 + bias
+    out = torch.full((M, N), float("nan"), dtype=out_dtype, device=DEV)
+    ops.gemm_fp8(a8.view(torch.uint8), w8.view(torch.uint8), out, bias=bias, act=_lib.ACT_GELU_TANH, scale_exp=-4)
+    assert rel_err(out, torch.nn.functional.gelu(ref, approximate="tanh")) <= 3 * eps(out_dtype)
