@@ -39,6 +39,7 @@ from leopard_amd.config import full_config  # noqa: E402
 from leopard_amd.synth import synth_image_u8, synth_prompt_ids  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_FP8_TFLOPS = 5000.0 # dense fp8 peak (same guide); only the --dtype fp8 line is priced against it
 HBM_PEAK_GBS = 8000.0
 
 
@@ -106,10 +107,29 @@ class GemmTimer:
                 return r
             return call
         ops.gemm_ex, ops.rmsnorm_rope = timed(ops.gemm_ex), timed(ops.rmsnorm_rope)
+        # --dtype fp8: the fp8 GEMMs are their own family (own records, priced against the fp8 peak)
+        self._inner_fp8 = ops.gemm_fp8
+        self.fp8_records, self.fp8_bytes = [], 0
+
+        def gemm_fp8(a, w, out, *args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            r = timer._inner_fp8(a, w, out, *args, **kw)
+            e1.record(torch.cuda.current_stream())
+            timer.fp8_records.append((2.0 * a.shape[0] * w.shape[0] * w.shape[1], e0, e1, (a.shape[0], w.shape[0], w.shape[1])))
+            timer.fp8_bytes += (a.shape[0] + w.shape[0]) * w.shape[1] + out.numel() * out.element_size()
+            return r
+        ops.gemm_fp8 = gemm_fp8
         return inner
 
     def unwrap(self, ops, inner):
-        ops.gemm, ops.gemm_ex, ops.rmsnorm_rope = inner, self._inner_ex, self._inner_rope
+        ops.gemm, ops.gemm_ex, ops.rmsnorm_rope, ops.gemm_fp8 = inner, self._inner_ex, self._inner_rope, self._inner_fp8
+
+    def use_fp8_family(self):
+        """Make the fp8 launches the family summary() / dominant() describe; returns (flops, ms, n) of the 16-bit launches left."""
+        rest = self.summary()
+        self.records, self.bytes = self.fp8_records, self.fp8_bytes
+        return rest
 
     def summary(self):
         torch.cuda.synchronize()
@@ -117,7 +137,7 @@ class GemmTimer:
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         return flops, ms, len(self.records)
 
-    def dominant(self):
+    def dominant(self, peak=MFMA_PEAK_TFLOPS):
         """The (M, N, K) shape with the largest total time: launches, average ms, TFLOP/s."""
         by = {}
         for fl, e0, e1, shape in self.records:
@@ -126,7 +146,7 @@ class GemmTimer:
             t[1] += e0.elapsed_time(e1)
         shape, (n, ms, fl) = max(by.items(), key=lambda kv: kv[1][1])
         return {"shape_MNK": list(shape), "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(fl / (ms / n * 1e-3) / 1e12, 1),
-                "frac": round(fl / (ms / n * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                "frac": round(fl / (ms / n * 1e-3) / 1e12 / peak, 4)}
 
 
 def kernel_source_hash() -> str:
@@ -201,6 +221,19 @@ def cpu_baseline_sample(cfg):
     return tflops, t
 
 
+FP8_DETAIL = ("fp8 e4m3fn operands (static power-of-two scales, fp32 accumulate) for the qkv / out / fc1 / fc2 linears of the 27 SigLIP "
+              "layers and the qkv / o / gate-up / down linears of the 32 Llama layers; f16 attention, patch embed, projector; fp32 "
+              "residual stream, norms and head")
+
+
+def enable_fp8(eng, cfg, args):
+    """Static activation scales from a 16-bit prefill of a DIFFERENT synthetic sample (other images, other prompt)."""
+    u8, ids_np, _, _, _ = make_sample(cfg, 2, args.width, args.height, seed=977)
+    eng.enable_fp8([(torch.from_numpy(ids_np).reshape(1, -1), torch.from_numpy(u8).to(eng.device))])
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
 def bench_c5(args, dev, dtype, rank, world, D):
     """BASELINE config 5 shape: a batch of 8 samples x 8 images of 1344x896 (40 ViT inputs and 6861 tokens per sample), all 8
     samples in ONE packed pass (LeopardEngine.prefill_batch), 16-bit compute (the fp8 variant of that config is not built)."""
@@ -222,6 +255,8 @@ def bench_c5(args, dev, dtype, rank, world, D):
         ids = torch.from_numpy(synth_prompt_ids(plan.vit_inputs_per_image, cfg, seed=rank * 16 + j)).reshape(1, -1)
         samples.append((ids, tiles))
     n_tiles = sum(t.shape[0] for _, t in samples)
+    if args.dtype == "fp8":
+        enable_fp8(eng, cfg, args)
 
     def barrier():
         torch.cuda.synchronize()
@@ -241,6 +276,7 @@ def bench_c5(args, dev, dtype, rank, world, D):
            "value": round(world * n_samples * n_img * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           **({"dtype_detail": FP8_DETAIL} if args.dtype == "fp8" else {}),
            "config": {"workload": f"C5 shape: {n_samples} samples x {n_img} x (1344x896) -> {n_tiles} ViT inputs, "
                                   f"{sum(seq_lens)} tokens packed in one varlen pass; SigLIP-SO400M + Llama-3.1-8B prefill to "
                                   "last-token logits; synthetic seeded weights", "parallelism": f"sample-sharded x{world}"},
@@ -364,7 +400,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16"])
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "fp8"],
+                    help="f16 (default, the BASELINE metric's precision) / bf16; fp8 = BASELINE configs[4]: e4m3 operands for the ViT / "
+                         "LLM layer linears over an f16 engine (llava-c3 / llava-c5 only) — a separate line, never the headline")
     ap.add_argument("--images", type=int, default=6)
     ap.add_argument("--width", type=int, default=1344)
     ap.add_argument("--height", type=int, default=896)
@@ -402,6 +440,8 @@ def main():
     from leopard_amd.ops import Ops
     from leopard_amd.weights import EngineWeights, SynthSource
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if args.dtype == "fp8" and (args.workload == "idefics2-c4" or args.parallelism == "tp"):
+        raise SystemExit("--dtype fp8 is built for the Leopard-LLaVA replica path (llava-c3 / llava-c5)")
     if args.workload == "idefics2-c4":
         return bench_idefics2(args, dev, dtype, rank, world, D)
     if args.workload == "llava-c5":
@@ -465,6 +505,8 @@ def main():
         c.stream = torch.cuda.Stream(device=dev) if args.inflight > 1 else torch.cuda.current_stream(dev)
         ctxs.append(c)
     n_tiles, S = ctxs[0].n_tiles, ctxs[0].S
+    if args.dtype == "fp8":
+        enable_fp8(eng, cfg, args)
 
     def step(with_tiler=True):
         """One pass of the hot path over one sample: tiler (a1-a5, on the GPU, from the resident source pixels) -> SigLIP ->
@@ -509,6 +551,8 @@ def main():
         "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
+        **({"dtype_detail": FP8_DETAIL, "prefill_mfma_frac_note": "algorithmic FLOPs / time against the 2.5 PF 16-bit peak (mixed-precision step)"}
+           if args.dtype == "fp8" else {}),
         "config": {"workload": f"C3: {args.images}x({args.width}x{args.height}) images -> {n_tiles} ViT inputs (364x364), "
                                f"{n_tiles * cfg.tokens_per_tile} visual tokens, S={S}; SigLIP-SO400M/14 (27L) + Llama-3.1-8B (32L) "
                                "prefill to last-token logits, KV cache written; synthetic seeded weights",
@@ -533,8 +577,12 @@ def main():
             with torch.cuda.stream(ctxs[0].stream):
                 ctxs[0].cache.length = 0
                 eng.prefill(ctxs[0].ids, ctxs[0].tiles, cache=ctxs[0].cache)
+        peak, family, rest = MFMA_PEAK_TFLOPS, "lmi::gemm_kernel / gemm_stagger_kernel (all epilogues, incl. the fused RMSNorm / RoPE / KV-append ones)", None
+        if args.dtype == "fp8":
+            rest = timer.use_fp8_family()
+            peak, family = MFMA_PEAK_FP8_TFLOPS, "lmi::gemm_kernel / gemm_stagger_kernel, fp8 e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4), all epilogues"
         gflops, gms, n = timer.summary()
-        dominant = timer.dominant()
+        dominant = timer.dominant(peak)
         timer.unwrap(ops, inner)
         per_launch_flops = gflops / n
         avg_ms = gms / n
@@ -550,13 +598,18 @@ def main():
                 traffic, traffic_note = round(tj["hbm_bytes_per_launch"]), "profiles/gemm_hbm_traffic.json: " + tj["method"]
             else:
                 traffic_note = f"profiles/gemm_hbm_traffic.json is stale (measured on kernel sources {tj.get('kernel_source_hash')}); refused"
-        out["roofline"] = {"bound": "mfma", "kernel": "lmi::gemm_kernel / gemm_stagger_kernel (all epilogues, incl. the fused RMSNorm / RoPE / KV-append ones)", "achieved": round(achieved, 1),
-                           "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+        if args.dtype == "fp8":
+            traffic, traffic_note = None, "the committed PMC summary describes the f16 step; not collected for the fp8 line"
+        out["roofline"] = {"bound": "mfma", "kernel": family, "achieved": round(achieved, 1),
+                           "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": traffic_note,
                            "algorithmic_bytes_per_launch": round(timer.bytes / n),
                            "kernel_source_hash": kernel_source_hash(), "dominant": dominant,
                            "launches_per_step": n // min(args.steps, 2),
                            "avg_launch_ms": round(avg_ms, 4), "gemm_ms_per_step": round(gms / min(args.steps, 2), 2)}
+        if rest is not None:
+            out["roofline"]["f16_gemms_left"] = {"launches_per_step": rest[2] // min(args.steps, 2), "ms_per_step": round(rest[1] / min(args.steps, 2), 2),
+                                                 "achieved": round(rest[0] / (rest[1] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tflops, t = cpu_baseline_sample(cfg)                   # doubles as the warm-up of the timed C1 runs
         del eng, W, ctxs

@@ -31,7 +31,7 @@ extern "C" {
 #define LMI_ELAUNCH (-2)  /* HIP launch error */
 #define LMI_ECOMM (-3)    /* RCCL unavailable or a collective failed */
 
-enum { LMI_F16 = 0, LMI_BF16 = 1, LMI_F32 = 2 };
+enum { LMI_F16 = 0, LMI_BF16 = 1, LMI_F32 = 2, LMI_FP8 = 3 /* OCP e4m3fn bytes; fp8 entry points only */ };
 
 /* epilogues of lmi_gemm */
 enum {
@@ -147,8 +147,13 @@ int lmi_rmsnorm_rope(const void* A, const void* Wqkv, void* qkv, const float* ro
  * LMI_BF16) is the type of the 16-bit outputs.  lmi_quantize_fp8 is the hand-over of an activation (fp32 / 16-bit [M, D]) to such
  * an operand: out = fp8(x * scale), round to nearest even, saturating at +-448. */
 int lmi_quantize_fp8(const void* x, int x_dtype, void* out, int M, int D, int ldx, int ldo, float scale, void* stream);
+/* out_dtype LMI_FP8 (STORE [+GELU-tanh] and SWIGLU only): the results are written as fp8(value * out_scale), ready to be the A operand
+ * of the next fp8 GEMM (SigLIP fc1 -> fc2, Llama gate/up -> down) without a separate quantisation pass. */
 int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
-                 int scale_exp, int out_dtype, void* stream);
+                 int scale_exp, int out_dtype, float out_scale, void* stream);
+/* LayerNorm (b != null) / RMSNorm (b == null) of the fp32 stream written straight as an fp8 GEMM operand: out = fp8(norm(x) * out_scale). */
+int lmi_norm_fp8(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps, float out_scale,
+                 void* stream);
 
 /* Variable-length FlashAttention-2 forward over packed sequences (SigLIP: non-causal, head_dim 72, one
  * sequence per tile; Llama / Mistral: causal GQA, head_dim 128, optional sliding window; Idefics2 perceiver: head_dim 96,

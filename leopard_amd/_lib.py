@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libleopard_amd.so")
 
-LMI_F16, LMI_BF16, LMI_F32 = 0, 1, 2
+LMI_F16, LMI_BF16, LMI_F32, LMI_FP8 = 0, 1, 2, 3
 EPI_STORE, EPI_RESIDUAL, EPI_STORE_F32, EPI_SWIGLU, EPI_QKV_ROPE = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
 A_PLAIN, A_PIXEL_SHUFFLE = 0, 1
@@ -34,7 +34,8 @@ SIGNATURES = {
     "lmi_gemm_ex": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _P, _P, _I, _I, _P],
     "lmi_rmsnorm_rope": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_quantize_fp8": [_P, _I, _P, _I, _I, _I, _I, _F, _P],
-    "lmi_gemm_fp8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_gemm_fp8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "lmi_norm_fp8": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
     "lmi_attn_varlen_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
     "lmi_rope_qk": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     "lmi_rope_qk_at": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],

@@ -281,14 +281,14 @@ int dispatch_gemv(const void* W, const void* x, const float* gamma, float eps, c
 }
 template <typename T, bool RMS>
 int norm_impl(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo,
-                     float eps, void* stream, const char* what) {
+                     float eps, void* stream, const char* what, float out_scale = 1.0f) {
     if (!x || !w || !out || (!RMS && !b) || M < 0 || D <= 0 || (D & 7) || D > 4096 || (ldx & 3) || (ldo & 7) ||
         !aligned16(x) || !aligned16(w) || !aligned16(out))
         return fail(LMI_EINVAL, "%s: bad argument (M=%d D=%d ldx=%d ldo=%d; D%%8==0, D<=4096)", what, M, D, ldx, ldo);
     if (M == 0) return LMI_OK;
     const int grid = (M + 3) / 4;
-    if (D <= 1536) LMI_LAUNCH((norm_kernel<T, RMS, 3>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
-    else LMI_LAUNCH((norm_kernel<T, RMS, 8>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps);
+    if (D <= 1536) LMI_LAUNCH((norm_kernel<T, RMS, 3>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps, out_scale);
+    else LMI_LAUNCH((norm_kernel<T, RMS, 8>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps, out_scale);
     return check_launch(what);
 }
 
@@ -448,6 +448,7 @@ int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, in
 int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps,
                   int dtype, void* stream) {
     if (dtype == LMI_F32) return norm_impl<float, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm");
+    if (dtype == LMI_FP8) return fail(LMI_EINVAL, "lmi_layernorm: fp8 output needs a scale: use lmi_norm_fp8");
     LMI_DISPATCH_T(dtype, (norm_impl<f16_t, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm")),
                    (norm_impl<bf16_t, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm")));
 }
@@ -455,6 +456,7 @@ int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int
 int lmi_rmsnorm(const float* x, const float* w, void* out, int M, int D, int ldx, int ldo, float eps, int dtype,
                 void* stream) {
     if (dtype == LMI_F32) return norm_impl<float, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm");
+    if (dtype == LMI_FP8) return fail(LMI_EINVAL, "lmi_rmsnorm: fp8 output needs a scale: use lmi_norm_fp8");
     LMI_DISPATCH_T(dtype, (norm_impl<f16_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm")),
                    (norm_impl<bf16_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_rmsnorm")));
 }
@@ -498,6 +500,7 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     a.rope_cos = x.rope_cos; a.rope_sin = x.rope_sin; a.k_cache = x.k_cache; a.v_cache = x.v_cache;
     a.ld_cache = x.ld_cache; a.cache_pos0 = x.cache_pos0; a.rope_q = x.rope_q; a.rope_k = x.rope_k;
     a.scale_e8m0 = 0x7f7f7f7f;
+    a.out_scale = 1.0f;
     // extents for the buffer resources the LDS-DMA reads through (32-bit offsets)
     const long a_rows = (a_mode == LMI_A_PIXEL_SHUFFLE) ? (long)(M / ((ps_grid / 2) * (ps_grid / 2))) * ps_grid * ps_grid : (long)M;
     const long a_cols = (a_mode == LMI_A_PIXEL_SHUFFLE) ? K / 4 : K;
@@ -560,6 +563,13 @@ int lmi_rmsnorm_rope(const void* A, const void* Wqkv, void* qkv, const float* ro
                       LMI_A_PLAIN, 0, dtype, stream, x);
 }
 
+int lmi_norm_fp8(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps, float out_scale,
+                 void* stream) {
+    if (ldo & 15) return fail(LMI_EINVAL, "lmi_norm_fp8: ldo must be a multiple of 16 (fp8 GEMM operand rows)");
+    if (b) return norm_impl<fp8_t, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_norm_fp8", out_scale);
+    return norm_impl<fp8_t, true>(x, w, nullptr, out, M, D, ldx, ldo, eps, stream, "lmi_norm_fp8", out_scale);
+}
+
 int lmi_quantize_fp8(const void* x, int x_dtype, void* out, int M, int D, int ldx, int ldo, float scale, void* stream) {
     if (!x || !out || M < 0 || D <= 0 || (D & 7) || (ldx & 7) || (ldo & 15) || !aligned16(x) || !aligned16(out))
         return fail(LMI_EINVAL, "lmi_quantize_fp8: bad argument (M=%d D=%d ldx=%d ldo=%d; D %% 8 == 0, ldx %% 8 == 0, ldo %% 16 == 0)", M, D, ldx, ldo);
@@ -574,7 +584,7 @@ int lmi_quantize_fp8(const void* x, int x_dtype, void* out, int M, int D, int ld
 }
 
 int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
-                 int scale_exp, int out_dtype, void* stream) {
+                 int scale_exp, int out_dtype, float out_scale, void* stream) {
     if (!A || !W || !out) return fail(LMI_EINVAL, "lmi_gemm_fp8: null pointer");
     if (M < 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128))
         return fail(LMI_EINVAL, "lmi_gemm_fp8: need N %% 128 == 0 and K %% 128 == 0 (M=%d N=%d K=%d)", M, N, K);
@@ -588,9 +598,17 @@ int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
     const int e = 127 + scale_exp;
     a.scale_e8m0 = e | (e << 8) | (e << 16) | (e << 24);
+    a.out_scale = out_scale;
     const long a_bytes = ((long)(M - 1) * lda + K), w_bytes = ((long)(N - 1) * ldw + K);
     if (a_bytes >= (1L << 32) || w_bytes >= (1L << 32)) return fail(LMI_EINVAL, "lmi_gemm_fp8: operand extent >= 4 GiB");
     a.a_bytes = (unsigned)a_bytes; a.w_bytes = (unsigned)w_bytes;
+    if (out_dtype == LMI_FP8) {                                    // fp8 results for the next fp8 GEMM: GELU (ViT fc1) and SwiGLU (gate/up) only
+        if ((ldo & 7) || out_scale <= 0.f) return fail(LMI_EINVAL, "lmi_gemm_fp8: fp8 output needs ldo %% 8 == 0 and out_scale > 0");
+        if (epilogue == LMI_EPI_STORE && act == LMI_ACT_GELU_TANH) return launch_gemm_fp8<fp8_t, EPI_STORE_T, ACT_GELU_TANH>(a, stream);
+        if (epilogue == LMI_EPI_STORE && act == LMI_ACT_NONE) return launch_gemm_fp8<fp8_t, EPI_STORE_T, ACT_NONE>(a, stream);
+        if (epilogue == LMI_EPI_SWIGLU && act == LMI_ACT_NONE) return launch_gemm_fp8<fp8_t, EPI_SWIGLU_T, ACT_NONE>(a, stream);
+        return fail(LMI_EINVAL, "lmi_gemm_fp8: fp8 output is supported for STORE (+GELU-tanh) and SWIGLU");
+    }
     LMI_DISPATCH_T(out_dtype, dispatch_gemm_fp8<f16_t>(a, epilogue, act, stream), dispatch_gemm_fp8<bf16_t>(a, epilogue, act, stream));
 }
 

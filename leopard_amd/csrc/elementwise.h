@@ -96,7 +96,7 @@ __global__ void resample_u8_kernel(const uint8_t* src, uint8_t* dst, int rows, i
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool RMS, int MAXV>     // MAXV = max 8-element chunks per lane (D <= MAXV*512)
 __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* w, const float* b, T* out,
-                                                   int M, int D, int ldx, int ldo, float eps) {
+                                                   int M, int D, int ldx, int ldo, float eps, float out_scale) {
     typedef typename vec_of<T>::x8 T8;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -148,11 +148,17 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
                 const f32x4 ww = *(const f32x4*)(w + c * 8 + 4 * h);
                 if (RMS) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[4 * h + e] = (T)(ww[e] * (v[i][h][e] * rstd));
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = ww[e] * (v[i][h][e] * rstd);
+                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);       // fp8 operand: static power-of-two scale
+                    }
                 } else {
                     const f32x4 bb = *(const f32x4*)(b + c * 8 + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[4 * h + e] = (T)((v[i][h][e] - mean) * rstd * ww[e] + bb[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = (v[i][h][e] - mean) * rstd * ww[e] + bb[e];
+                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);
+                    }
                 }
             }
             *(T8*)(orow + c * 8) = o;

@@ -77,6 +77,7 @@ struct GemmArgs {
     // ---- fp8 operands (lmi_gemm_fp8): the accumulators come out multiplied by 2^(scale_e8m0 - 127) (E8M0 block scale of the MFMA,
     // every byte the same), which undoes the power-of-two scales the operands were quantised with
     int scale_e8m0;
+    float out_scale;             // fp8 OUTPUTS (T = fp8_t: GELU / SwiGLU results handed to the next fp8 GEMM): value * out_scale, then e4m3
 };
 
 constexpr int GEMM_BK = 64;
@@ -304,7 +305,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 if (is_v) {                                             // v: natural order, plain copy
                     c1 = nw0 + oc; c2 = c1 + 32;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { o1[e] = (T)a0[e]; o1[4 + e] = (T)a1[e]; o2[e] = (T)b0[e]; o2[4 + e] = (T)b1[e]; }
+                    for (int e = 0; e < 4; ++e) { o1[e] = OutCvt<T>::cvt(a0[e]); o1[4 + e] = OutCvt<T>::cvt(a1[e]); o2[e] = OutCvt<T>::cvt(b0[e]); o2[4 + e] = OutCvt<T>::cvt(b1[e]); }
                 } else {                                                // q / k: rotate-half RoPE on the fp32 accumulators
                     const int d1 = hb * 32 + oc;                        // 0..63: element of the first half; partner d1 + 64
                     c1 = hbase + d1; c2 = c1 + 64;
@@ -316,10 +317,10 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     // kernel instantiation contracts `a*c - b*s` its own way and a row's bits would depend on the tile geometry
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o1[e] = (T)__builtin_fmaf(a0[e], cs0[e], -mul_rn(b0[e], sn0[e]));
-                        o1[4 + e] = (T)__builtin_fmaf(a1[e], cs1[e], -mul_rn(b1[e], sn1[e]));
-                        o2[e] = (T)__builtin_fmaf(b0[e], cs0[e], mul_rn(a0[e], sn0[e]));
-                        o2[4 + e] = (T)__builtin_fmaf(b1[e], cs1[e], mul_rn(a1[e], sn1[e]));
+                        o1[e] = OutCvt<T>::cvt(__builtin_fmaf(a0[e], cs0[e], -mul_rn(b0[e], sn0[e])));
+                        o1[4 + e] = OutCvt<T>::cvt(__builtin_fmaf(a1[e], cs1[e], -mul_rn(b1[e], sn1[e])));
+                        o2[e] = OutCvt<T>::cvt(__builtin_fmaf(b0[e], cs0[e], mul_rn(a0[e], sn0[e])));
+                        o2[4 + e] = OutCvt<T>::cvt(__builtin_fmaf(b1[e], cs1[e], mul_rn(a1[e], sn1[e])));
                     }
                 }
                 if (m < p.M) {
@@ -348,10 +349,11 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     g0 *= rstd; g1 *= rstd; u0 *= rstd; u1 *= rstd;
                 }
                 T8 o;
+                const float os = (sizeof(T) == 1) ? p.out_scale : 1.0f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (T)(fast_silu(g0[e]) * u0[e]);
-                    o[4 + e] = (T)(fast_silu(g1[e]) * u1[e]);
+                    o[e] = OutCvt<T>::cvt(fast_silu(g0[e]) * u0[e] * os);
+                    o[4 + e] = OutCvt<T>::cvt(fast_silu(g1[e]) * u1[e] * os);
                 }
                 if (m < p.M) {
                     const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
@@ -409,8 +411,9 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
             if (mb + it * RPI + r_in >= p.M) continue;
             if (EPI == EPI_STORE_T) {
                 T8 o;
+                const float os = (sizeof(T) == 1) ? p.out_scale : 1.0f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = (T)v0[it][e]; o[4 + e] = (T)v1[it][e]; }
+                for (int e = 0; e < 4; ++e) { o[e] = OutCvt<T>::cvt(v0[it][e] * os); o[4 + e] = OutCvt<T>::cvt(v1[it][e] * os); }
                 *(T8*)((T*)p.out + orow[it] * p.ldo + nw0 + oc) = o;
             } else {
                 float* drow = (float*)p.out + orow[it] * p.ldo + nw0 + oc;
@@ -420,7 +423,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     // the next RMSNorm, started here: gain applied and rounded; its row scale is finished by the consumer GEMM
                     T8 hn;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { hn[e] = (T)(v0[it][e] * gam0[e]); hn[4 + e] = (T)(v1[it][e] * gam1[e]); }
+                    for (int e = 0; e < 4; ++e) { hn[e] = OutCvt<T>::cvt(v0[it][e] * gam0[e]); hn[4 + e] = OutCvt<T>::cvt(v1[it][e] * gam1[e]); }
                     *(T8*)((T*)p.norm_out + orow[it] * p.ld_norm + nw0 + oc) = hn;
                     if ((lane & 7) == 0) p.rowsq_out[orow[it] * (long)(p.N >> 6) + (nw0 >> 6)] = sq;
                 }

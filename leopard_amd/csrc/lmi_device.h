@@ -42,6 +42,7 @@ template <typename T> struct vec_of;
 template <> struct vec_of<f16_t> { typedef f16x8 x8; typedef f16x4 x4; typedef f16x2 x2; };
 template <> struct vec_of<bf16_t> { typedef bf16x8 x8; typedef bf16x4 x4; typedef bf16x2 x2; };
 template <> struct vec_of<float> { typedef f32x8 x8; typedef f32x4 x4; typedef f32x2 x2; };   // fp32-output norms
+template <> struct vec_of<fp8_t> { typedef u8x8 x8; };                                          // fp8 outputs (8 bytes per lane)
 
 #define LMI_WAVE 64
 
@@ -359,6 +360,9 @@ LMI_DEV int imin(int a, int b) { return a < b ? a : b; }
 LMI_DEV int imax(int a, int b) { return a > b ? a : b; }
 template <typename T> LMI_DEV float to_f32(T v) { return (float)v; }
 template <typename T> LMI_DEV T from_f32(float v) { return (T)v; }
+// element of an 8-wide output vector from an fp32 value: a cast for the 16-bit / fp32 types, the saturating e4m3 conversion for fp8
+template <typename T> struct OutCvt { static LMI_DEV T cvt(float v) { return (T)v; } };
+template <> struct OutCvt<fp8_t> { static LMI_DEV uint8_t cvt(float v) { return to_fp8(v); } };
 // two fp32 -> one dword of two T (x in the low half)
 template <typename T> LMI_DEV unsigned pack2(float x, float y) {
     typename vec_of<T>::x2 v;

@@ -114,6 +114,8 @@ class LeopardEngine:
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
+        self.fp8 = None                # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
+        self._rec = None               # calibration recorder callable((tower, layer, site), operand tensor)
         tc = cfg.text_config
         self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
         self._geom_cache: Dict[tuple, tuple] = {}      # seq_lens -> (cu, cos, sin, last_rows) device tensors
@@ -188,29 +190,75 @@ class LeopardEngine:
         x = self._empty(M, D, dtype=torch.float32)
         ops.gemm(patches, W.patch_w, x, bias=W.patch_b, addmat=W.pos_emb, epilogue=_lib.EPI_STORE_F32)
         del patches
+        cu = self._vit_cu_cache.get(n)
+        if cu is None:
+            cu = self._vit_cu_cache[n] = torch.arange(0, (n + 1) * T, T, dtype=torch.int32, device=self.device)
+        if self.trace:
+            self.trace("vit.embed", x)
+        if self.fp8 is not None:
+            return self._vit_layers_fp8(x, n)
         h = self._empty(M, D)
         qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0]) if W.vit_layers else None
         att = self._empty(M, D)
         ff = self._empty(M, W.vit_ff)
-        cu = self._vit_cu_cache.get(n)
-        if cu is None:
-            cu = self._vit_cu_cache[n] = torch.arange(0, (n + 1) * T, T, dtype=torch.int32, device=self.device)
         scale = hd ** -0.5
-        if self.trace:
-            self.trace("vit.embed", x)
+        rec = self._rec
         for li, L in enumerate(W.vit_layers):
             ops.layernorm(x, L.ln1_w, L.ln1_b, h, vc.layer_norm_eps)
+            rec and rec(("vit", li, "h1"), h)
             ops.gemm(h, L.qkv_w, qkv, bias=L.qkv_b)
             ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, cu, cu, T, H, H, hd, scale, False,
                           self.use_tr)
+            rec and rec(("vit", li, "att"), att)
             ops.gemm(att, L.o_w, x, bias=L.o_b, epilogue=_lib.EPI_RESIDUAL)
             ops.layernorm(x, L.ln2_w, L.ln2_b, h, vc.layer_norm_eps)
+            rec and rec(("vit", li, "h2"), h)
             ops.gemm(h, L.fc1_w, ff, bias=L.fc1_b, act=_lib.ACT_GELU_TANH)
+            rec and rec(("vit", li, "ff"), ff)
             ops.gemm(ff, L.fc2_w, x, bias=L.fc2_b, epilogue=_lib.EPI_RESIDUAL)
             if self.trace:
                 self.trace(f"vit.{li}", x)
         ops.layernorm(x, W.post_ln_w, W.post_ln_b, h, vc.layer_norm_eps)
         return h
+
+    def _vit_layers_fp8(self, x: torch.Tensor, n: int) -> torch.Tensor:
+        """The SigLIP layers with fp8 linears (leopard_amd.fp8): LayerNorm -> fp8 operand in one launch, fc1's GELU epilogue
+        writes fc2's fp8 operand; q|k|v and the attention stay 16-bit, the residual stream fp32."""
+        ops, W, vc, P = self.ops, self.W, self.cfg.vision_config, self.fp8
+        T, D, H, hd = vc.num_patches, vc.hidden_size, vc.num_attention_heads, vc.head_dim
+        M = n * T
+        u8 = torch.uint8
+        h8 = self._empty(M, D, dtype=u8)
+        att8 = self._empty(M, D, dtype=u8)
+        ff8 = self._empty(M, W.vit_ff, dtype=u8)
+        qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0])
+        att = self._empty(M, D)
+        cu = self._vit_cu_cache[n]
+        scale = hd ** -0.5
+        for li, (L, Q) in enumerate(zip(W.vit_layers, P.vit)):
+            ops.norm_fp8(x, L.ln1_w, L.ln1_b, h8, vc.layer_norm_eps, 2.0 ** Q.act["h1"])
+            ops.gemm_fp8(h8, Q.lin["qkv"].w8, qkv, bias=L.qkv_b, scale_exp=Q.out_exp("h1", "qkv"))
+            ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, cu, cu, T, H, H, hd, scale, False,
+                          self.use_tr)
+            ops.quantize_fp8(att, att8, 2.0 ** Q.act["att"])
+            ops.gemm_fp8(att8, Q.lin["o"].w8, x, bias=L.o_b, epilogue=_lib.EPI_RESIDUAL, scale_exp=Q.out_exp("att", "o"))
+            ops.norm_fp8(x, L.ln2_w, L.ln2_b, h8, vc.layer_norm_eps, 2.0 ** Q.act["h2"])
+            ops.gemm_fp8(h8, Q.lin["fc1"].w8, ff8, bias=L.fc1_b, act=_lib.ACT_GELU_TANH, scale_exp=Q.out_exp("h2", "fc1"),
+                         out_scale=2.0 ** Q.act["ff"])
+            ops.gemm_fp8(ff8, Q.lin["fc2"].w8, x, bias=L.fc2_b, epilogue=_lib.EPI_RESIDUAL, scale_exp=Q.out_exp("ff", "fc2"))
+            if self.trace:
+                self.trace(f"vit.{li}", x)
+        h = self._empty(M, D)
+        ops.layernorm(x, W.post_ln_w, W.post_ln_b, h, vc.layer_norm_eps)
+        return h
+
+    def enable_fp8(self, calibration_samples, headroom: float = 2.0):
+        """Switch the ViT / LLM layer linears to fp8 operands (BASELINE configs[4]): quantise the weights once, take the static
+        activation scales from a 16-bit prefill of ``calibration_samples`` [(input_ids, tiles)].  ``engine.fp8 = None`` reverts."""
+        from . import fp8 as F8
+        self.fp8 = F8.calibrate(self, calibration_samples, headroom)
+        self._encode_graphs.clear()
+        return self.fp8
 
     # ------------------------------------------------------------------------------------------------
     # a8 + a9: pixel shuffle + projector
@@ -293,21 +341,27 @@ class LeopardEngine:
         assert cu_list[-1] == S
         if cache is not None:       # one sequence, or a pool holding the packed rows of several (generate_batch splits it afterwards)
             assert cache.length == 0 and cache.capacity >= S
+        max_len = max(int(l) for l in seq_lens)
+        if self.trace:
+            self.trace("llm.embed", x)
+        if self.fp8 is not None:
+            self._llm_layers_fp8(x, cache, cu, cos, sin, max_len)
+            if cache is not None:
+                cache.length = S
+            return self._lm_head(x, last_rows, all_logits)
         h = self._empty(S, D)
         qkv = self._empty(S, qw + 2 * kw)
         att = self._empty(S, qw)
         gu = self._empty(S, W.llm_ff)
         tmp = self._empty(S, D, dtype=torch.float32) if self.tp_size > 1 else None
         scale = hd ** -0.5
-        max_len = max(int(l) for l in seq_lens)
-        if self.trace:
-            self.trace("llm.embed", x)
         # Fused schedule (one rank, head_dim 128): the RMSNorms and the RoPE ride in the GEMM epilogues.  Each residual GEMM
         # (o_proj, down_proj) also emits T(x * gamma_next) and per-row partial sums of squares; the GEMM that consumes them
         # (gate/up, next layer's qkv) applies rstd to its accumulator rows; the qkv GEMM rotates q / k and appends K / V to the
         # cache in its epilogue.  Only the very first norm of the stack is a launch of its own.
         fused = (self.fuse_norm_rope and self.tp_size == 1 and hd == 128 and D % 256 == 0 and W.llm_layers
                  and W.llm_layers[0].qkv_w_rope is not None)
+        rec = self._rec
         if fused:
             parts = D // 64
             sq_a = self._empty(S, parts, dtype=torch.float32)       # partials feeding gate/up
@@ -332,19 +386,52 @@ class LeopardEngine:
         else:
             for i, L in enumerate(W.llm_layers):
                 ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
+                rec and rec(("llm", i, "h1"), h)
                 ops.gemm(h, L.qkv_w, qkv)
                 ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
                 ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
                               True, self.use_tr, window=tc.sliding_window or 0)
+                rec and rec(("llm", i, "att"), att)
                 self._row_parallel(att, L.o_w, x, tmp)
                 ops.rmsnorm(x, L.post_norm, h, tc.rms_norm_eps)
+                rec and rec(("llm", i, "h2"), h)
                 ops.gemm(h, L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
+                rec and rec(("llm", i, "gu"), gu)
                 self._row_parallel(gu, L.down_w, x, tmp)
                 if self.trace:
                     self.trace(f"llm.{i}", x)
         if cache is not None:
             cache.length = S
         return self._lm_head(x, last_rows, all_logits)
+
+    def _llm_layers_fp8(self, x, cache, cu, cos, sin, max_len):
+        """The Llama layers with fp8 linears (leopard_amd.fp8): RMSNorm -> fp8 operand in one launch, the SwiGLU epilogue of
+        gate/up writes down_proj's fp8 operand; q|k|v, RoPE, the KV cache and the attention stay 16-bit, the stream fp32."""
+        ops, W, tc, P = self.ops, self.W, self.cfg.text_config, self.fp8
+        S, D = x.shape
+        (H, KV), hd = self._llm_heads(), tc.head_dim
+        qw, kw = H * hd, KV * hd
+        u8 = torch.uint8
+        h8 = self._empty(S, D, dtype=u8)
+        att8 = self._empty(S, qw, dtype=u8)
+        gu8 = self._empty(S, W.llm_ff, dtype=u8)
+        qkv = self._empty(S, qw + 2 * kw)
+        att = self._empty(S, qw)
+        scale = hd ** -0.5
+        for i, (L, Q) in enumerate(zip(W.llm_layers, P.llm)):
+            ops.norm_fp8(x, L.in_norm, None, h8, tc.rms_norm_eps, 2.0 ** Q.act["h1"])
+            ops.gemm_fp8(h8, Q.lin["qkv"].w8, qkv, scale_exp=Q.out_exp("h1", "qkv"))
+            ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
+            ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
+                          True, self.use_tr, window=tc.sliding_window or 0)
+            ops.quantize_fp8(att, att8, 2.0 ** Q.act["att"])
+            ops.gemm_fp8(att8, Q.lin["o"].w8, x, epilogue=_lib.EPI_RESIDUAL, scale_exp=Q.out_exp("att", "o"))
+            ops.norm_fp8(x, L.post_norm, None, h8, tc.rms_norm_eps, 2.0 ** Q.act["h2"])
+            ops.gemm_fp8(h8, Q.lin["gu"].w8, gu8, epilogue=_lib.EPI_SWIGLU, scale_exp=Q.out_exp("h2", "gu"),
+                         out_scale=2.0 ** Q.act["gu"])
+            ops.gemm_fp8(gu8, Q.lin["down"].w8, x, epilogue=_lib.EPI_RESIDUAL, scale_exp=Q.out_exp("gu", "down"))
+            if self.trace:
+                self.trace(f"llm.{i}", x)
 
     def _lm_head(self, x, last_rows, all_logits):
         ops, W, tc = self.ops, self.W, self.cfg.text_config

@@ -214,11 +214,22 @@ class Ops:
         self._check(self.lib.lmi_quantize_fp8(_ptr(x), _DT[x.dtype], _ptr(out), M, D, x.stride(0), out.stride(0), float(scale), self._stream(x)))
         return out
 
-    def gemm_fp8(self, a8, w8, out, bias=None, epilogue=EPI_STORE, act=ACT_NONE, scale_exp: int = 0):
-        """out = epilogue(2^scale_exp * (a8 @ w8.T)) on fp8 e4m3fn operands (uint8 / float8 tensors [M, K], [N, K])."""
+    def gemm_fp8(self, a8, w8, out, bias=None, epilogue=EPI_STORE, act=ACT_NONE, scale_exp: int = 0, out_scale: float = 1.0):
+        """out = epilogue(2^scale_exp * (a8 @ w8.T)) on fp8 e4m3fn operands (uint8 / float8 tensors [M, K], [N, K]); a uint8 / float8
+        ``out`` (STORE [+GELU-tanh], SWIGLU) receives fp8(result * out_scale)."""
         N, K = w8.shape
         M = a8.shape[0]
-        dt = _DT[out.dtype] if out.dtype in (torch.float16, torch.bfloat16) else LMI_F16
+        if out.dtype in (torch.uint8, torch.float8_e4m3fn):
+            dt = _lib.LMI_FP8
+        else:
+            dt = _DT[out.dtype] if out.dtype in (torch.float16, torch.bfloat16) else LMI_F16
         self._check(self.lib.lmi_gemm_fp8(_ptr(a8), _ptr(w8), _ptr(out), _ptr(bias), M, N, K, a8.stride(0), w8.stride(0), out.stride(0),
-                                          epilogue, act, int(scale_exp), dt, self._stream(out)))
+                                          epilogue, act, int(scale_exp), dt, float(out_scale), self._stream(out)))
         return out
+
+    def norm_fp8(self, x, w, b, out8, eps, out_scale: float):
+        """out8 (uint8 / float8 [M, D]) = fp8(norm(x) * out_scale): LayerNorm when b is given, RMSNorm when b is None."""
+        M, D = x.shape
+        self._check(self.lib.lmi_norm_fp8(_ptr(x), _ptr(w), _ptr(b), _ptr(out8), M, D, x.stride(0), out8.stride(0), float(eps),
+                                          float(out_scale), self._stream(out8)))
+        return out8

@@ -60,11 +60,39 @@ class _Emu:
     fp32_head = True      # the HIP path feeds the last-token lm_head the fp32 normalised row (lmi_lm_head_last)
     fused = True          # production Llama schedule (lmi_gemm_ex / lmi_rmsnorm_rope): the RMSNorm operand is rounded as
                           # T(x * gamma) BEFORE the row scale, and q / k are rounded once, after the rotation
+    operand_dtype = None  # fp8 schedule (BASELINE config 5): the A operands AND the weights of the ViT / LLM layer linears are
+                          # float8_e4m3fn with per-tensor power-of-two scales; everything else stays at ``dtype``
+    _wcache: dict = {}
 
 
 def _q(x: Tensor) -> Tensor:
     """Hand-over rounding point: identity unless emulate_rounding() is active."""
     return x if _Emu.dtype is None else x.to(_Emu.dtype).to(torch.float32)
+
+
+def _fp8_round(x: Tensor) -> Tensor:
+    """Per-tensor power-of-two scale that puts amax in [112, 224], saturating e4m3 rounding, back to fp32 (the engine's static
+    scales differ from this only in the exponent they pick, which does not change a floating-point format's relative error)."""
+    amax = float(x.abs().max())
+    if amax == 0.0:
+        return x
+    s = 2.0 ** math.floor(math.log2(224.0 / amax))
+    return (x * s).clamp(-448.0, 448.0).to(_Emu.operand_dtype).to(torch.float32) / s
+
+
+def _qa(x: Tensor) -> Tensor:
+    """Hand-over point that is the A operand of a ViT / LLM layer linear (norm outputs, attention output, GELU / SwiGLU output)."""
+    return _q(x) if _Emu.operand_dtype is None else _fp8_round(x)
+
+
+def _wq(w: Tensor) -> Tensor:
+    """Weight of a ViT / LLM layer linear: exact unless the fp8 schedule is emulated."""
+    if _Emu.operand_dtype is None:
+        return w
+    hit = _Emu._wcache.get(id(w))
+    if hit is None or hit[0] is not w:
+        hit = _Emu._wcache[id(w)] = (w, _fp8_round(w))
+    return hit[1]
 
 
 def _tr(name: str, x: Tensor) -> None:
@@ -73,16 +101,19 @@ def _tr(name: str, x: Tensor) -> None:
 
 
 class emulate_rounding:
-    def __init__(self, dtype, trace: Optional[list] = None):
-        self.dtype, self.trace = dtype, trace
+    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None):
+        self.dtype, self.trace, self.operand_dtype = dtype, trace, operand_dtype
 
     def __enter__(self):
-        self._old = (_Emu.dtype, _Emu.trace)
-        _Emu.dtype, _Emu.trace = self.dtype, self.trace
+        self._old = (_Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused)
+        _Emu.dtype, _Emu.trace, _Emu.operand_dtype = self.dtype, self.trace, self.operand_dtype
+        if self.operand_dtype is not None:
+            _Emu.fused = False               # the fp8 schedule keeps the norms as launches of their own (lmi_norm_fp8)
         return self
 
     def __exit__(self, *exc):
-        _Emu.dtype, _Emu.trace = self._old
+        _Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused = self._old
+        _Emu._wcache.clear()
         return False
 
 
@@ -224,18 +255,18 @@ def siglip_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, prefix: str = "vi
     N, T, D = x.shape
     H, hd = vc.num_attention_heads, vc.head_dim
     r = x
-    h = _q(F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], vc.layer_norm_eps))
-    q = _q(F.linear(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
-    k = _q(F.linear(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
-    v = _q(F.linear(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
+    h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], vc.layer_norm_eps))
+    q = _q(F.linear(h, _wq(W[p + "self_attn.q_proj.weight"]), W[p + "self_attn.q_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
+    k = _q(F.linear(h, _wq(W[p + "self_attn.k_proj.weight"]), W[p + "self_attn.k_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
+    v = _q(F.linear(h, _wq(W[p + "self_attn.v_proj.weight"]), W[p + "self_attn.v_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)      # full (non-causal) attention per tile
     a = _softmax_q(s)
-    o = _q(torch.matmul(a, v)).transpose(1, 2).reshape(N, T, D)
-    x = r + F.linear(o, W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"])
+    o = _qa(_q(torch.matmul(a, v))).transpose(1, 2).reshape(N, T, D)
+    x = r + F.linear(o, _wq(W[p + "self_attn.out_proj.weight"]), W[p + "self_attn.out_proj.bias"])
     r = x
-    h = _q(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], vc.layer_norm_eps))
-    h = _q(gelu_tanh(F.linear(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])))
-    return r + F.linear(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"])
+    h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], vc.layer_norm_eps))
+    h = _qa(gelu_tanh(F.linear(h, _wq(W[p + "mlp.fc1.weight"]), W[p + "mlp.fc1.bias"])))
+    return r + F.linear(h, _wq(W[p + "mlp.fc2.weight"]), W[p + "mlp.fc2.bias"])
 
 
 def siglip_vision_tower(pixel_values: Tensor, W: Dict[str, Tensor], cfg) -> Tensor:
@@ -362,7 +393,7 @@ def rms_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
 def _rms_norm_q(x: Tensor, w: Tensor, eps: float, first: bool) -> Tensor:
     """rms_norm followed by the hand-over rounding of the HIP path (identity without emulate_rounding)."""
     if _Emu.dtype is None or not _Emu.fused or first:
-        return _q(rms_norm(x, w, eps))
+        return _qa(rms_norm(x, w, eps))
     v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
     return _q(x * w) * torch.rsqrt(v + eps)          # producer epilogue rounds x * gamma; the consumer applies rstd in fp32
 
@@ -376,9 +407,9 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
     r = x
     pre = (lambda t: t) if _Emu.fused else _q          # unfused schedule: q / k are also rounded before the rotation
     h = _rms_norm_q(x, W[p + "input_layernorm.weight"], tc.rms_norm_eps, first=(i == 0))
-    q = pre(F.linear(h, W[p + "self_attn.q_proj.weight"])).view(B, S, H, hd).transpose(1, 2)
-    k = pre(F.linear(h, W[p + "self_attn.k_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
-    v = _q(F.linear(h, W[p + "self_attn.v_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
+    q = pre(F.linear(h, _wq(W[p + "self_attn.q_proj.weight"]))).view(B, S, H, hd).transpose(1, 2)
+    k = pre(F.linear(h, _wq(W[p + "self_attn.k_proj.weight"]))).view(B, S, KV, hd).transpose(1, 2)
+    v = _q(F.linear(h, _wq(W[p + "self_attn.v_proj.weight"]))).view(B, S, KV, hd).transpose(1, 2)
     q = _q(q * cos + rotate_half(q) * sin)
     k = _q(k * cos + rotate_half(k) * sin)
     if kv_out is not None:
@@ -398,13 +429,13 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
             causal = causal & (ar[s0:s1, None] - ar[None, :s1] < tc.sliding_window)
         sc = sc.masked_fill(~causal, float("-inf"))
         o[:, :, s0:s1] = torch.matmul(_softmax_q(sc), vv[:, :, :s1])
-    o = _q(o.transpose(1, 2).reshape(B, S, H * hd))
-    x = r + F.linear(o, W[p + "self_attn.o_proj.weight"])
+    o = _qa(_q(o.transpose(1, 2).reshape(B, S, H * hd)))
+    x = r + F.linear(o, _wq(W[p + "self_attn.o_proj.weight"]))
     r = x
     h = _rms_norm_q(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps, first=False)
-    g = F.linear(h, W[p + "mlp.gate_proj.weight"])
-    u = F.linear(h, W[p + "mlp.up_proj.weight"])
-    return r + F.linear(_q(F.silu(g) * u), W[p + "mlp.down_proj.weight"])       # XFMR:136-139
+    g = F.linear(h, _wq(W[p + "mlp.gate_proj.weight"]))
+    u = F.linear(h, _wq(W[p + "mlp.up_proj.weight"]))
+    return r + F.linear(_qa(F.silu(g) * u), _wq(W[p + "mlp.down_proj.weight"]))       # XFMR:136-139
 
 
 def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tensor], cfg,

@@ -91,3 +91,94 @@ def test_gemm_fp8_rejects_bad_shapes(ops):
     a8, w8 = torch.zeros(8, 192, dtype=torch.uint8), torch.zeros(128, 192, dtype=torch.uint8)
     with pytest.raises(RuntimeError, match="K % 128"):
         ops.gemm_fp8(a8, w8, torch.empty(8, 128, dtype=torch.float16))
+
+
+def _fp8_close(out_u8, want_scaled):
+    """fp8 outputs against fp8(want): identical bytes except where the fp32 value sits within summation noise of a rounding tie
+    (then one e4m3 ulp apart)."""
+    want8 = q8(want_scaled)
+    got, ref = out_u8.view(F8).float(), want8.view(F8).float()
+    assert float((out_u8 == want8).float().mean()) >= 0.99
+    assert bool(((got - ref).abs() <= 0.126 * ref.abs() + 2.0 ** -9).all())
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 5])
+def test_gemm_fp8_fp8_outputs_gelu_and_swiglu(ops, cfg):
+    """SigLIP fc1 -> fc2 and Llama gate/up -> down hand-overs: the epilogue writes fp8(result * out_scale) directly."""
+    M, N, K = 200, 256, 256
+    g = torch.Generator().manual_seed(5)
+    a8, w8 = q8(torch.randn(M, K, generator=g)), q8(torch.randn(N, K, generator=g) * 0.5)
+    ref = a8.view(F8).float() @ w8.view(F8).float().T
+    bias = torch.randn(N, generator=g)
+    ops.set_option("gemm.config", cfg)
+    try:
+        out = torch.zeros(M, N, dtype=torch.uint8)
+        ops.gemm_fp8(a8, w8, out, bias=bias, act=_lib.ACT_GELU_TANH, scale_exp=-4, out_scale=8.0)
+        _fp8_close(out, 8.0 * torch.nn.functional.gelu(ref * 2.0 ** -4 + bias, approximate="tanh"))
+        ops.gemm_fp8(a8, w8, out, bias=bias, scale_exp=-4, out_scale=4.0)
+        _fp8_close(out, 4.0 * (ref * 2.0 ** -4 + bias))
+        F = N // 2
+        sw = torch.zeros(M, F, dtype=torch.uint8)
+        ops.gemm_fp8(a8, interleave_gate_up(w8[:F], w8[F:]), sw, epilogue=_lib.EPI_SWIGLU, scale_exp=-3, out_scale=16.0)
+        _fp8_close(sw, 16.0 * torch.nn.functional.silu(ref[:, :F] / 8) * (ref[:, F:] / 8))
+        with pytest.raises(RuntimeError, match="fp8 output"):
+            ops.gemm_fp8(a8, w8, out, epilogue=_lib.EPI_RESIDUAL)
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
+@pytest.mark.parametrize("D", [256, 1152, 4096])
+def test_norm_fp8_layernorm_and_rmsnorm(ops, D):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(21, D, generator=g) * 3 + 0.5
+    w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    out = torch.zeros(21, D, dtype=torch.uint8)
+    ops.norm_fp8(x, w, b, out, 1e-6, 16.0)
+    _fp8_close(out, 16.0 * torch.nn.functional.layer_norm(x, (D,), w, b, 1e-6))
+    ops.norm_fp8(x, w, None, out, 1e-5, 8.0)
+    _fp8_close(out, 8.0 * (x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * w))
+
+
+# ---- the engine's fp8 schedule (leopard_amd.fp8) end to end on the emulator --------------------------------------------------------
+def test_engine_fp8_schedule_matches_fp8_emulating_oracle(ops):
+    """enable_fp8(): calibration, weight quantisation, the launch sequence (lmi_norm_fp8 -> lmi_gemm_fp8 -> ... with fp8-output
+    GELU / SwiGLU epilogues).  The fp8 path must sit where the oracle that rounds the same operands to e4m3 predicts: its error
+    against the fp32 oracle equals the predicted budget, and it is much closer to the emulating oracle than to the fp32 one is
+    not required (the emulation is a statistical twin) — but both errors must have the same size."""
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    from leopard_amd.engine import LeopardEngine
+    from leopard_amd.synth import synth_state_dict_numpy
+    from leopard_amd.tiler import siglip_normalize
+    from leopard_amd.weights import EngineWeights, SynthSource
+    from oracle import leopard_oracle as O
+    cfg = LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=2, num_attention_heads=16,
+                                   image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1,
+                               num_key_value_heads=1, vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+    dtype = torch.float16
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", dtype), dtype)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    u8 = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (3, 28, 28, 3), dtype=np.uint8))
+    ids = torch.tensor([[5, 250, 9, 250, 250, 17, 33]])
+    calib = torch.from_numpy(np.random.default_rng(9).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
+    base = eng.prefill(ids, u8, all_logits=True).logits_all.clone()
+    plan = eng.enable_fp8([(torch.tensor([[3, 250, 250, 8]]), calib)])
+    assert len(plan.vit) == 2 and len(plan.llm) == 2 and set(plan.llm[0].lin) == {"qkv", "o", "gu", "down"}
+    assert all(l.w8.dtype == torch.uint8 for lay in plan.vit + plan.llm for l in lay.lin.values())
+    got = eng.prefill(ids, u8, all_logits=True).logits_all
+    pix = torch.from_numpy(siglip_normalize(u8.numpy()))
+    Wt = O.weights_from_numpy(synth_state_dict_numpy(cfg))
+    exact = O.prefill_logits(ids, pix, Wt, cfg)[0]
+    with O.emulate_rounding(dtype, operand_dtype=torch.float8_e4m3fn):
+        emu = O.prefill_logits(ids, pix, Wt, cfg)[0]
+    scale = exact.abs().max().item()
+    predicted = (emu - exact).abs().max().item() / scale
+    measured = (got - exact).abs().max().item() / scale
+    e16 = (base - exact).abs().max().item() / scale
+    assert measured > 3 * e16                              # the fp8 schedule really ran (an fp16 path would be far more accurate)
+    assert 0.5 * predicted <= measured <= 2.0 * predicted, (predicted, measured)
+    assert (got - emu).abs().max().item() / scale <= 2.0 * predicted
+    eng.fp8 = None                                         # reverts to the 16-bit schedule bit for bit
+    assert torch.equal(eng.prefill(ids, u8, all_logits=True).logits_all, base)

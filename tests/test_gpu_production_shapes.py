@@ -452,3 +452,53 @@ def test_gemm_fp8_swiglu_and_gelu(ops, out_dtype):
     out = torch.full((M, N), float("nan"), dtype=out_dtype, device=DEV)
     ops.gemm_fp8(a8.view(torch.uint8), w8.view(torch.uint8), out, bias=bias, act=_lib.ACT_GELU_TANH, scale_exp=-4)
     assert rel_err(out, torch.nn.functional.gelu(ref, approximate="tanh")) <= 3 * eps(out_dtype)
+
+
+def _fp8_close(out_u8, want_scaled):
+    """fp8 outputs against torch's fp8 conversion of the fp32 result: identical bytes except where the value sits within summation
+    noise of a rounding tie (then one e4m3 ulp apart)."""
+    want8 = want_scaled.clamp(-448, 448).to(F8)
+    got, ref = out_u8.view(F8).float(), want8.float()
+    assert float((out_u8 == want8.view(torch.uint8)).float().mean()) >= 0.99
+    assert bool(((got - ref).abs() <= 0.126 * ref.abs() + 2.0 ** -9).all())
+
+
+def test_gemm_fp8_fp8_outputs_at_production_shapes(ops):
+    """gate/up -> down and fc1 -> fc2 hand-overs: the SwiGLU / GELU epilogues write the next GEMM's fp8 operand directly."""
+    from leopard_amd.weights import interleave_gate_up
+    M, F, K = 7187, 14336, 4096
+    g = torch.Generator(device=DEV).manual_seed(97)
+    a8 = torch.randn(M, K, generator=g, device=DEV).to(F8)
+    w8 = (torch.randn(2 * F, K, generator=g, device=DEV) * 0.25).to(F8)
+    ref = (a8.float() @ w8.float().T) * 2.0 ** -6
+    want = torch.nn.functional.silu(ref[:, :F]) * ref[:, F:] * 32.0
+    wi = interleave_gate_up(w8.view(torch.uint8)[:F], w8.view(torch.uint8)[F:])
+    out = torch.zeros(M, F, dtype=torch.uint8, device=DEV)
+
+    def swiglu():
+        out.zero_()
+        ops.gemm_fp8(a8.view(torch.uint8), wi, out, epilogue=_lib.EPI_SWIGLU, scale_exp=-6, out_scale=32.0)
+        return out.clone()
+    _fp8_close(run3(swiglu), want)
+    del ref, want, wi, w8, a8
+    M, N, K = 28392, 4352, 1152
+    a8 = torch.randn(M, K, generator=g, device=DEV).to(F8)
+    w8 = (torch.randn(N, K, generator=g, device=DEV) * 0.25).to(F8)
+    bias = torch.randn(N, generator=g, device=DEV)
+    ref = torch.nn.functional.gelu((a8.float() @ w8.float().T) * 2.0 ** -4 + bias, approximate="tanh")
+    out = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+    ops.gemm_fp8(a8.view(torch.uint8), w8.view(torch.uint8), out, bias=bias, act=_lib.ACT_GELU_TANH, scale_exp=-4, out_scale=16.0)
+    _fp8_close(out, ref * 16.0)
+
+
+@pytest.mark.parametrize("shape", [(7187, 4096), (28392, 1152)])
+def test_norm_fp8_at_production_shapes(ops, shape):
+    M, D = shape
+    g = torch.Generator(device=DEV).manual_seed(98)
+    x = torch.randn(M, D, generator=g, device=DEV) * 3 + 0.5
+    w, b = 1 + 0.1 * torch.randn(D, generator=g, device=DEV), 0.1 * torch.randn(D, generator=g, device=DEV)
+    out = torch.zeros(M, D, dtype=torch.uint8, device=DEV)
+    ops.norm_fp8(x, w, b, out, 1e-6, 16.0)
+    _fp8_close(out, 16.0 * torch.nn.functional.layer_norm(x, (D,), w, b, 1e-6))
+    ops.norm_fp8(x, w, None, out, 1e-5, 8.0)
+    _fp8_close(out, 8.0 * (x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * w))
