@@ -15,12 +15,16 @@ Transports (``Comm``): on GPUs the data path uses RCCL through the C ABI (``Rccl
 lmi_reduce_scatter / lmi_allreduce, stream-ordered, so collectives can run on a side stream under the next GEMM); the
 128-byte RCCL unique id travels over torch.distributed (backend "nccl" = RCCL), which also carries the barriers of bench.py.
 ``TorchComm`` drives the same algorithms over any torch.distributed group — gloo in the CPU tests (emulated kernels) and in the
-functional 2-processes-on-one-GPU test.  There is NO silent fallback: if RCCL cannot come up on a GPU job, ``init`` raises.
+functional 2-processes-on-one-GPU test.  There is NO path from a GPU job to gloo: if RCCL cannot come up, ``init`` raises; if only
+the C-ABI communicator cannot (agreed on by all ranks), the same algorithm runs over torch.distributed's RCCL group and the
+transport name says so (LMI_COMM_STRICT=1 makes that an error too).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
+import warnings
 from typing import List, Optional, Tuple
 
 import torch
@@ -125,48 +129,59 @@ class TorchComm(Comm):
     def __init__(self):
         assert dist.is_initialized()
         self.rank, self.world, self.backend = dist.get_rank(), dist.get_world_size(), dist.get_backend()
+        self._group_backend = self.backend                     # ``backend`` is a display name (get_comm may extend it)
         self.sent_bytes = 0
 
     def _host_staged(self, t):
-        return self.backend == "gloo" and t.device.type == "cuda"
+        return self._group_backend == "gloo" and t.device.type == "cuda"
 
     def ranks_seen(self) -> int:
-        return self.world if self.backend == "nccl" else 0
+        return self.world if self._group_backend == "nccl" else 0
+
+    @staticmethod
+    def _on(stream):
+        """torch.distributed orders a collective against the CURRENT stream: make ``stream`` current, so that the side-stream
+        overlap of the engine holds for this transport as it does for RcclComm."""
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
 
     def all_gather(self, out, inp, stream=None):
         self._count("ag", inp)
-        if self._host_staged(inp):
-            h = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(h, inp.cpu().contiguous())
-            out.copy_(h)
-        else:
-            dist.all_gather_into_tensor(out, inp)
+        with self._on(stream):
+            if self._host_staged(inp):
+                h = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_gather_into_tensor(h, inp.cpu().contiguous())
+                out.copy_(h)
+            else:
+                dist.all_gather_into_tensor(out, inp)
 
     def reduce_scatter(self, out, inp, stream=None):
         self._count("rs", inp)
-        if self._host_staged(inp):
-            h = torch.empty(out.shape, dtype=out.dtype)
-            dist.reduce_scatter_tensor(h, inp.cpu().contiguous())
-            out.copy_(h)
-        else:
-            dist.reduce_scatter_tensor(out, inp)
+        with self._on(stream):
+            if self._host_staged(inp):
+                h = torch.empty(out.shape, dtype=out.dtype)
+                dist.reduce_scatter_tensor(h, inp.cpu().contiguous())
+                out.copy_(h)
+            else:
+                dist.reduce_scatter_tensor(out, inp)
 
     def all_reduce(self, t, stream=None):
         self._count("ar", t)
-        if self._host_staged(t):
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        with self._on(stream):
+            if self._host_staged(t):
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     def broadcast(self, t, root, stream=None):
-        if self._host_staged(t):
-            h = t.cpu()
-            dist.broadcast(h, src=root)
-            t.copy_(h)
-        else:
-            dist.broadcast(t, src=root)
+        with self._on(stream):
+            if self._host_staged(t):
+                h = t.cpu()
+                dist.broadcast(h, src=root)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=root)
 
 
 _LMI_DT = {torch.float16: _lib.LMI_F16, torch.bfloat16: _lib.LMI_BF16, torch.float32: _lib.LMI_F32}
@@ -245,7 +260,30 @@ def get_comm(device=None, lib=None) -> Optional[Comm]:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return None
     if _COMM is None:
-        _COMM = RcclComm(lib=lib, device=device) if dist.get_backend() == "nccl" else TorchComm()
+        if dist.get_backend() != "nccl":
+            _COMM = TorchComm()
+        else:
+            # RCCL through the C ABI.  Whether it came up is agreed on by ALL ranks (a rank that failed must not leave the others
+            # inside ncclCommInitRank's rendezvous with a different transport).  If it did not, the SAME algorithm runs over the
+            # torch.distributed group — which is RCCL as well — and says so in ``backend`` (bench.py prints it); LMI_COMM_STRICT=1
+            # turns that into an error.  There is no path from a GPU job to gloo.
+            comm, err = None, ""
+            try:
+                comm = RcclComm(lib=lib, device=device)
+            except Exception as e:                                   # noqa: BLE001  (re-raised or reported below)
+                err = repr(e)[:300]
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
+                              device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.destroy()
+                if os.environ.get("LMI_COMM_STRICT") == "1":
+                    raise RuntimeError(f"RCCL communicator through the C ABI unavailable on at least one rank: {err or 'other rank'}")
+                warnings.warn(f"lmi_comm_init failed on at least one rank ({err or 'other rank'}): collectives run over torch.distributed's RCCL group")
+                comm = TorchComm()
+                comm.backend = f"rccl (torch.distributed nccl; lmi_comm unavailable: {err or 'failed on another rank'})"
+            _COMM = comm
     return _COMM
 
 
