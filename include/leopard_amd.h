@@ -113,6 +113,29 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
              const int* row_map, int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
              int ps_grid, int dtype, void* stream);
 
+/* SURVEY.md 8(b) names the linear "lmi_gemm_bias_act": the same GEMM behind the short argument list of that row —
+ * act in {LMI_ACT_NONE, LMI_ACT_GELU_TANH, LMI_ACT_GELU_ERF, LMI_ACT_SWIGLU}, residual != 0: out[f32] += result (else out[T] = result),
+ * ps_grid > 0: A gathered through the 2x2 pixel shuffle of a ps_grid x ps_grid token grid (EVAL:165-176). */
+enum { LMI_ACT_SWIGLU = 3 /* lmi_gemm_bias_act only: W rows interleaved [32 gate | 32 up], out width N/2 */ };
+int lmi_gemm_bias_act(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int act,
+                      int residual, int ps_grid, int dtype, void* stream);
+
+/* SURVEY.md 8(b) "lmi_patch_embed" — SiglipVisionEmbeddings (patch convolution 3 -> N with kernel = stride = patch, bias, + position
+ * embedding; inside self.vision_tower(...), EVAL:268) fused with SiglipImageProcessor's rescale / normalise (EVAL:403-405) as ONE
+ * im2col + MFMA GEMM: each k-tile stages a slice of the patches' pixel rows from the image into LDS (normalised with the
+ * processor's exact arithmetic, rounded to T) — no im2col matrix in HBM.  pixels: u8 [n_tiles, S, S, 3] (from_u8 = 1; the GPU
+ * tiler's output) or fp32 [n_tiles, 3, S, S] pixel_values (from_u8 = 0): both give bit-identical results.  W: T [N, ldw] with
+ * K in IMAGE order, k = ky * RP + kx * 3 + c, RP = roundup(3 * patch, 8), zero in the pad positions, ldw >= roundup(patch * RP, 64)
+ * (leopard_amd/weights.py: patch_w_fused); pos_emb fp32 [(S/patch)^2, N]; out fp32 [n_tiles * (S/patch)^2, ldo].  N % 128 == 0. */
+int lmi_patch_embed(const void* pixels, int from_u8, const void* W, const float* bias, const float* pos_emb, float* out, int n_tiles,
+                    int image_size, int patch, int N, int ldw, int ldo, int dtype, void* stream);
+
+/* SURVEY.md 8(b) "lmi_kv_append" — the cache update of the decode branch (EVAL:291-320) for rows that are already rotated:
+ * k_cache / v_cache rows [cache_pos0, cache_pos0 + S) = k / v rows [0, S) (T, `width` = n_kv_heads * head_dim elements).  Used to
+ * move a packed batch's K/V from the pooled prefill cache into per-sample caches (LeopardEngine.generate_batch). */
+int lmi_kv_append(const void* k, const void* v, void* k_cache, void* v_cache, int S, int width, int ld_src, int ld_cache, int cache_pos0,
+                  int dtype, void* stream);
+
 /* RMSNorm folded into the GEMMs around it (north_star "fused RMSNorm + RoPE"; RMSNorm = megatron/legacy/model/rms_norm.py:26-31,
  * call sites megatron_patch/model/llava/transformer.py:1208-1340).  lmi_gemm restricted to plain A, plus:
  *   producer (epilogue LMI_EPI_RESIDUAL, norm_out != null): after x += acc + bias it also writes

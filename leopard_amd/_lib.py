@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libleopard_amd.so")
 
 LMI_F16, LMI_BF16, LMI_F32, LMI_FP8 = 0, 1, 2, 3
 EPI_STORE, EPI_RESIDUAL, EPI_STORE_F32, EPI_SWIGLU, EPI_QKV_ROPE = 0, 1, 2, 3, 4
-ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3      # ACT_SWIGLU: lmi_gemm_bias_act only
 A_PLAIN, A_PIXEL_SHUFFLE = 0, 1
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -36,6 +36,9 @@ SIGNATURES = {
     "lmi_quantize_fp8": [_P, _I, _P, _I, _I, _I, _I, _F, _P],
     "lmi_gemm_fp8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "lmi_norm_fp8": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
+    "lmi_gemm_bias_act": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_patch_embed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_kv_append": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lmi_attn_varlen_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
     "lmi_rope_qk": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     "lmi_rope_qk_at": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],

@@ -9,6 +9,7 @@
 
 #include "attention.h"
 #include "elementwise.h"
+#include "patch_embed.h"
 #include "gemm.h"
 
 using namespace lmi;
@@ -314,6 +315,26 @@ int rope_impl(void* qkv, int S, int ld, int nq, int nkv, int D, const float* c, 
     return check_launch("lmi_rope_qk");
 }
 template <typename T>
+int patch_embed_impl(const PatchEmbedArgs& a, int from_u8, void* stream) {
+    static std::atomic<uint64_t> done_u8{0}, done_f32{0};
+    const int grid = ((a.M + PE_BM - 1) / PE_BM) * (a.N / PE_BN);
+    if (from_u8) {
+        allow_big_lds(patch_embed_kernel<T, true>, PE_SMEM, done_u8);
+        LMI_LAUNCH((patch_embed_kernel<T, true>), dim3(grid), dim3(256), PE_SMEM, stream, a);
+    } else {
+        allow_big_lds(patch_embed_kernel<T, false>, PE_SMEM, done_f32);
+        LMI_LAUNCH((patch_embed_kernel<T, false>), dim3(grid), dim3(256), PE_SMEM, stream, a);
+    }
+    return check_launch("lmi_patch_embed");
+}
+template <typename T>
+int kv_append_impl(const void* k, const void* v, void* kc, void* vc, int S, int width, int ld_src, int ld_cache, int pos0, void* stream) {
+    const long total = (long)S * (width >> 3) * 2;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    LMI_LAUNCH((kv_append_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)k, (const T*)v, (T*)kc, (T*)vc, S, width, ld_src, ld_cache, pos0);
+    return check_launch("lmi_kv_append");
+}
+template <typename T>
 int merge_impl(const int64_t* ids, const int64_t* src, const void* table, const float* feats, float* out, int S, int D,
                int ld_feats, void* stream) {
     LMI_LAUNCH((embed_merge_kernel<T>), dim3(S), dim3(256), 0, stream, (const long*)ids, (const long*)src, (const T*)table,
@@ -445,6 +466,37 @@ int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, in
     return lmi_preprocess_images(in, from_u8, out, n_tiles, image_size, image_size, patch, ldo, dtype, stream);
 }
 
+int lmi_patch_embed(const void* pixels, int from_u8, const void* W, const float* bias, const float* pos_emb, float* out, int n_tiles,
+                    int image_size, int patch, int N, int ldw, int ldo, int dtype, void* stream) {
+    if (!pixels || !W || !bias || !pos_emb || !out) return fail(LMI_EINVAL, "lmi_patch_embed: null pointer");
+    if (n_tiles < 0 || image_size <= 0 || patch <= 0 || image_size % patch || N <= 0 || (N % 128) || (ldo & 3) || ldo < N)
+        return fail(LMI_EINVAL, "lmi_patch_embed: bad shape (n=%d S=%d P=%d N=%d ldo=%d; S %% P == 0, N %% 128 == 0)", n_tiles, image_size, patch, N, ldo);
+    PatchEmbedArgs a;
+    a.pix = pixels; a.W = W; a.bias = bias; a.pos = pos_emb; a.out = out;
+    a.S = image_size; a.P = patch; a.G = image_size / patch; a.N = N;
+    a.RP = (3 * patch + 7) & ~7;
+    a.KP = (patch * a.RP + 63) & ~63;
+    a.ldw = ldw; a.ldo = ldo;
+    const long M = (long)n_tiles * a.G * a.G;
+    if (M > 0x7fffffffL) return fail(LMI_EINVAL, "lmi_patch_embed: too many patches");
+    a.M = (int)M;
+    if (ldw < a.KP || (ldw & 7) || !aligned16(W) || !aligned16(out) || !aligned16(bias) || !aligned16(pos_emb))
+        return fail(LMI_EINVAL, "lmi_patch_embed: weight rows must hold %d elements ((ky, kx, c) order, pixel rows padded to %d) and be 16-byte aligned",
+                    a.KP, a.RP);
+    if (M == 0) return LMI_OK;
+    LMI_DISPATCH_T(dtype, patch_embed_impl<f16_t>(a, from_u8, stream), patch_embed_impl<bf16_t>(a, from_u8, stream));
+}
+
+int lmi_kv_append(const void* k, const void* v, void* k_cache, void* v_cache, int S, int width, int ld_src, int ld_cache, int cache_pos0,
+                  int dtype, void* stream) {
+    if (!k || !v || !k_cache || !v_cache || S < 0 || width <= 0 || (width & 7) || (ld_src & 7) || (ld_cache & 7) || cache_pos0 < 0 ||
+        !aligned16(k) || !aligned16(v) || !aligned16(k_cache) || !aligned16(v_cache))
+        return fail(LMI_EINVAL, "lmi_kv_append: bad argument (S=%d width=%d ld_src=%d ld_cache=%d pos0=%d)", S, width, ld_src, ld_cache, cache_pos0);
+    if (S == 0) return LMI_OK;
+    LMI_DISPATCH_T(dtype, kv_append_impl<f16_t>(k, v, k_cache, v_cache, S, width, ld_src, ld_cache, cache_pos0, stream),
+                   kv_append_impl<bf16_t>(k, v, k_cache, v_cache, S, width, ld_src, ld_cache, cache_pos0, stream));
+}
+
 int lmi_layernorm(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps,
                   int dtype, void* stream) {
     if (dtype == LMI_F32) return norm_impl<float, false>(x, w, b, out, M, D, ldx, ldo, eps, stream, "lmi_layernorm");
@@ -534,6 +586,15 @@ int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const f
     if (epilogue == LMI_EPI_QKV_ROPE) return fail(LMI_EINVAL, "lmi_gemm: the q|k|v + RoPE epilogue is reached through lmi_rmsnorm_rope");
     return gemm_entry("lmi_gemm", A, W, out, bias, addmat, add_rows, row_map, M, N, K, lda, ldw, ldo, add_period, epilogue, act, a_mode, ps_grid,
                       dtype, stream, GemmExtras());
+}
+
+int lmi_gemm_bias_act(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int act,
+                      int residual, int ps_grid, int dtype, void* stream) {
+    if (act < LMI_ACT_NONE || act > LMI_ACT_SWIGLU || (act == LMI_ACT_SWIGLU && residual))
+        return fail(LMI_EINVAL, "lmi_gemm_bias_act: act must be LMI_ACT_NONE / GELU_TANH / GELU_ERF / SWIGLU (SwiGLU has no residual form)");
+    const int epilogue = residual ? LMI_EPI_RESIDUAL : (act == LMI_ACT_SWIGLU ? LMI_EPI_SWIGLU : LMI_EPI_STORE);
+    return gemm_entry("lmi_gemm_bias_act", A, W, out, bias, nullptr, nullptr, nullptr, M, N, K, lda, ldw, ldo, 0, epilogue,
+                      act == LMI_ACT_SWIGLU ? LMI_ACT_NONE : act, ps_grid > 0 ? LMI_A_PIXEL_SHUFFLE : LMI_A_PLAIN, ps_grid, dtype, stream, GemmExtras());
 }
 
 int lmi_gemm_ex(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,

@@ -58,6 +58,25 @@ __global__ void im2col_kernel(const void* in, T* out, int n_tiles, int H, int W,
 }
 
 // ------------------------------------------------------------------------------------------------
+// K / V rows -> cache rows [pos0, pos0 + S): the cache update of EVAL:291-320 without a rotation (rows that are already
+// rotated: moving a packed batch's K/V from the pooled prefill cache into per-sample caches, chunked TP prefill)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void kv_append_kernel(const T* k, const T* v, T* k_cache, T* v_cache, int S, int width, int ld_src, int ld_cache, int pos0) {
+    typedef typename vec_of<T>::x8 T8;
+    const int cpr = width >> 3;
+    const long total = (long)S * cpr * 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int which = (int)(i / ((long)S * cpr));
+        const long j = i - (long)which * S * cpr;
+        const int s = (int)(j / cpr), c = (int)(j - (long)s * cpr);
+        const T* src = (which ? v : k) + (long)s * ld_src + c * 8;
+        T* dst = (which ? v_cache : k_cache) + (long)(pos0 + s) * ld_cache + c * 8;
+        *(T8*)dst = *(const T8*)src;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One pass of Pillow's antialiased resampling for 8-bit RGB (a3 / a5: Image.resize inside resize_and_pad_image,
 // EVAL:102-140, and the thumbnail squash of SiglipImageProcessor, EVAL:403-404).  Bit-identical to libImaging
 // ImagingResampleHorizontal_8bpc / Vertical_8bpc: 22-bit fixed-point taps from the host (leopard_amd/tiler.py

@@ -185,11 +185,9 @@ class LeopardEngine:
         n = tiles.shape[0]
         T, D, H, hd = vc.num_patches, vc.hidden_size, vc.num_attention_heads, vc.head_dim
         M = n * T
-        patches = self._empty(M, W.patch_k)
-        ops.preprocess_tiles(tiles, patches, vc.image_size, vc.patch_size)
         x = self._empty(M, D, dtype=torch.float32)
-        ops.gemm(patches, W.patch_w, x, bias=W.patch_b, addmat=W.pos_emb, epilogue=_lib.EPI_STORE_F32)
-        del patches
+        # normalise + im2col + patch conv + bias + position embedding: one launch, no im2col matrix in HBM (lmi_patch_embed)
+        ops.patch_embed(tiles, W.patch_w_fused, W.patch_b, W.pos_emb, x, vc.image_size, vc.patch_size)
         cu = self._vit_cu_cache.get(n)
         if cu is None:
             cu = self._vit_cu_cache[n] = torch.arange(0, (n + 1) * T, T, dtype=torch.int32, device=self.device)
@@ -845,8 +843,7 @@ class LeopardEngine:
         for (ids, _), S, nxt in zip(samples, seq_lens, first):
             cache = KVCache(self.cfg, S + max_new_tokens, self.dtype, self.device)
             for i in range(len(cache.k)):
-                cache.k[i][:S].copy_(pool.k[i][off:off + S])
-                cache.v[i][:S].copy_(pool.v[i][off:off + S])
+                self.ops.kv_append(pool.k[i][off:off + S], pool.v[i][off:off + S], cache.k[i], cache.v[i], 0)
             cache.length = S
             off += S
             out = self._greedy_loop([int(t) for t in ids.reshape(-1).tolist()], nxt, cache, max_new_tokens, eos)

@@ -57,6 +57,36 @@ class Ops:
                                                   out.shape[1], _DT[out.dtype], self._stream(out)))
         return out
 
+    def patch_embed(self, pixels: torch.Tensor, w_fused: torch.Tensor, bias: torch.Tensor, pos_emb: torch.Tensor, out: torch.Tensor,
+                    image_size: int, patch: int):
+        """out fp32 [n*(S/P)^2, N] = conv(normalise(pixels)) + bias + pos_emb in ONE im2col + MFMA GEMM (lmi_patch_embed).
+        pixels: u8 [n,S,S,3] or fp32 [n,3,S,S]; w_fused: T [N, KP] in image K order (weights.patch_weight_image_order)."""
+        from_u8 = pixels.dtype == torch.uint8
+        assert pixels.is_contiguous() and out.is_contiguous() and (from_u8 or pixels.dtype == torch.float32) and out.dtype == torch.float32
+        self._check(self.lib.lmi_patch_embed(_ptr(pixels), int(from_u8), _ptr(w_fused), _ptr(bias), _ptr(pos_emb), _ptr(out), pixels.shape[0],
+                                             image_size, patch, w_fused.shape[0], w_fused.stride(0), out.stride(0), _DT[w_fused.dtype],
+                                             self._stream(out)))
+        return out
+
+    def kv_append(self, k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos0: int):
+        """cache rows [pos0, pos0 + S) = k / v rows (already rotated K; lmi_kv_append)."""
+        S, width = k.shape
+        if S == 0:
+            return
+        assert v.shape == k.shape and k.stride(1) == 1 and v.stride(1) == 1 and k.stride(0) == v.stride(0)
+        assert k_cache.stride(0) == v_cache.stride(0) and pos0 + S <= k_cache.shape[0]
+        self._check(self.lib.lmi_kv_append(_ptr(k), _ptr(v), _ptr(k_cache), _ptr(v_cache), S, width, k.stride(0), k_cache.stride(0), int(pos0),
+                                           _DT[k.dtype], self._stream(k)))
+
+    def gemm_bias_act(self, a, w, out, bias=None, act=ACT_NONE, residual=False, ps_grid=0, M=None):
+        """SURVEY.md 8(b)'s short form of the linear (lmi_gemm_bias_act)."""
+        N, K = w.shape
+        if M is None:
+            M = a.shape[0]
+        self._check(self.lib.lmi_gemm_bias_act(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), M, N, K, a.stride(0), w.stride(0), out.stride(0), act,
+                                               int(bool(residual)), int(ps_grid), _DT[w.dtype], self._stream(out)))
+        return out
+
     def preprocess_images(self, src: torch.Tensor, out: torch.Tensor, patch: int):
         """src: u8 [n,H,W,3] or fp32 [n,3,H,W] (one size); out: T [n*(H//P)*(W//P), ldo]."""
         from_u8 = src.dtype == torch.uint8

@@ -72,6 +72,19 @@ def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return torch.stack([gate.view(F // 32, 32, K), up.view(F // 32, 32, K)], dim=1).reshape(2 * F, K).contiguous()
 
 
+def patch_weight_image_order(w: torch.Tensor, patch: int) -> torch.Tensor:
+    """Conv weight [D, 3, P, P] -> [D, KP] in the K order lmi_patch_embed stages pixels in: k = ky * RP + kx * 3 + c (the byte order
+    of an HWC image row), every pixel row padded from 3P to RP = roundup(3P, 8) and the whole row to a multiple of 64, zeros in
+    the pad positions."""
+    D = w.shape[0]
+    rp = (3 * patch + 7) & ~7
+    kp = _round_up(patch * rp, 64)
+    rows = w.reshape(D, 3, patch, patch).permute(0, 2, 3, 1).reshape(D, patch, 3 * patch)        # [D, ky, (kx, c)]
+    out = torch.zeros(D, kp, dtype=w.dtype, device=w.device)
+    out[:, :patch * rp].view(D, patch, rp)[:, :, :3 * patch] = rows
+    return out
+
+
 def rope_permute_rows(w: torch.Tensor, head_dim: int = 128) -> torch.Tensor:
     """Row order of the q / k projection weights for lmi_rmsnorm_rope: inside every head the rows d = 0..127 are stored as
     [0..31, 64..95, 32..63, 96..127], so that each 64-column slice of the GEMM output that one wave owns holds 32 first-half
@@ -152,7 +165,8 @@ def check_tp_degree(tc, tp_size: int) -> None:
 class EngineWeights:
     cfg: LeopardConfig
     dtype: torch.dtype
-    patch_w: torch.Tensor = None; patch_b: torch.Tensor = None; pos_emb: torch.Tensor = None
+    patch_w_fused: torch.Tensor = None     # the conv weight in lmi_patch_embed's image K order (patch_weight_image_order)
+    patch_b: torch.Tensor = None; pos_emb: torch.Tensor = None
     vit_layers: List[VitLayerW] = field(default_factory=list)
     post_ln_w: torch.Tensor = None; post_ln_b: torch.Tensor = None
     proj1_w: torch.Tensor = None; proj1_b: torch.Tensor = None
@@ -162,7 +176,6 @@ class EngineWeights:
     final_norm: torch.Tensor = None
     lm_head: torch.Tensor = None
     # padded geometry
-    patch_k: int = 0        # im2col K padded to 64
     vit_ff: int = 0         # fc1 width padded to 128
     llm_ff: int = 0
     # tensor-parallel shard of the LLM (1 = whole model): local head counts, llm_ff is the local FFN slice
@@ -188,11 +201,10 @@ class EngineWeights:
             raise ValueError("LLM FFN width must be a multiple of 64")
         g = source.get
         v = "vision_tower.vision_model."
-        W.patch_k = _round_up(vc.patch_dim, 64)
         W.vit_ff = _round_up(vc.intermediate_size, 128)
         W.llm_ff = tc.intermediate_size // tp_size
         W.llm_heads, W.llm_kv_heads = tc.num_attention_heads // tp_size, tc.num_key_value_heads // tp_size
-        W.patch_w = _pad2(g(v + "embeddings.patch_embedding.weight").reshape(vc.hidden_size, -1), vc.hidden_size, W.patch_k)
+        W.patch_w_fused = patch_weight_image_order(g(v + "embeddings.patch_embedding.weight"), vc.patch_size)
         W.patch_b = _pad1(g(v + "embeddings.patch_embedding.bias"), vc.hidden_size)
         W.pos_emb = g(v + "embeddings.position_embedding.weight").to(torch.float32).contiguous()
         for i in range(vc.num_hidden_layers):

@@ -57,7 +57,7 @@ def test_synth_source_equals_tensor_source(setup):
     b = EngineWeights.build(cfg, TensorSource(Wn, "cpu", torch.float16), torch.float16)
     assert torch.equal(a.vit_layers[0].qkv_w, b.vit_layers[0].qkv_w)
     assert torch.equal(a.llm_layers[1].gu_w, b.llm_layers[1].gu_w)
-    assert torch.equal(a.patch_w, b.patch_w) and a.patch_w.shape[1] == 640
+    assert torch.equal(a.patch_w_fused, b.patch_w_fused) and a.patch_w_fused.shape[1] == 704         # 14 pixel rows x 48, padded to 64s
     assert a.vit_ff == 128 and a.vit_layers[0].fc1_w.shape == (128, 1152)
     assert torch.equal(a.lm_head, b.lm_head) and torch.equal(a.pos_emb, b.pos_emb)
 

@@ -502,3 +502,67 @@ def test_norm_fp8_at_production_shapes(ops, shape):
     _fp8_close(out, 16.0 * torch.nn.functional.layer_norm(x, (D,), w, b, 1e-6))
     ops.norm_fp8(x, w, None, out, 1e-5, 8.0)
     _fp8_close(out, 8.0 * (x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * w))
+
+
+# ---- lmi_patch_embed (fused normalise + im2col + patch conv + bias + pos-emb) at the C3 shape ----------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patch_embed_at_production_shape(ops, dtype):
+    """42 ViT inputs of 364 x 364 -> 28392 patch rows x 1152: against conv2d over the processor-normalised pixels rounded to the
+    operand type; u8 tiles and fp32 pixel_values bit-identical; three launches bit-identical; and against the unfused pair
+    (lmi_preprocess_tiles + lmi_gemm) it replaced, timed."""
+    from leopard_amd.weights import patch_weight_image_order
+    n, S, P, N = 42, 364, 14, 1152
+    G = S // P
+    g = torch.Generator(device=DEV).manual_seed(99)
+    u8 = torch.randint(0, 256, (n, S, S, 3), generator=g, device=DEV, dtype=torch.uint8)
+    w = (torch.randn(N, 3, P, P, generator=g, device=DEV) * 0.05).to(dtype)
+    bias, pos = torch.randn(N, generator=g, device=DEV), torch.randn(G * G, N, generator=g, device=DEV)
+    wf = patch_weight_image_order(w, P)
+    out = torch.empty(n * G * G, N, device=DEV)
+
+    def fused():
+        out.fill_(float("nan"))
+        ops.patch_embed(u8, wf, bias, pos, out, S, P)
+        return out.clone()
+    o = run3(fused)
+    pix = (u8.float() * (1.0 / 255.0) - 0.5) * 2.0                              # == the processor (mul, sub, mul; no contraction in eager torch)
+    pix = pix.permute(0, 3, 1, 2).contiguous()
+    ref = torch.nn.functional.conv2d(pix.to(dtype).float(), w.float(), bias, stride=P).flatten(2).transpose(1, 2).reshape(n * G * G, N)
+    ref = ref + pos.repeat(n, 1)
+    assert (o - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+    o32 = torch.empty_like(o)
+    ops.patch_embed(pix, wf, bias, pos, o32, S, P)
+    assert torch.equal(o32, o)
+    # the pair it replaced: im2col matrix in HBM + GEMM
+    kp = 640
+    w2 = torch.zeros(N, kp, dtype=dtype, device=DEV)
+    w2[:, :588] = w.reshape(N, -1)
+    patches = torch.empty(n * G * G, kp, dtype=dtype, device=DEV)
+    o2 = torch.empty_like(o)
+
+    def pair():
+        ops.preprocess_tiles(u8, patches, S, P)
+        ops.gemm(patches, w2, o2, bias=bias, addmat=pos, epilogue=_lib.EPI_STORE_F32)
+    pair()
+    assert (o2 - o).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+
+    def timed(fn, reps=20):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    t_f, t_p = timed(lambda: ops.patch_embed(u8, wf, bias, pos, out, S, P)), timed(pair)
+    print(f"[patch embed {dtype}] fused {t_f:.1f} us  ({2.0 * n * G * G * N * 588 / t_f / 1e6:.0f} TFLOP/s algorithmic)   unfused pair {t_p:.1f} us")
+
+
+def test_kv_append_on_device(ops):
+    g = torch.Generator(device=DEV).manual_seed(100)
+    pk, pv = torch.randn(9000, 1024, generator=g, device=DEV).half(), torch.randn(9000, 1024, generator=g, device=DEV).half()
+    kc, vc = torch.zeros(7400, 1024, dtype=torch.float16, device=DEV), torch.zeros(7400, 1024, dtype=torch.float16, device=DEV)
+    ops.kv_append(pk[1000:8187], pv[1000:8187], kc, vc, 100)
+    assert torch.equal(kc[100:7287], pk[1000:8187]) and torch.equal(vc[100:7287], pv[1000:8187])
+    assert bool((kc[:100] == 0).all()) and bool((kc[7287:] == 0).all())
