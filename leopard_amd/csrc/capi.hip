@@ -476,6 +476,7 @@ int lmi_patch_embed(const void* pixels, int from_u8, const void* W, const float*
     a.S = image_size; a.P = patch; a.G = image_size / patch; a.N = N;
     a.RP = (3 * patch + 7) & ~7;
     a.KP = (patch * a.RP + 63) & ~63;
+    if (a.KP / PE_BK > PE_MAX_KT) return fail(LMI_EINVAL, "lmi_patch_embed: patch size %d is beyond the kernel's gather table", patch);
     a.ldw = ldw; a.ldo = ldo;
     const long M = (long)n_tiles * a.G * a.G;
     if (M > 0x7fffffffL) return fail(LMI_EINVAL, "lmi_patch_embed: too many patches");

@@ -54,6 +54,27 @@ def test_patch_embed_matches_conv2d(ops, dtype, n, S, N):
     assert torch.equal(out32, out)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_patch_embed_every_byte_value_matches_the_processor(ops, dtype):
+    """All 256 pixel values through the kernel's u8 -> operand conversion (f16: one FMA, proven here to give the processor's
+    16-bit value for every input; bf16: the processor's three-step arithmetic): identity weights read the operands back."""
+    P, S, N = 14, 28, 640
+    vals = torch.arange(4 * 588, dtype=torch.int64) % 256                      # 4 patches x 588 pixel values: every byte 9 times
+    u8 = torch.zeros(1, S, S, 3, dtype=torch.uint8)
+    for m in range(4):
+        py, px = divmod(m, 2)
+        u8[0, py * P:(py + 1) * P, px * P:(px + 1) * P, :] = vals[m * 588:(m + 1) * 588].reshape(P, P, 3).to(torch.uint8)
+    w = torch.zeros(N, 3, P, P)
+    for k in range(588):                                                        # output column k = pixel (ky, kx, c) of the patch
+        ky, r = divmod(k, 42)
+        kx, c = divmod(r, 3)
+        w[k, c, ky, kx] = 1.0
+    out = torch.empty(4, N)
+    ops.patch_embed(u8, patch_weight_image_order(w.to(dtype), P), torch.zeros(N), torch.zeros(4, N), out, S, P)
+    want = torch.from_numpy(siglip_normalize(np.arange(256, dtype=np.uint8).reshape(1, 16, 16, 1).repeat(3, axis=3)))[0, 0].reshape(256).to(dtype).float()
+    assert torch.equal(out[:, :588].reshape(-1), want[vals])
+
+
 def test_patch_embed_rejects_bad_arguments(ops):
     u8 = torch.zeros(1, 28, 28, 3, dtype=torch.uint8)
     wf = torch.zeros(128, 704, dtype=torch.float16)
