@@ -469,8 +469,9 @@ int lmi_preprocess_tiles(const void* in, int from_u8, void* out, int n_tiles, in
 int lmi_patch_embed(const void* pixels, int from_u8, const void* W, const float* bias, const float* pos_emb, float* out, int n_tiles,
                     int image_size, int patch, int N, int ldw, int ldo, int dtype, void* stream) {
     if (!pixels || !W || !bias || !pos_emb || !out) return fail(LMI_EINVAL, "lmi_patch_embed: null pointer");
-    if (n_tiles < 0 || image_size <= 0 || patch <= 0 || image_size % patch || N <= 0 || (N % 128) || (ldo & 3) || ldo < N)
-        return fail(LMI_EINVAL, "lmi_patch_embed: bad shape (n=%d S=%d P=%d N=%d ldo=%d; S %% P == 0, N %% 128 == 0)", n_tiles, image_size, patch, N, ldo);
+    if (n_tiles < 0 || image_size <= 0 || patch < 3 || image_size % patch || N <= 0 || (N % 128) || (ldo & 3) || ldo < N)
+        return fail(LMI_EINVAL, "lmi_patch_embed: bad shape (n=%d S=%d P=%d N=%d ldo=%d; P >= 3, S %% P == 0, N %% 128 == 0)", n_tiles, image_size, patch, N,
+                    ldo);
     PatchEmbedArgs a;
     a.pix = pixels; a.W = W; a.bias = bias; a.pos = pos_emb; a.out = out;
     a.S = image_size; a.P = patch; a.G = image_size / patch; a.N = N;

@@ -179,7 +179,7 @@ class LeopardEngine:
     # ------------------------------------------------------------------------------------------------
     # a5 + a7: vision tower
     # ------------------------------------------------------------------------------------------------
-    def vision_tower(self, tiles: torch.Tensor, shard: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    def vision_tower(self, tiles: torch.Tensor) -> torch.Tensor:
         """tiles: u8 [N,S,S,3] (HWC) or fp32 pixel_values [N,3,S,S].  Returns post-LN features T [N*T, D]."""
         ops, W, vc = self.ops, self.W, self.cfg.vision_config
         n = tiles.shape[0]
