@@ -16,6 +16,7 @@ from leopard_amd.synth import synth_image_u8, synth_prompt_ids  # noqa: E402
 from leopard_amd.weights import EngineWeights, SynthSource  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+fp8 = len(sys.argv) > 2 and sys.argv[2] == "fp8"          # the fp8 schedule (leopard_amd.fp8) instead of the f16 one
 dev = torch.device("cuda:0")
 cfg = full_config()
 ops = Ops()
@@ -23,6 +24,9 @@ eng = LeopardEngine(cfg, EngineWeights.build(cfg, SynthSource(cfg, ops, dev, tor
 tiles, plan = GpuTiler(ops, dev).tile_sample([synth_image_u8(i, 1344, 896) for i in range(6)])
 ids = torch.from_numpy(synth_prompt_ids(plan.vit_inputs_per_image, cfg, seed=0)).reshape(1, -1)
 S = ids.shape[1] + tiles.shape[0] * (cfg.tokens_per_tile - 1)
+if fp8:
+    ctiles, cplan = GpuTiler(ops, dev).tile_sample([synth_image_u8(90 + i, 1344, 896) for i in range(2)])
+    eng.enable_fp8([(torch.from_numpy(synth_prompt_ids(cplan.vit_inputs_per_image, cfg, seed=9)).reshape(1, -1), ctiles)])
 ref, ref_dec, bad = None, None, 0
 for r in range(reps):
     cache = KVCache(cfg, S + 8, torch.float16, dev)
@@ -37,5 +41,5 @@ for r in range(reps):
         bad += 0 if same else 1
         if not same:
             print(f"rep {r}: MISMATCH max|d| prefill {float((ref - res.logits_last).abs().max()):.3e}")
-print(f"{reps} repetitions, {bad} mismatches")
+print(f"{'fp8' if fp8 else 'f16'} schedule: {reps} repetitions, {bad} mismatches")
 sys.exit(1 if bad else 0)
