@@ -490,7 +490,7 @@ def main():
         gpu_tiler.tile_sample(raw)                                 # warm (tap tables, allocator)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        c.raw = [torch.from_numpy(np.ascontiguousarray(r)).to(dev) for r in raw]   # source pixels resident in HBM before the timed region
+        c.raw = [torch.from_numpy(np.array(r)).to(dev) for r in raw]   # source pixels resident in HBM before the timed region (np.array: a writable copy)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         c.tiles, _ = gpu_tiler.tile_sample(c.raw)                  # the tiler on the GPU (a3-a5), from resident source pixels
@@ -558,7 +558,8 @@ def main():
                                "prefill to last-token logits, KV cache written; synthetic seeded weights",
                    "samples_per_rank_per_step": args.inflight, "samples_in_flight_per_gpu": args.inflight,
                    "parallelism": f"sample-sharded x{world} (the reference's scheme: one process per GPU over dataset shards, no data-path collective)"},
-        "backend": ("rccl (torch.distributed nccl): barrier + timing reduce only" if world > 1 else "none"),
+        "backend": ((("rccl (torch.distributed nccl)" if D.backend_name() == "nccl" else D.backend_name()) + ": barrier + timing reduce only")
+                    if world > 1 else "none"),
         "rccl_ranks": (world if world > 1 and D.backend_name() == "nccl" else 0), "comm_bytes_per_step": 0,
         "visual_tokens_per_s": round(world * args.inflight * n_tiles * cfg.tokens_per_tile * args.steps / elapsed, 1),
         "algorithmic_tflop_per_step": round(args.inflight * fl["total"] / 1e12, 2),
