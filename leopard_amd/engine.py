@@ -114,7 +114,7 @@ class LeopardEngine:
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
-        self.fp8 = None                # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
+        self._fp8 = None               # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
         self._rec = None               # calibration recorder callable((tower, layer, site), operand tensor)
         tc = cfg.text_config
         self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
@@ -122,6 +122,16 @@ class LeopardEngine:
         self._vit_cu_cache: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------
+    @property
+    def fp8(self):
+        return self._fp8
+
+    @fp8.setter
+    def fp8(self, plan):
+        """Switching the schedule invalidates the captured vision-encode graphs (they replay the launches of the old one)."""
+        self._fp8 = plan
+        self._encode_graphs.clear()
+
     @property
     def tp_size(self) -> int:
         return getattr(self.W, "tp_size", 1)
@@ -255,7 +265,6 @@ class LeopardEngine:
         activation scales from a 16-bit prefill of ``calibration_samples`` [(input_ids, tiles)].  ``engine.fp8 = None`` reverts."""
         from . import fp8 as F8
         self.fp8 = F8.calibrate(self, calibration_samples, headroom)
-        self._encode_graphs.clear()
         return self.fp8
 
     # ------------------------------------------------------------------------------------------------

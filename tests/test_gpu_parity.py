@@ -226,8 +226,14 @@ def test_mid_config_fp8_vs_oracle(ops, mid_oracle):
     assert r > 3 * r16                                       # the fp8 schedule ran
     assert 0.7 * vpr <= vr <= 1.4 * vpr and 0.7 * pr <= r <= 1.4 * pr
     assert r2 <= 1.8 * pr
+    # the captured vision encode follows the schedule: graphs taken under fp8 replay fp8, and are dropped when the plan is removed
+    eng.graph_encode = True
+    t8 = torch.from_numpy(u8).to(DEV)
+    for _ in range(2):
+        assert torch.equal(eng.prefill(ids.to(DEV), t8, all_logits=True).logits_all, res.logits_all)
     eng.fp8 = None
-    assert torch.equal(eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV), all_logits=True).logits_all.cpu(), base)
+    for _ in range(2):
+        assert torch.equal(eng.prefill(ids.to(DEV), t8, all_logits=True).logits_all.cpu(), base)
 
 
 def test_full_depth_fp8_c1_vs_oracle(ops, full_depth_oracle):
