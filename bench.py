@@ -234,6 +234,16 @@ def enable_fp8(eng, cfg, args):
     torch.cuda.empty_cache()
 
 
+def config_label(args) -> str:
+    """BASELINE.json configuration the image arguments correspond to (C3 = the metric's own, the default)."""
+    key = (args.images, args.width, args.height)
+    return {(6, 1344, 896): "C3", (1, 1344, 896): "C2", (1, 336, 336): "C1"}.get(key, "custom")
+
+
+def metric_name(args) -> str:
+    return f"multi-image prefill images/sec (Leopard-LLaVA, {args.images}x{args.width}x{args.height} per sample)"
+
+
 def bench_c5(args, dev, dtype, rank, world, D):
     """BASELINE config 5 shape: a batch of 8 samples x 8 images of 1344x896 (40 ViT inputs and 6861 tokens per sample), all 8
     samples in ONE packed pass (LeopardEngine.prefill_batch), 16-bit compute (the fp8 variant of that config is not built)."""
@@ -440,6 +450,9 @@ def main():
     from leopard_amd.ops import Ops
     from leopard_amd.weights import EngineWeights, SynthSource
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    for kv in args.opt:                                            # library options are process-wide: set them before any workload
+        k, v = kv.split("=")
+        Ops().set_option(k, int(v))
     if args.dtype == "fp8" and (args.workload == "idefics2-c4" or args.parallelism == "tp"):
         raise SystemExit("--dtype fp8 is built for the Leopard-LLaVA replica path (llava-c3 / llava-c5)")
     if args.workload == "idefics2-c4":
@@ -448,18 +461,15 @@ def main():
         return bench_c5(args, dev, dtype, rank, world, D)
     cfg = full_config()
     ops = Ops()
-    for kv in args.opt:
-        k, v = kv.split("=")
-        ops.set_option(k, int(v))
     t0 = time.perf_counter()
     tp = args.parallelism == "tp" and world > 1
     from leopard_amd.gpu_tiler import GpuTiler
     if tp:                                       # headline = ONE sample on all ranks
         r = measure_tp(args, cfg, ops, dev, dtype, rank, world, D, GpuTiler(ops, dev))
-        out = {"metric": "multi-image prefill images/sec (Leopard-LLaVA, 6x1344x896 per sample)", "value": r["value"], "unit": "images/s",
+        out = {"metric": metric_name(args), "value": r["value"], "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"C3: {args.images}x({args.width}x{args.height}) images, one sample per step on all ranks",
+               "config": {"workload": f"{config_label(args)}: {args.images}x({args.width}x{args.height}) images, one sample per step on all ranks",
                           "parallelism": r["parallelism"]},
                "backend": r["backend"], "rccl_ranks": r["rccl_ranks"], "comm_bytes_per_step": r["comm_bytes_per_step_per_rank"] * world,
                "tp": r}
@@ -547,13 +557,13 @@ def main():
     fl = algorithmic_flops(cfg, n_tiles, S)
 
     out = {
-        "metric": "multi-image prefill images/sec (Leopard-LLaVA, 6x1344x896 per sample)",
+        "metric": metric_name(args),
         "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         **({"dtype_detail": FP8_DETAIL, "prefill_mfma_frac_note": "algorithmic FLOPs / time against the 2.5 PF 16-bit peak (mixed-precision step)"}
            if args.dtype == "fp8" else {}),
-        "config": {"workload": f"C3: {args.images}x({args.width}x{args.height}) images -> {n_tiles} ViT inputs (364x364), "
+        "config": {"workload": f"{config_label(args)}: {args.images}x({args.width}x{args.height}) images -> {n_tiles} ViT inputs (364x364), "
                                f"{n_tiles * cfg.tokens_per_tile} visual tokens, S={S}; SigLIP-SO400M/14 (27L) + Llama-3.1-8B (32L) "
                                "prefill to last-token logits, KV cache written; synthetic seeded weights",
                    "samples_per_rank_per_step": args.inflight, "samples_in_flight_per_gpu": args.inflight,

@@ -105,11 +105,38 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
 
 // Geometry per shape class, from end-to-end A/B runs of the C3 prefill (`bench.py --opt`, profiles/README.md): N >= 2048 takes the
 // staggered 256x256 schedule; narrow-N / deep-K (SigLIP fc2) the 256x128 3-slot ring; small problems 128x128.
+// Problems that leave the class geometry fewer than two rounds of tiles on the 256 CUs (one image instead of six: BASELINE
+// configs C1 / C2, Idefics2's text side) are decided by the tile count instead: cost = tiles per CU x tile area / the geometry's
+// relative efficiency on large problems (256x256 staggered 1.0, 256x128 0.85, 128x128 0.75, 64x128 0.55; tools/sweep_fp8_cfg.py and
+// the round-1 sweeps).  Every C3 / C5 shape has >= 464 tiles and evaluates to its class geometry, so the headline path is unchanged.
+int g_gemm_auto_small = 1;                  // lmi_set_option("gemm.auto_small", 0) = class rules only (A/B)
 int choose_gemm_cfg(const GemmArgs& a) {
     if (g_gemm_cfg >= 0) return g_gemm_cfg;
     if (a.M < 512) return 8;
-    if (a.N >= 2048) return a.K <= 1536 ? g_gemm_short : g_gemm_wide;
-    return a.K >= 2048 ? g_gemm_narrow : g_gemm_small;
+    const int cls = a.N >= 2048 ? (a.K <= 1536 ? g_gemm_short : g_gemm_wide) : (a.K >= 2048 ? g_gemm_narrow : g_gemm_small);
+    if (!g_gemm_auto_small) return cls;
+    struct Geo { int cfg, bm, bn; float eff; };
+    auto geo_of = [](int cfg) -> Geo {
+        switch (cfg) {
+            case 1: case 5: case 6: case 7: return {cfg, 256, 256, 1.0f};
+            case 2: case 3: return {cfg, 256, 128, 0.85f};
+            case 4: return {cfg, 128, 256, 0.85f};
+            case 8: case 9: return {cfg, 64, 128, 0.55f};
+            default: return {cfg, 128, 128, 0.75f};
+        }
+    };
+    auto tiles = [&](const Geo& g) { return (long)((a.M + g.bm - 1) / g.bm) * ((a.N + g.bn - 1) / g.bn); };
+    const Geo c0 = geo_of(cls);
+    if (tiles(c0) >= 512) return cls;
+    auto cost = [&](const Geo& g) { return (float)((tiles(g) + 255) / 256) * (float)(g.bm * g.bn) / g.eff; };
+    Geo best = c0;
+    float best_cost = cost(c0);
+    for (int cfg : {2, 0, 8}) {
+        const Geo g = geo_of(cfg);
+        const float c = cost(g);
+        if (c < best_cost * 0.97f) { best = g; best_cost = c; }      // ties stay with the larger tile
+    }
+    return best.cfg;
 }
 
 template <typename T, int EPI, int ACT, int AMODE>
@@ -407,6 +434,7 @@ int lmi_set_option(const char* key, int value) {
         return LMI_OK;
     }
     if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "gemm.auto_small")) { g_gemm_auto_small = value ? 1 : 0; return LMI_OK; }
     {
         struct { const char* key; int* var; } classes[] = {{"gemm.wide", &g_gemm_wide}, {"gemm.short_k", &g_gemm_short},
                                                           {"gemm.narrow_n", &g_gemm_narrow}, {"gemm.small", &g_gemm_small}};
