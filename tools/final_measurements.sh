@@ -10,6 +10,9 @@ timeout 200 python bench.py --dtype fp8 --no-cpu-baseline --steps 10 --warmup 3 
 timeout 200 python bench.py --workload llava-c5 --graph-encode --steps 3 --warmup 2 > gpurun_out/final/bench_c5_f16_graph.json 2>/dev/null
 timeout 200 python bench.py --workload llava-c5 --dtype fp8 --graph-encode --steps 3 --warmup 2 > gpurun_out/final/bench_c5_fp8_graph.json 2>/dev/null
 timeout 200 python bench.py --workload idefics2-c4 --steps 10 --warmup 3 > gpurun_out/final/bench_idefics2_c4.json 2>/dev/null
+timeout 200 python bench.py --images 1 --dtype bf16 --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/final/bench_c2_bf16.json 2>/dev/null
+timeout 200 python bench.py --images 1 --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/final/bench_c2_f16.json 2>/dev/null
+timeout 200 python bench.py --images 1 --width 336 --height 336 --no-cpu-baseline --steps 30 --warmup 5 > gpurun_out/final/bench_c1_f16.json 2>/dev/null
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_f16 -o f16 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/final/prof_f16_bench.json 2> $R/gpurun_out/final/prof_f16.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_fp8 -o fp8 -- python $R/bench.py --dtype fp8 --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/final/prof_fp8_bench.json 2> $R/gpurun_out/final/prof_fp8.err
