@@ -73,13 +73,14 @@ def test_tile_slices_balanced():
             assert max(b - a for a, b in s) - min(b - a for a, b in s) <= 1
 
 
-def _tp_config():
+def _tp_config(world=2):
+    """2 ranks: 2 q / 2 kv heads, FFN 128; 4 ranks: 4 q / 4 kv heads (hidden 512), FFN 256 — one head and a 64-wide FFN slice per rank."""
     from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
     return LeopardConfig(
         vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16,
                                    image_size=28, patch_size=14),
-        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
-                               num_key_value_heads=2, vocab_size=256, rope_scaling=RopeScaling()),
+        text_config=TextConfig(hidden_size=128 * world, intermediate_size=64 * world, num_hidden_layers=2, num_attention_heads=world,
+                               num_key_value_heads=world, vocab_size=256, rope_scaling=RopeScaling()),
         image_token_index=250)
 
 
@@ -91,7 +92,7 @@ def _tp_worker(rank, world, port, out):
     from tests.emu_util import emu_ops
     D.init(backend="gloo")
     ops = emu_ops()
-    cfg = _tp_config()
+    cfg = _tp_config(world)
     src = SynthSource(cfg, ops, "cpu", torch.float16)
     eng = LeopardEngine(cfg, EngineWeights.build(cfg, src, torch.float16, tp_rank=rank, tp_size=world), ops=ops, device="cpu")
     assert eng.tp_size == world and eng.W.llm_layers[0].qkv_w.shape[0] == (1 + 2) * 128 and eng.W.llm_layers[0].down_w.shape[1] == 64
@@ -125,8 +126,9 @@ def _tp_worker(rank, world, port, out):
     D.barrier()
 
 
-def test_tensor_parallel_llm_two_ranks_gloo():
-    """SURVEY.md 8e phase B on CPU: the LLM sharded over 2 ranks — heads / FFN slices, sequence-parallel norms, all-gather of the
+@pytest.mark.parametrize("world", [2, 4])
+def test_tensor_parallel_llm_two_ranks_gloo(world):
+    """SURVEY.md 8e phase B on CPU: the LLM sharded over 2 (and 4: row padding to ranks x chunks, one row per rank and chunk) ranks — heads / FFN slices, sequence-parallel norms, all-gather of the
     normalised rows, reduce-scatter of the partial o_proj / down_proj products in two row chunks, column-parallel last-token
     head — gives every rank the logits of the unsharded model, in prefill, decode and greedy generation."""
     mp.set_start_method("spawn", force=True)
@@ -135,15 +137,15 @@ def test_tensor_parallel_llm_two_ranks_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_tp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, l0, ref), (_, l1, _) = res
-    assert l0 == l1                                                # both ranks hold the same, complete logits
+    (_, l0, ref) = res[0]
+    assert all(l == l0 for _, l, _ in res[1:])                     # every rank holds the same, complete logits
     d_prefill, d_decode, same_tokens, scale, d_exact, sent = ref
     assert d_prefill <= 3e-3 * max(1.0, scale) and d_decode <= 3e-3 * max(1.0, scale) and same_tokens
     assert d_exact <= 2e-4 * max(1.0, scale)                       # fp32 exchange: only the summation order differs
