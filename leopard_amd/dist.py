@@ -272,8 +272,8 @@ def get_comm(device=None, lib=None) -> Optional[Comm]:
                 comm = RcclComm(lib=lib, device=device)
             except Exception as e:                                   # noqa: BLE001  (re-raised or reported below)
                 err = repr(e)[:300]
-            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
-                              device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+            flag_dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu")
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=flag_dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 if comm is not None:

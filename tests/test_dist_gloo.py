@@ -208,3 +208,55 @@ def test_idefics2_tensor_parallel_two_ranks_gloo():
     assert l0 == l1
     vis_equal, d, scale, same = ref
     assert vis_equal and d <= 3e-3 * max(1.0, scale) and same
+
+
+def _fallback_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import warnings
+    from leopard_amd import dist as D
+    D.init(backend="gloo")
+
+    class FakeRccl:                                                 # stands in for RcclComm: comes up on rank 0 only
+        destroyed = False
+
+        def __init__(self, lib=None, device=None):
+            if D.dist.get_rank() == 1:
+                raise RuntimeError("lmi_comm_init failed (simulated)")
+
+        def destroy(self):
+            FakeRccl.destroyed = True
+    D.RcclComm = FakeRccl
+    real = D.dist.get_backend
+    D.dist.get_backend = lambda *a, **k: "nccl"                     # take get_comm's RCCL branch on a gloo group
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            comm = D.get_comm()
+    finally:
+        D.dist.get_backend = real
+    # every rank ends on the same transport, the one that came up is torn down, and the name says what happened
+    x = torch.full((4,), float(rank + 1))
+    comm._group_backend = "gloo"
+    comm.all_reduce(x)
+    out.put((rank, type(comm).__name__, comm.backend, FakeRccl.destroyed, len(w), x.tolist()))
+    D.barrier()
+
+
+def test_c_abi_communicator_failure_is_agreed_on_by_all_ranks():
+    """dist.get_comm: if lmi_comm_init fails on ANY rank, all ranks drop to the torch.distributed group together (no rank is left
+    inside the other transport), loudly, and LMI_COMM_STRICT=1 would raise instead."""
+    mp.set_start_method("spawn", force=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, kind, backend, destroyed, n_warn, x in res:
+        assert kind == "TorchComm" and "lmi_comm unavailable" in backend and n_warn >= 1
+        assert x == [3.0] * 4
+    assert res[0][3] is True                                        # rank 0's communicator had come up and was destroyed
