@@ -167,8 +167,8 @@ def _idefics2_tp_worker(rank, world, port, out):
     cfg = Idefics2Config(
         vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16,
                                    image_size=56, patch_size=14),
-        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
-                               num_key_value_heads=2, vocab_size=256, rope_theta=10000.0, rope_scaling=None, sliding_window=9),
+        text_config=TextConfig(hidden_size=128 * world, intermediate_size=64 * world, num_hidden_layers=2, num_attention_heads=world,
+                               num_key_value_heads=world, vocab_size=256, rope_theta=10000.0, rope_scaling=None, sliding_window=9),
         perceiver_config=PerceiverConfig(n_latents=3, depth=1, n_heads=1, head_dim=96, num_key_value_heads=1),
         image_token_id=250, longest_edge=56)
     src = Idefics2SynthSource(cfg, ops, "cpu", torch.float16)
@@ -176,7 +176,7 @@ def _idefics2_tp_worker(rank, world, port, out):
     rng = np.random.default_rng(8)
     imgs = [torch.from_numpy(rng.standard_normal((3, 42, 56)).astype(np.float32)),
             torch.from_numpy(rng.standard_normal((3, 58, 30)).astype(np.float32)),
-            torch.from_numpy(rng.standard_normal((3, 28, 28)).astype(np.float32))]          # 3 images on 2 ranks: 2 + 1
+            torch.from_numpy(rng.standard_normal((3, 28, 28)).astype(np.float32))]          # 3 images: 2 + 1 on 2 ranks; on 8, five ranks have none
     L = cfg.perceiver_config.n_latents
     ids = torch.tensor([[5, 7] + [250] * L + [9, 11] + [250] * L + [13] + [250] * L + [17, 19]])
     vis = eng.encode_images_sharded(imgs)
@@ -191,8 +191,9 @@ def _idefics2_tp_worker(rank, world, port, out):
     D.barrier()
 
 
-def test_idefics2_tensor_parallel_two_ranks_gloo():
-    """BASELINE config 4 (Leopard-Idefics2, TP LLM) on 2 CPU ranks: images sharded round-robin + one all-gather (bit-identical
+@pytest.mark.parametrize("world", [2, 8])
+def test_idefics2_tensor_parallel_two_ranks_gloo(world):
+    """BASELINE config 4 (Leopard-Idefics2, TP LLM) on 2 and 8 CPU ranks: images sharded round-robin + one all-gather (bit-identical
     visual tokens), Mistral decoder tensor-parallel with sequence-parallel norms and the sliding window, column-parallel head."""
     mp.set_start_method("spawn", force=True)
     from tests.emu_util import emu_ops
@@ -200,15 +201,15 @@ def test_idefics2_tensor_parallel_two_ranks_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_idefics2_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_idefics2_tp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, l0, ref), (_, l1, _) = res
-    assert l0 == l1
+    (_, l0, ref) = res[0]
+    assert all(l == l0 for _, l, _ in res[1:])
     vis_equal, d, scale, same = ref
     assert vis_equal and d <= 3e-3 * max(1.0, scale) and same
 
