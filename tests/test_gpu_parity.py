@@ -30,8 +30,8 @@ DEV = "cuda:0"
 # bounds = measured x 1.25 on the production (fused norm / RoPE) schedule; measured values in the comments, the per-layer table and the
 # predicted budget in profiles/r02_error_growth.txt
 LOGIT_TOL = {torch.float16: 1.25e-3, torch.bfloat16: 1.03e-2}     # mid configuration, 2 + 2 layers: all-position logits 9.9e-4 / 8.2e-3 (last position 5.0e-4 / 4.0e-3)
-FULL_TOL = {("c1", torch.float16): 2.0e-3, ("c1", torch.bfloat16): 1.47e-2,       # full depth, 27 + 32 layers: 1.60e-3 / 1.17e-2
-            ("c2", torch.float16): 1.46e-3, ("c2", torch.bfloat16): 1.23e-2}      #                             1.17e-3 / 9.9e-3
+FULL_TOL = {("c1", torch.float16): 2.12e-3, ("c1", torch.bfloat16): 1.65e-2,      # full depth, 27 + 32 layers: 1.69e-3 / 1.32e-2
+            ("c2", torch.float16): 1.46e-3, ("c2", torch.bfloat16): 1.43e-2}      #                             1.14e-3 / 1.14e-2
 # C3 sequence length, 2 + 2 layers: residual stream max over 29 M elements / rel-rms, ViT features, last-position logits
 C3LEN_TOL = {torch.float16: (1.13e-3, 9.2e-4, 7.3e-4, 7.1e-4),                    # measured 9.0e-4, 7.4e-4, 5.8e-4, 5.7e-4
              torch.bfloat16: (8.4e-3, 7.3e-3, 5.1e-3, 5.0e-3)}                    # measured 6.8e-3, 5.8e-3, 4.1e-3, 4.0e-3
