@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Same-box, same-process A/B of library options over the C3 prefill step (run on the GPU box).
+
+  python tools/ab_step.py --variant base: --variant succ:gemm.wide=6,gemm.short_k=6,gemm.flags=1 ... [--steps 8 --rounds 4]
+
+Builds the engine once (bench.py's C3 sample), then alternates the variants round by round (variant x round, so that clock /
+temperature drift hits every arm alike); each measurement = `steps` prefill steps between two device synchronisations.  A variant is
+`name:key=value,key=value` over lmi_set_option keys; every key any variant sets is reset to its default before each arm.  Prints the
+per-round ms per step and the median per variant, and checks that every arm's last-position logits equal the first arm's within 2e-2
+(the options are speed-only; identical kernels give identical bits, variants that change the summation order do not)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from leopard_amd.config import full_config  # noqa: E402
+
+DEFAULTS = {"gemm.config": -1, "gemm.group_m": 4, "gemm.order": 0, "gemm.flags": 0, "gemm.wide": 5, "gemm.short_k": 5, "gemm.narrow_n": 2,
+            "gemm.small": 0, "gemm.auto_small": 1, "attn.dma": 1, "attn.lds_pad": 0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", action="append", default=[])
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--images", type=int, default=6)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    from leopard_amd.engine import KVCache, LeopardEngine
+    from leopard_amd.gpu_tiler import GpuTiler
+    from leopard_amd.ops import Ops
+    from leopard_amd.weights import EngineWeights, SynthSource
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    cfg = full_config()
+    ops = Ops()
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
+    eng = LeopardEngine(cfg, W, ops=ops, device=dev)
+    tiler = GpuTiler(ops, dev)
+    u8, ids_np, plan, _, raw = bench.make_sample(cfg, args.images, 1344, 896, seed=0)
+    raw_dev = [torch.from_numpy(np.array(r)).to(dev) for r in raw]
+    ids = torch.from_numpy(ids_np).reshape(1, -1)
+    n_tiles = u8.shape[0]
+    S = ids.shape[1] + n_tiles * (cfg.tokens_per_tile - 1)
+    cache = KVCache(cfg, S, dtype, dev)
+
+    variants = []
+    for v in args.variant or ["base:"]:
+        name, _, opts = v.partition(":")
+        kv = {}
+        for item in filter(None, opts.split(",")):
+            k, val = item.split("=")
+            kv[k] = int(val)
+        variants.append((name, kv))
+    touched = sorted({k for _, kv in variants for k in kv})
+
+    def apply(kv):
+        for k in touched:
+            if k.startswith("eng."):
+                setattr(eng, k[4:], bool(kv.get(k, 1)))
+            else:
+                ops.set_option(k, kv.get(k, DEFAULTS[k]))
+
+    def step():
+        cache.length = 0
+        return eng.prefill(ids, tiler.tile_sample(raw_dev)[0], cache=cache)
+
+    ref_logits, times = None, {n: [] for n, _ in variants}
+    for name, kv in variants:                                   # warm every arm once (first launches set function attributes), check results
+        apply(kv)
+        res = step()
+        torch.cuda.synchronize()
+        lg = res.logits_last.float().cpu()
+        if ref_logits is None:
+            ref_logits = lg
+        err = (lg - ref_logits).abs().max().item() / ref_logits.abs().max().item()
+        print(f"# {name}: logits vs first arm: {err:.2e}", flush=True)
+        assert err <= 2e-2 and torch.isfinite(lg).all(), name
+    for r in range(args.rounds):
+        for name, kv in variants:
+            apply(kv)
+            step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            times[name].append((time.perf_counter() - t0) / args.steps * 1e3)
+        print(f"# round {r}: " + "  ".join(f"{n} {times[n][-1]:.2f}" for n, _ in variants), flush=True)
+    apply({})
+    summary = {n: {"median_ms": round(float(np.median(times[n])), 3), "min_ms": round(min(times[n]), 3), "rounds": [round(t, 3) for t in times[n]],
+                   "options": kv} for n, kv in variants}
+    base = summary[variants[0][0]]["median_ms"]
+    for n, _ in variants:
+        summary[n]["vs_first"] = round(summary[n]["median_ms"] / base, 4)
+        print(f"{n:28s} median {summary[n]['median_ms']:8.3f} ms  min {summary[n]['min_ms']:8.3f}  x{summary[n]['vs_first']:.4f}", flush=True)
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump({"steps": args.steps, "rounds": args.rounds, "dtype": args.dtype, "S": S, "n_tiles": n_tiles, "variants": summary}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
