@@ -76,7 +76,6 @@ constexpr int kNumGemmCfg = 10;             // 0-4 ring geometries; 5-7 staggere
 int g_gemm_cfg = -1;                        // -1 = choose per shape
 int g_gemm_group_m = GEMM_GROUP_M;
 int g_gemm_order = 0;
-int g_gemm_flags = 0;                       // GEMM_F_* (gemm.h): L2-touch experiments, speed only
 // per-shape-class geometry (end-to-end A/B knobs; defaults = best measured on the C3 prefill, which runs at the power cap
 // and does not always agree with isolated bursts of one GEMM)
 int g_gemm_wide = 5;                        // N >= 2048, K > 1536 (Llama projections)
@@ -87,25 +86,20 @@ int g_gemm_small = 0;                       // N < 2048, K < 2048 (SigLIP out_pr
 template <typename T, int EPI, int ACT, int AMODE, typename C>
 int launch_gemm_cfg(const GemmArgs& a, void* stream) {
     int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
-    if (a.order >= 1) tiles = (tiles + 255) / 256 * 256;
+    if (a.order == 1) tiles = (tiles + 255) / 256 * 256;
     static std::atomic<uint64_t> attr_done{0};
     allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE, C>, C::SMEM_TOTAL, attr_done);
-    GemmArgs b = a;
-    constexpr int by_lds = 160 * 1024 / C::SMEM_TOTAL, by_waves = 2048 / C::NT;
-    b.succ_stride = 256 * (by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves);
-    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM_TOTAL, stream, b);
+    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE, C>), dim3(tiles), dim3(C::NT), C::SMEM_TOTAL, stream, a);
     return check_launch("lmi_gemm");
 }
 
 template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR>
 int launch_gemm_stagger(const GemmArgs& a, void* stream) {
     int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
-    if (a.order >= 1) tiles = (tiles + 255) / 256 * 256;
+    if (a.order == 1) tiles = (tiles + 255) / 256 * 256;
     static std::atomic<uint64_t> attr_done{0};
     allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>, C::SMEM_TOTAL, attr_done);
-    GemmArgs b = a;
-    b.succ_stride = 256;                                           // 128 KiB of LDS: one workgroup per CU
-    LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>), dim3(tiles), dim3(C::NT), C::SMEM_TOTAL, stream, b);
+    LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE, C, VAR>), dim3(tiles), dim3(C::NT), C::SMEM_TOTAL, stream, a);
     return check_launch("lmi_gemm");
 }
 
@@ -152,9 +146,8 @@ int launch_gemm(const GemmArgs& a, void* stream) {
         case 2: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg2>(a, stream);
         case 3: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg3>(a, stream);
         case 4: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg4>(a, stream);
-        case 5: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 0>(a, stream);   // staggered two-group schedule
-        case 6: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 1>(a, stream);   // + two-k-tile prologue, N-tail wave skip, successor touch
-        case 7: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 2>(a, stream);   // + in-loop L2 touch of k-tile t + 2
+        case 5: case 7: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 0>(a, stream);   // staggered two-group schedule (production)
+        case 6: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 1>(a, stream);   // the same with the single-tile prologue of rounds 1-2 (A/B)
         case 8: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgS>(a, stream);
         case 9: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgS6>(a, stream);
         default: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg0>(a, stream);
@@ -439,16 +432,7 @@ int lmi_set_option(const char* key, int value) {
         g_gemm_group_m = value;
         return LMI_OK;
     }
-    if (!strcmp(key, "gemm.order")) {
-        if (value < 0 || value > 2) return fail(LMI_EINVAL, "lmi_set_option: gemm.order in [0, 2]");
-        g_gemm_order = value;
-        return LMI_OK;
-    }
-    if (!strcmp(key, "gemm.flags")) {
-        if (value < 0 || value > 15) return fail(LMI_EINVAL, "lmi_set_option: gemm.flags in [0, 15]");
-        g_gemm_flags = value;
-        return LMI_OK;
-    }
+    if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "gemm.auto_small")) { g_gemm_auto_small = value ? 1 : 0; return LMI_OK; }
     {
         struct { const char* key; int* var; } classes[] = {{"gemm.wide", &g_gemm_wide}, {"gemm.short_k", &g_gemm_short},
@@ -591,7 +575,7 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     if (M == 0) return LMI_OK;
     GemmArgs a;
     a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.add_rows = add_rows; a.row_map = row_map;
-    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m; a.order = g_gemm_order; a.flags = g_gemm_flags; a.succ_stride = 256;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
     a.norm_out = x.norm_out; a.norm_gamma = x.norm_gamma; a.rowsq_out = x.rowsq_out; a.ld_norm = x.ld_norm;
     a.rowsq_in = x.rowsq_in; a.rowsq_parts = x.rowsq_parts; a.norm_dim = x.norm_dim; a.norm_eps = x.norm_eps;
     a.rope_cos = x.rope_cos; a.rope_sin = x.rope_sin; a.k_cache = x.k_cache; a.v_cache = x.v_cache;
@@ -701,7 +685,7 @@ int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.W = W; a.out = out; a.bias = bias;
-    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.group_m = g_gemm_group_m; a.order = 0;   // (the tile-order experiments are 16-bit only)
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
     const int e = 127 + scale_exp;
     a.scale_e8m0 = e | (e << 8) | (e << 16) | (e << 24);
     a.out_scale = out_scale;

@@ -48,10 +48,7 @@ struct GemmArgs {
     int add_period;
     int ps_grid;          // pixel-shuffle: G (26); output tokens per tile = (G/2)^2; C = K/4
     int group_m;          // row-tiles per L2 group in the XCD-aware tile order
-    int order;            // 0 = each XCD owns a contiguous slab of the grouped order; 1 = XCDs take 32-tile chunks round-robin;
-                          // 2 = round-robin chunks of a STRIP-major order (strips of 8 column tiles, row groups inside): all XCDs share a W strip
-    int flags;            // GEMM_F_* (speed only: L2 prefetch experiments, see gemm_stagger_kernel)
-    int succ_stride;      // workgroups resident on the chip (256 x workgroups per CU): workgroup b's CU is expected to run b + succ_stride next
+    int order;            // 0 = each XCD owns a contiguous slab of the grouped order; 1 = XCDs take 32-tile chunks round-robin
     unsigned a_bytes, w_bytes;   // extents of A and W (buffer resources of the LDS-DMA; both < 4 GiB)
     // ---- RMSNorm folded into the GEMMs around it (Llama / Mistral layers) ---------------------------------------------------
     // producer (EPI_RESID_F32): besides x += acc, write norm_out[m, n] = T(x[m, n] * norm_gamma[n]) — the NEXT RMSNorm's gain
@@ -83,9 +80,7 @@ struct GemmArgs {
     float out_scale;             // fp8 OUTPUTS (T = fp8_t: GELU / SwiGLU results handed to the next fp8 GEMM): value * out_scale, then e4m3
 };
 
-enum { GEMM_F_SUCC = 1, GEMM_F_PF_FULL = 2, GEMM_F_PF_DIST3 = 4, GEMM_F_EPI = 8 };
 constexpr int GEMM_BK = 64;
-constexpr int GEMM_TOUCH_BYTES = 2048;           // dummy LDS target of the L2-touch loads (256 B per wave, 8 waves)
 constexpr int GEMM_GROUP_M = 4;                 // end-to-end sweep 2..16 on the C3 prefill: 4-6 best (-0.5 % vs 8), 16 +4 %
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int STAGES_>
@@ -99,7 +94,7 @@ struct GemmCfg {
     static constexpr int G = A_PASSES + W_PASSES;              // LDS-DMA instructions per thread per k-tile
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int SMEM = STAGES * STAGE_BYTES;
-    static constexpr int SMEM_TOTAL = SMEM + BM * 4 + GEMM_TOUCH_BYTES;   // + the row scales of a folded RMSNorm (GemmRowScale) + the L2-touch dummy
+    static constexpr int SMEM_TOTAL = SMEM + BM * 4;             // + the row scales of a folded RMSNorm (GemmRowScale)
     static constexpr int D = STAGES - 1;                       // prefetch distance in k-tiles (>= 1)
     static_assert(STAGES >= 2, "ring needs at least two slots");
     static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows vs threads");
@@ -157,25 +152,6 @@ LMI_DEV bool gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, in
     const int nwg = tiles_m * tiles_n;
     const int xcd = bid & 7, idx = bid >> 3;
     int swz;
-    if (order == 2) {
-        // strip-major: strips of 8 column tiles; inside a strip groups of group_m row tiles; 32-tile chunks round-robin over the
-        // XCDs, so the eight XCDs work on (about) one strip at a time: its W panels are fetched from HBM once and shared through
-        // the Infinity Cache, the A panels (small: M x K) are re-read per strip
-        swz = ((idx >> 5) * 8 + xcd) * 32 + (idx & 31);
-        if (swz >= nwg) return false;
-        constexpr int SW = 8;
-        const int s = swz / (tiles_m * SW);
-        const int first_n = s * SW, ssize = imin(SW, tiles_n - first_n);
-        const int in_s = swz - s * tiles_m * SW;
-        const int per_group = group_m * ssize;
-        const int g = in_s / per_group;
-        const int first_m = g * group_m;
-        const int gsize = imin(group_m, tiles_m - first_m);
-        const int in_g = in_s - g * per_group;
-        tm = first_m + in_g % gsize;
-        tn = first_n + in_g / gsize;
-        return true;
-    }
     if (order == 1) {
         swz = ((idx >> 5) * 8 + xcd) * 32 + (idx & 31);
         if (swz >= nwg) return false;
@@ -519,49 +495,6 @@ struct GemmStager {
 };
 
 
-// ---- L2 touches (speed only; never affect results) ---------------------------------------------------------------------------
-// Thread r < BM owns A row r of a tile, thread BM + j owns W row j (BM % 64 == 0: a wave is all-A or all-W); one k-tile of one row
-// is exactly one 128-byte line, so `touch(kt)` pulls the tile's k-tile kt into this XCD's L2 with one 4-byte load per lane.
-// Uses: (a) SUCCESSOR: near the end of its main loop a workgroup touches k-tiles 0 / 1 of the tile that the next workgroup on
-// this CU will run (block b + succ_stride: same XCD, same L2) so that its prologue — exposed, one workgroup per CU — finds them
-// in L2 instead of paying Infinity-Cache / HBM latency with every CU bursting at once; (b) IN-LOOP: k-tile t + 2 of the own tile
-// ahead of the LDS-DMA pieces that fetch it (gemm_stagger_kernel VAR 2).
-template <int AMODE, typename C, int ES>
-struct GemmToucher {
-    unsigned voff;
-    bool is_a, valid;
-    char* dummy;
-    LMI_DEV void init(const GemmArgs& p, int m0, int n0, int tid, char* smem) {
-        const int r = tid;
-        is_a = r < C::BM;
-        valid = (AMODE == AMODE_PLAIN) && r < C::BM + C::BN;
-        voff = is_a ? (unsigned)((long)imin(m0 + r, p.M - 1) * p.lda * ES) : (unsigned)((long)imin(n0 + r - C::BM, p.N - 1) * p.ldw * ES);
-        dummy = smem + C::SMEM + C::BM * 4 + (tid >> 6) * 256;
-    }
-    LMI_DEV void touch(const BufRsrc& a_buf, const BufRsrc& w_buf, int kt) const {
-        if (valid) l2_touch_buf(is_a ? a_buf : w_buf, voff, (unsigned)kt * 128u, dummy);
-    }
-};
-// (c) EPILOGUE (GEMM_F_EPI, residual epilogue only): the tile's rows of the fp32 stream x, which the epilogue reads, adds to and
-// writes back, are touched one k-tile before the main loop ends, so that the exposed read-modify-write finds them in L2.
-// BN * 4 / 128 lines per row; the NT threads split them evenly (row = slot / lines-per-row).
-template <int EPI, typename C>
-LMI_DEV void gemm_touch_out_tile(const GemmArgs& p, int m0, int n0, int tid, char* smem) {
-    if (EPI != EPI_RESID_F32 || p.row_map) return;
-    const long extent = ((long)(p.M - 1) * p.ldo + p.N) * 4;
-    if (extent >= (1L << 32)) return;
-    const BufRsrc o_buf = make_buf(p.out, (unsigned)extent);
-    constexpr int LPR = C::BN * 4 / 128, LINES = C::BM * LPR, PER = (LINES + C::NT - 1) / C::NT;
-    char* dummy = smem + C::SMEM + C::BM * 4 + (tid >> 6) * 256;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int slot = j * C::NT + tid;
-        const int row = slot / LPR, line = slot - row * LPR;
-        if (slot < LINES && m0 + row < p.M && n0 * 4 + line * 128 < p.N * 4)
-            l2_touch_buf(o_buf, (unsigned)(((long)(m0 + row) * p.ldo + n0) * 4 + line * 128), 0u, dummy);
-    }
-}
-
 // write phase for v_mfma_f32_32x32x16 accumulators acc[NI][MI]: lane (fr, fh) owns row fr and the quads n = ni*32 + q*8 + fh*4
 template <typename C>
 LMI_DEV void gemm_put32(const f32x16 (&acc)[C::NI][C::MI], int mi, int lane, char* stage) {
@@ -608,16 +541,6 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 
     const int fr = lane & 31, fh = lane >> 5;
     const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
-    GemmToucher<AMODE, C, ES> succ;
-    bool succ_on = false;
-    if ((p.flags & GEMM_F_SUCC) && nt >= 2 + C::D) {                // (nt - 2 must lie beyond the counted-wait iterations)
-        int tm2, tn2;
-        if ((int)blockIdx.x + p.succ_stride < (int)gridDim.x &&
-            gemm_tile_coords((int)blockIdx.x + p.succ_stride, tiles_m, tiles_n, p.group_m, p.order, tm2, tn2)) {
-            succ.init(p, tm2 * C::BM, tn2 * C::BN, tid, smem);
-            succ_on = true;
-        }
-    }
 
     // ---- prologue: D tiles in flight -----------------------------------------------------------------------------
 #pragma unroll
@@ -631,9 +554,6 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
         // tile t has landed once at most the D-1 younger tiles are outstanding (ring tail: everything)
         if (C::D >= 2 && t + C::D - 1 < nt) wait_vmcnt_barrier<(C::D >= 2 ? C::G * (C::D - 1) : 0)>();
         else wait_vmcnt_barrier<0>();
-        // successor touch (GEMM_F_SUCC): from here on every wait is vmcnt(0), so the two extra VMEM operations cannot upset a counted wait
-        if (succ_on && t == nt - 2) { succ.touch(stager.a_buf, stager.w_buf, 0); succ.touch(stager.a_buf, stager.w_buf, 1); }
-        if ((p.flags & GEMM_F_EPI) && t == nt - 2) gemm_touch_out_tile<EPI, C>(p, m0, n0, tid, smem);
         const int slot = t % C::STAGES;
         const char* a_t = smem + slot * C::STAGE_BYTES;
         const char* w_t = a_t + C::A_BYTES;
@@ -675,16 +595,15 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 // k-steps 0 and 1 of tile t (the slot's previous tenant, tile t-1, was last read one full segment earlier by the
 // lagging group) and every wave drains its own pieces (vmcnt(0)) before the barrier that closes its k-step-3 LOAD
 // segment, which precedes the first read of tile t+1 by either group.
-// VAR 0 = as described.
-// VAR 1 = + k-tiles 0 AND 1 requested in the prologue (both ring slots are free at entry: the second tile's latency hides behind
-//           the wait for the first); + waves whose 64 columns lie entirely past N (N % 256 == 128: SigLIP q|k|v) skip their MFMAs and
-//           fragment reads like the padding row blocks do; + the successor touch (GEMM_F_SUCC, GemmToucher).
-// VAR 2 = VAR 1 + in-loop L2 touch of k-tile t + 2 (t + 3 with GEMM_F_PF_DIST3) ahead of the LDS-DMA pieces that will fetch it.
-//           Default duty split: the 32 concurrent tiles of an XCD form a (group_m x 8)-tile patch whose members share A row panels
-//           (8 tiles each) and W column panels (group_m tiles each); each member touches 1/8 of its A lines and 1/4 of its W lines,
-//           so one patch touches every line once.  GEMM_F_PF_FULL: every workgroup touches all 512 lines of its own k-tile.
-// (Earlier variants — no s_setprio; LDS-DMA pieces between the MFMAs — are in profiles/README.md; the second was 1-2 % faster in
-// isolated bursts and 2.4 % slower over the power-capped prefill step.)
+// Prologue: k-tiles 0 AND 1 are requested at entry (both ring slots are free: the second tile's latency hides behind the wait
+// for the first; -0.3 % on the C3 step).  Waves whose 64 columns lie entirely past N (N % 256 == 128: SigLIP q|k|v) skip their
+// MFMAs and fragment reads, as the padding row blocks of the tail row-tile do.
+// VAR 0 = as described (production); VAR 1 = the single-tile prologue of rounds 1-2 (kept as the A/B reference, gemm.config 6).
+// Measured and dropped (profiles/README.md): no s_setprio; LDS-DMA pieces between the MFMAs (1-2 % faster in isolated bursts,
+// 2.4 % slower over the power-capped step); L2 touches — of the own k-tile t + 2 ahead of its LDS-DMA pieces (+2.8 % step time
+// with one touch per patch line, +17.5 % with every workgroup touching its own 512 lines: VMEM issue is what the LOAD segments
+// are short of, not L2 hit rate), of the successor workgroup's first k-tiles (+0.4 %), of the residual epilogue's rows (+0.3 %);
+// a strip-major tile order that lets all XCDs share one W strip (+0.4 %).
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR, typename TA = T>
 __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
@@ -723,7 +642,8 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
 #pragma unroll
     for (int g = 0; g < C::G; ++g) issue_piece(g, 0, 0);
-    if (VAR >= 1 && nt > 1) {
+    constexpr bool TWO = (VAR == 0);                                // two-k-tile prologue
+    if (TWO && nt > 1) {
 #pragma unroll
         for (int g = 0; g < C::G; ++g) issue_piece(g, 1, 1);
         wait_vmcnt_barrier<C::G>();                                // k-tile 0 landed; k-tile 1 in flight
@@ -732,31 +652,12 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     }
     if (grp == 1) raw_barrier();                                   // waves 4-7 run one barrier behind
 
-    // ---- L2 touches (VAR >= 1; speed only) ---------------------------------------------------------------------------------------
-    GemmToucher<AMODE, C, ES> succ, ahead;
-    bool succ_on = false, ahead_on = false;
-    int pfd = 2;
-    if (VAR >= 1 && (p.flags & GEMM_F_SUCC) && nt >= 2) {
-        int tm2, tn2;
-        if ((int)blockIdx.x + p.succ_stride < (int)gridDim.x &&
-            gemm_tile_coords((int)blockIdx.x + p.succ_stride, tiles_m, tiles_n, p.group_m, p.order, tm2, tn2)) {
-            succ.init(p, tm2 * C::BM, tn2 * C::BN, tid, smem);
-            succ_on = true;
-        }
-    }
-    if (VAR == 2) {
-        ahead.init(p, m0, n0, tid, smem);
-        pfd = (p.flags & GEMM_F_PF_DIST3) ? 3 : 2;
-        const bool duty = ahead.is_a ? ((tid >> 5) == (tn & 7)) : (((tid - C::BM) >> 6) == (tm & 3));
-        ahead_on = ahead.valid && ((p.flags & GEMM_F_PF_FULL) || duty);
-    }
-
     // 32-row blocks of this wave's tile that hold rows below M: the tail row-tile (M = 7187 leaves 19 rows of 256) skips the
     // MFMAs and fragment reads of the blocks that are entirely padding — they would cost as much energy as useful ones, and
     // the step runs at the package power cap.  Barriers and LDS-DMA pieces are unaffected.
     const int rows_left = p.M - (m0 + wm * C::WTM);
     int nmi = rows_left >= C::WTM ? C::MI : (rows_left <= 0 ? 0 : (rows_left + 31) >> 5);
-    if (VAR >= 1 && n0 + wn * C::WTN >= p.N) nmi = 0;              // this wave's columns are all past N (masked on store anyway)
+    if (n0 + wn * C::WTN >= p.N) nmi = 0;              // this wave's columns are all past N (masked on store anyway)
     // ISSUE (a next k-tile exists) and FULL (no padding blocks) are compile-time: a runtime test per LDS-DMA piece or per
     // MFMA would cut the MFMA segment into scheduling regions with a branch each
     auto tile = [&](auto issue_tag, auto full_tag, int t) {
@@ -773,8 +674,6 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < C::NI; ++i)
                 if (FULL || nmi > 0) wf[i] = gemm_frag_load<TA>(w_t, wn * C::WTN + i * 32 + fr, ks, fh);
-            if (VAR == 2 && ISSUE && ks == 0 && ahead_on && t + pfd < nt)       // ahead of this k-step's pieces: completes before them
-                l2_touch_buf(ahead.is_a ? stager.a_buf : stager.w_buf, ahead.voff, (unsigned)(t + pfd) * 128u, ahead.dummy);
             if (ks < KS_ISSUE && ISSUE) {
 #pragma unroll
                 for (int g = ks * C::G / KS_ISSUE; g < (ks + 1) * C::G / KS_ISSUE; ++g) issue_piece(g, t + 1, (t + 1) & 1);
@@ -794,13 +693,9 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
         }
     };
     auto run = [&](auto full_tag) {
-        if (VAR >= 1 && nt > 1) {
-            tile(std::false_type{}, full_tag, 0);                  // k-tile 1 is already in flight
+        if (TWO && nt > 1) {
+            tile(std::false_type{}, full_tag, 0);                  // k-tile 1 is already in flight; its pieces drain in k-step 3 as usual
             for (int t = 1; t + 1 < nt; ++t) tile(std::true_type{}, full_tag, t);
-            // the last k-tile issues nothing and drains nothing of its own: the successor's first two k-tiles are touched here and
-            // have the whole k-tile to arrive before its closing vmcnt(0)
-            if (succ_on) { succ.touch(stager.a_buf, stager.w_buf, 0); succ.touch(stager.a_buf, stager.w_buf, 1); }
-            if (p.flags & GEMM_F_EPI) gemm_touch_out_tile<EPI, C>(p, m0, n0, tid, smem);
             tile(std::false_type{}, full_tag, nt - 1);
         } else {
             for (int t = 0; t + 1 < nt; ++t) tile(std::true_type{}, full_tag, t);

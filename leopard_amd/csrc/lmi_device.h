@@ -79,14 +79,6 @@ LMI_DEV void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, vo
                                              (int)soffset, 0, 0);
 }
 
-// L2 touch: a 4-byte-per-lane LDS-DMA load whose only purpose is to pull the addressed cache lines into this XCD's L2 ahead of
-// the LDS-DMA pieces that will need them; the data lands in a dummy LDS area (lds_wave_base + lane*4) nobody reads, so no VGPR
-// is tied to the outstanding load.  Counts in vmcnt like any other VMEM operation.
-LMI_DEV void l2_touch_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, (int)voffset,
-                                             (int)soffset, 0, 0);
-}
-
 // D[32x32] += A[32x64] * B[64x32] on fp8 e4m3 operands at twice the 16-bit MFMA rate (v_mfma_scale_f32_32x32x64_f8f6f4; the
 // unscaled fp8 MFMA runs at the 16-bit rate).  Lane l supplies A[l&31][32*(l>>5) + j] and B[32*(l>>5) + j][l&31], j = 0..31
 // (32 bytes; layout measured with tools/ubench/mfma_fp8_layout.hip), receives D as mfma32.  The E8M0 block scales are used as
@@ -288,13 +280,6 @@ inline void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, voi
     const unsigned long off = (unsigned long)voffset + soffset;
     if (off + 16 <= b.num_records) __builtin_memcpy(dst, b.base + off, 16);
     else __builtin_memset(dst, 0, 16);
-}
-
-inline void l2_touch_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
-    char* dst = (char*)lds_wave_base + lane_id() * 4;
-    const unsigned long off = (unsigned long)voffset + soffset;
-    if (off + 4 <= b.num_records) __builtin_memcpy(dst, b.base + off, 4);
-    else __builtin_memset(dst, 0, 4);
 }
 
 inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {

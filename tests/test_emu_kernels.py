@@ -449,33 +449,6 @@ def test_gemm_tile_order_round_robin(ops):
         ops.set_option("gemm.config", -1)
 
 
-@pytest.mark.parametrize("order", [0, 2])
-@pytest.mark.parametrize("cfg,M,N,K", [(6, 700, 640, 256), (7, 700, 640, 320), (7, 2304, 7424, 192), (2, 700, 640, 256)])
-def test_gemm_tile_order_strips_and_l2_touches(ops, cfg, M, N, K, order):
-    """gemm.order = 2 (strip-major round-robin chunks) and the L2-touch experiments (gemm.flags: successor touch, in-loop touch full /
-    duty, distance 3; staggered variants 6 / 7): speed-only features, results must be those of the plain kernels.  The (7, 2304, 7424)
-    case has more workgroups than one residency round, so the successor touch is actually issued."""
-    a, w = rnd((M, K), torch.float16, 95), rnd((N, K), torch.float16, 96, 0.1)
-    ref = a.float() @ w.float().T
-    try:
-        ops.set_option("gemm.order", order)
-        ops.set_option("gemm.config", cfg)
-        for flags in ((15,) if M > 2000 else (0, 1, 5, 15)):
-            ops.set_option("gemm.flags", flags)
-            out = torch.full((M, N), float("nan"), dtype=torch.float16)
-            ops.gemm(a, w, out)
-            assert (out.float() - ref).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item()), (cfg, order, flags)
-            if M < 2000:
-                x = rnd((M, N), torch.float32, 7)
-                x0 = x.clone()
-                ops.gemm(a, w, x, epilogue=_lib.EPI_RESIDUAL)
-                assert (x - (x0 + ref)).abs().max() <= 2e-4 * max(1.0, ref.abs().max().item()), (cfg, order, flags)
-    finally:
-        ops.set_option("gemm.flags", 0)
-        ops.set_option("gemm.order", 0)
-        ops.set_option("gemm.config", -1)
-
-
 @pytest.mark.parametrize("dma", [1, 0])
 def test_attention_kernel_variants(ops, dma):
     """Both attention kernels behind lmi_attn_varlen_fwd (LDS-DMA = production, register-staged = cross-check) on a causal

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box, same-process A/B of library options over the C3 prefill step (run on the GPU box).
 
-  python tools/ab_step.py --variant base: --variant succ:gemm.wide=6,gemm.short_k=6,gemm.flags=1 ... [--steps 8 --rounds 4]
+  python tools/ab_step.py --variant base: --variant old_prologue:gemm.wide=6,gemm.short_k=6 ... [--steps 8 --rounds 4]
 
 Builds the engine once (bench.py's C3 sample), then alternates the variants round by round (variant x round, so that clock /
 temperature drift hits every arm alike); each measurement = `steps` prefill steps between two device synchronisations.  A variant is
@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from leopard_amd.config import full_config  # noqa: E402
 
-DEFAULTS = {"gemm.config": -1, "gemm.group_m": 4, "gemm.order": 0, "gemm.flags": 0, "gemm.wide": 5, "gemm.short_k": 5, "gemm.narrow_n": 2,
+DEFAULTS = {"gemm.config": -1, "gemm.group_m": 4, "gemm.order": 0, "gemm.wide": 5, "gemm.short_k": 5, "gemm.narrow_n": 2,
             "gemm.small": 0, "gemm.auto_small": 1, "attn.dma": 1, "attn.lds_pad": 0}
 
 

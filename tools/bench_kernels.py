@@ -56,7 +56,6 @@ def bench_gemm(args):
     if args.group_m:
         ops.set_option("gemm.group_m", args.group_m)
     ops.set_option("gemm.order", args.order)
-    ops.set_option("gemm.flags", args.flags)
     base = SMALL_SHAPES if args.small else GEMM_SHAPES
     shapes = base if args.only < 0 else [base[args.only]]
     for name, M, N, K, epi, act in shapes:
@@ -131,7 +130,6 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--group-m", type=int, default=0)
     ap.add_argument("--order", type=int, default=0)
-    ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--lds-pad", type=int, default=0)
     ap.add_argument("--lib", default="", help="A/B: path of another build of libleopard_amd.so")
