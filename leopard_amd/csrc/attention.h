@@ -23,13 +23,6 @@
 #include <type_traits>
 #include "lmi_device.h"
 
-// timing-only ablations of the production attention kernel (tools/_ab builds with -DLMI_ATTN_ABLATE=n; results are wrong)
-#ifdef LMI_ATTN_ABLATE
-#define LMI_ABL(n) (LMI_ATTN_ABLATE == (n))
-#else
-#define LMI_ABL(n) false
-#endif
-
 namespace lmi {
 
 struct AttnArgs {
@@ -50,6 +43,7 @@ struct AttnArgs {
     int n_splits, split_tiles, part_rows;
     float* part_o;            // [n_splits, part_rows, n_heads, D]
     float* part_ml;           // [n_splits, part_rows, n_heads, 2]  (m, l)
+    int check_k_extent;       // 1 = the launcher could not bound a sequence's K / V extent (< 4 GiB): the kernel checks (and traps)
 };
 
 constexpr int ATT_BQ = 128, ATT_BKV = 64, ATT_THREADS = 256;
@@ -363,8 +357,10 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     // advances a scalar offset, and rows past len_k read as zeros (no address clamp in the loop).
     const T* k_base = (const T*)p.k + (long)k_beg * p.ldk + kvh * D;
     const T* v_base = (const T*)p.v + (long)k_beg * p.ldv + kvh * D;
-    // 32-bit buffer offsets: one sequence's K (or V) rows must span < 4 GiB (ldk = 6144 halves: 349 k keys); fail loudly beyond
-    if (((long)len_k * p.ldk + D) * 2 >= (1L << 32) || ((long)len_k * p.ldv + D) * 2 >= (1L << 32)) lmi_trap();
+    // 32-bit buffer offsets: one sequence's K (or V) rows must span < 4 GiB (ldk = 6144 halves: 349 k keys).  Where the host knows
+    // the longest key sequence (self-attention: cu_k == cu_q; decode: max_seqlen_k) the launcher has already returned LMI_EINVAL;
+    // only cross-attention launches, whose key lengths exist on the device alone, carry the check into the kernel.
+    if (p.check_k_extent && (((long)len_k * p.ldk + D) * 2 >= (1L << 32) || ((long)len_k * p.ldv + D) * 2 >= (1L << 32))) lmi_trap();
     const BufRsrc k_buf = make_buf(k_base, len_k > 0 ? (unsigned)(((long)(len_k - 1) * p.ldk + D) * 2) : 0u);
     const BufRsrc v_buf = make_buf(v_base, len_k > 0 ? (unsigned)(((long)(len_k - 1) * p.ldv + D) * 2) : 0u);
     unsigned p_ko[PPW], p_vo[PPW];
@@ -380,7 +376,6 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     auto issue_piece = [&](int j, int t, int slot) {
         const int i = j < PPW ? j : j - PPW;
         if ((G::PIECES % NW) != 0 && wave + NW * i >= G::PIECES) return;      // wave-uniform; only ragged piece counts (d = 72) branch
-        if (LMI_ABL(4) && t >= 2) return;
         char* dst = smem + slot * 2 * G::TILE_BYTES + (j < PPW ? 0 : G::TILE_BYTES) + (wave + NW * i) * 1024;
         if (j < PPW) glds16_buf(k_buf, p_ko[i], (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldk, dst);
         else glds16_buf(v_buf, p_vo[i], (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldv, dst);
@@ -457,7 +452,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
                 }
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    if (!LMI_ABL(2)) s[b] = mfma32(kf[ks][b], qf[ks], s[b]); else s[b][ks] += (float)kf[ks][b][0];
+                    s[b] = mfma32(kf[ks][b], qf[ks], s[b]);
                 }
                 if (DMA && ks < 2 * PPW) issue_piece(ks, t + 1, (t + 1 - t_begin) & 1);
             }
@@ -515,7 +510,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = LMI_ABL(1) ? s[b][r] : fast_exp2(s[b][r] * c2 - mc);
+                const float pv = fast_exp2(s[b][r] * c2 - mc);
                 psum += pv;
                 pf[b][r >> 3][r & 7] = (T)pv;
             }
@@ -533,7 +528,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
                 const u32x4 a = u32x4{vlo[g & 1][db][0], vlo[g & 1][db][1], vhi[g & 1][db][0], vhi[g & 1][db][1]};
-                if (!LMI_ABL(3)) o_acc[db] = mfma32(__builtin_bit_cast(T8, a), pf[g >> 1][g & 1], o_acc[db]); else o_acc[db][g] += (float)__builtin_bit_cast(T8, a)[0] * (float)pf[g >> 1][g & 1][0];
+                o_acc[db] = mfma32(__builtin_bit_cast(T8, a), pf[g >> 1][g & 1], o_acc[db]);
             }
         }
 #ifdef LMI_ATTN_PROF

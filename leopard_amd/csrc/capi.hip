@@ -3,6 +3,7 @@
 #include "../../include/leopard_amd.h"
 
 #include <atomic>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -73,15 +74,15 @@ typedef GemmCfg<128, 256, 2, 4, 3> Cfg4;   // 144 KiB LDS, wave tile 64x64, 3-sl
 typedef GemmCfg<64, 128, 2, 2, 3> CfgS;    //  72 KiB LDS, 256 threads, wave tile 32x64: small-M problems
 typedef GemmCfg<64, 128, 2, 2, 6> CfgS6;   // 144 KiB LDS: 5 k-tiles in flight for latency-bound weight streaming at small M
 constexpr int kNumGemmCfg = 10;             // 0-4 ring geometries; 5-7 staggered 256x256 schedules; 8-9 small-M rings
-int g_gemm_cfg = -1;                        // -1 = choose per shape
-int g_gemm_group_m = GEMM_GROUP_M;
-int g_gemm_order = 0;
+std::atomic<int> g_gemm_cfg{-1};            // -1 = choose per shape (options are process-wide; relaxed atomics: launches on other threads read them)
+std::atomic<int> g_gemm_group_m{GEMM_GROUP_M};
+std::atomic<int> g_gemm_order{0};
 // per-shape-class geometry (end-to-end A/B knobs; defaults = best measured on the C3 prefill, which runs at the power cap
 // and does not always agree with isolated bursts of one GEMM)
-int g_gemm_wide = 5;                        // N >= 2048, K > 1536 (Llama projections)
-int g_gemm_short = 5;                       // N >= 2048, K <= 1536 (SigLIP qkv, fc1)
-int g_gemm_narrow = 2;                      // N < 2048, K >= 2048 (SigLIP fc2)
-int g_gemm_small = 0;                       // N < 2048, K < 2048 (SigLIP out_proj, patch embedding)
+std::atomic<int> g_gemm_wide{5};                        // N >= 2048, K > 1536 (Llama projections)
+std::atomic<int> g_gemm_short{5};                       // N >= 2048, K <= 1536 (SigLIP qkv, fc1)
+std::atomic<int> g_gemm_narrow{2};                      // N < 2048, K >= 2048 (SigLIP fc2)
+std::atomic<int> g_gemm_small{0};                       // N < 2048, K < 2048 (SigLIP out_proj, patch embedding)
 
 template <typename T, int EPI, int ACT, int AMODE, typename C>
 int launch_gemm_cfg(const GemmArgs& a, void* stream) {
@@ -109,12 +110,13 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
 // configs C1 / C2, Idefics2's text side) are decided by the tile count instead: cost = tiles per CU x tile area / the geometry's
 // relative efficiency on large problems (256x256 staggered 1.0, 256x128 0.85, 128x128 0.75, 64x128 0.55; tools/sweep_fp8_cfg.py and
 // the round-1 sweeps).  Every C3 / C5 shape has >= 464 tiles and evaluates to its class geometry, so the headline path is unchanged.
-int g_gemm_auto_small = 1;                  // lmi_set_option("gemm.auto_small", 0) = class rules only (A/B)
+std::atomic<int> g_gemm_auto_small{1};                  // lmi_set_option("gemm.auto_small", 0) = class rules only (A/B)
 int choose_gemm_cfg(const GemmArgs& a) {
-    if (g_gemm_cfg >= 0) return g_gemm_cfg;
+    const int forced = g_gemm_cfg.load(std::memory_order_relaxed);
+    if (forced >= 0) return forced;
     if (a.M < 512) return 8;
-    const int cls = a.N >= 2048 ? (a.K <= 1536 ? g_gemm_short : g_gemm_wide) : (a.K >= 2048 ? g_gemm_narrow : g_gemm_small);
-    if (!g_gemm_auto_small) return cls;
+    const int cls = a.N >= 2048 ? (a.K <= 1536 ? g_gemm_short.load() : g_gemm_wide.load()) : (a.K >= 2048 ? g_gemm_narrow.load() : g_gemm_small.load());
+    if (!g_gemm_auto_small.load()) return cls;
     struct Geo { int cfg, bm, bn; float eff; };
     auto geo_of = [](int cfg) -> Geo {
         switch (cfg) {
@@ -237,8 +239,8 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
                AttnGeom<D>::SMEM, stream, a);
     return check_launch("lmi_attn_varlen_fwd");
 }
-int g_attn_lds_pad = 0;                      // experiment knob: extra dynamic LDS per workgroup (lowers residency)
-int g_attn_dma = 1;                          // 1 = LDS-DMA kernel (production), 0 = register-staged kernel (cross-checks)
+std::atomic<int> g_attn_lds_pad{0};                      // experiment knob: extra dynamic LDS per workgroup (lowers residency)
+std::atomic<int> g_attn_dma{1};                          // 1 = LDS-DMA kernel (production), 0 = register-staged kernel (cross-checks)
 
 template <typename T, int D, bool CAUSAL>
 int launch_attn_dma(const AttnArgs& a, int n_seq, int max_q, void* stream) {
@@ -435,7 +437,7 @@ int lmi_set_option(const char* key, int value) {
     if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "gemm.auto_small")) { g_gemm_auto_small = value ? 1 : 0; return LMI_OK; }
     {
-        struct { const char* key; int* var; } classes[] = {{"gemm.wide", &g_gemm_wide}, {"gemm.short_k", &g_gemm_short},
+        struct { const char* key; std::atomic<int>* var; } classes[] = {{"gemm.wide", &g_gemm_wide}, {"gemm.short_k", &g_gemm_short},
                                                           {"gemm.narrow_n", &g_gemm_narrow}, {"gemm.small", &g_gemm_small}};
         for (auto& c : classes)
             if (!strcmp(key, c.key)) {
@@ -718,6 +720,12 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
     a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr;
+    a.check_k_extent = 1;
+    if (cu_seqlens_k == cu_seqlens_q) {                              // self-attention: the longest key sequence is max_seqlen_q
+        if (((long)max_seqlen_q * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_q * ldv + head_dim) * 2 >= (1L << 32))
+            return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: one sequence's K / V rows span >= 4 GiB (max_seqlen %d, ldk %d, ldv %d)", max_seqlen_q, ldk, ldv);
+        a.check_k_extent = 0;
+    }
     if (head_dim == 128)
         LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
                        (dispatch_attn<bf16_t, 128>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
@@ -753,6 +761,9 @@ int lmi_attn_decode_fwd(const void* q, const void* k, const void* v, void* out, 
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
+    if (((long)max_seqlen_k * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_k * ldv + head_dim) * 2 >= (1L << 32))
+        return fail(LMI_EINVAL, "lmi_attn_decode_fwd: one sequence's K / V rows span >= 4 GiB (max_seqlen_k %d, ldk %d, ldv %d)", max_seqlen_k, ldk, ldv);
+    a.check_k_extent = 0;
     a.n_splits = decode_splits(max_seqlen_k, &a.split_tiles);
     a.part_rows = q_rows;
     a.part_o = (float*)workspace;
@@ -846,18 +857,16 @@ struct Rccl {
 Rccl g_rccl;
 std::atomic<int> g_rccl_state{0};                              // 0 = not tried, 1 = bound, -1 = unavailable
 
-int rccl_bind() {
-    int st = g_rccl_state.load();
-    if (st != 0) return st;
+std::once_flag g_rccl_once;
+void rccl_bind_once() {
 #ifdef LMI_EMU
     g_rccl_state = -1;
-    return -1;
 #else
     static const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
     for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;     // a copy already in the process (PyTorch's)
     if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) { g_rccl_state = -1; return -1; }
+    if (!h) { g_rccl_state = -1; return; }
     Rccl r;
     r.handle = h;
     bool ok = true;
@@ -871,11 +880,14 @@ int rccl_bind() {
     r.ReduceScatter = (decltype(r.ReduceScatter))sym("ncclReduceScatter");
     r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-    if (!ok) { g_rccl_state = -1; return -1; }
-    g_rccl = r;
-    g_rccl_state = 1;
-    return 1;
+    if (!ok) { g_rccl_state = -1; return; }
+    g_rccl = r;                                                    // written once, under the once_flag; readers see it after the state store
+    g_rccl_state.store(1, std::memory_order_release);
 #endif
+}
+int rccl_bind() {                                                  // thread-safe: two threads' first collectives cannot both write g_rccl
+    std::call_once(g_rccl_once, rccl_bind_once);
+    return g_rccl_state.load(std::memory_order_acquire);
 }
 int rccl_fail(const char* what, int rc) {
     return fail(LMI_ECOMM, "%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");

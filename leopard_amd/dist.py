@@ -198,13 +198,21 @@ class RcclComm(Comm):
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.sent_bytes = 0
-        uid = (C.c_char * 128)()
+        # Rank 0 creates the unique id and EVERY rank takes part in its broadcast, whatever happened on rank 0: the message is one
+        # status byte + the 128 id bytes.  (Raising on rank 0 before the broadcast would leave the other ranks blocked in it while
+        # rank 0 moved on to the next collective — mismatched collectives, a hang instead of the agreed fallback in get_comm.)
+        uid, status, err = (C.c_char * 128)(), 1, ""
         if self.rank == 0:
-            self._check(self.lib.lmi_comm_unique_id(uid))
-        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
+            rc = self.lib.lmi_comm_unique_id(uid)
+            if rc != 0:
+                status, err = 0, f"libleopard_amd comm error {rc}: {self.lib.lmi_last_error().decode()}"
+        t = torch.tensor([status] + list(bytes(uid)), dtype=torch.uint8)
         t = t.to(self.device) if dist.get_backend() != "gloo" else t
         dist.broadcast(t, src=0)
-        uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+        msg = t.cpu().tolist()
+        if msg[0] != 1:
+            raise RuntimeError(err or "rank 0 could not create the RCCL unique id (lmi_comm_unique_id)")
+        uid = (C.c_char * 128).from_buffer_copy(bytes(msg[1:]))
         handle = C.c_void_p()
         torch.cuda.set_device(self.device)
         self._check(self.lib.lmi_comm_init(self.rank, self.world, uid, C.byref(handle)))
@@ -307,10 +315,14 @@ def encode_images_sharded(engine, tiles: torch.Tensor) -> torch.Tensor:
     tpt = engine.cfg.tokens_per_tile
     D = engine.cfg.text_config.hidden_size
     max_rows = max(b - a for a, b in slices) * tpt
-    mine = torch.zeros(max_rows, D, dtype=torch.float32, device=tiles.device)
+    # exchange dtype: the 16-bit compute type by default (SURVEY.md 8e budgets 58 MB for C3; the merged rows are rounded to that
+    # type at their first hand-over to a GEMM operand anyway, one layer later), fp32 when `engine.tp_vision_gather_dtype` asks
+    # for the bit-identical-to-one-rank result (parity runs)
+    gdt = getattr(engine, "tp_vision_gather_dtype", None) or engine.dtype
+    mine = torch.zeros(max_rows, D, dtype=gdt, device=tiles.device)
     if hi > lo:
         mine[:(hi - lo) * tpt] = engine.encode_images(tiles[lo:hi].contiguous())
-    gathered = torch.empty(world * max_rows, D, dtype=torch.float32, device=tiles.device)
+    gathered = torch.empty(world * max_rows, D, dtype=gdt, device=tiles.device)
     comm.all_gather(gathered, mine)                               # equal-size padded shards, one collective
     parts = [gathered[r * max_rows:r * max_rows + (b - a) * tpt] for r, (a, b) in enumerate(slices)]
-    return torch.cat(parts, dim=0)
+    return torch.cat(parts, dim=0).float()

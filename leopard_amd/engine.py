@@ -108,9 +108,10 @@ class LeopardEngine:
                 raise RuntimeError(f"tensor-parallel weights (tp_size {weights.tp_size}) need an initialised process group of that size")
         self.tp_chunks = 2             # row chunks per layer under TP: chunk c's collectives overlap chunk c+1's GEMMs
         self.tp_comm_dtype = None      # dtype of the reduce-scattered partial products: None = the compute type, torch.float32 = exact sums
+        self.tp_vision_gather_dtype = None   # all-gather of the projected visual tokens: None = the compute type (58 MB at C3), torch.float32 = bit-identical to one rank
         self._comm_stream = None
         self.graph_encode = False      # capture the vision encode per ViT-input count in a HIP graph (BASELINE config 5)
-        self._encode_graphs: Dict[int, tuple] = {}
+        self._encode_graphs: Dict[tuple, tuple] = {}   # (ViT-input count, stream) -> (graph, static in, static out)
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
@@ -294,7 +295,10 @@ class LeopardEngine:
         of the eager path bit for bit (same kernels, same order).  The returned tensor is the graph's static output buffer:
         it is overwritten by the next encode of the same N (callers here consume it immediately in embed_merge)."""
         n = tiles.shape[0]
-        ent = self._encode_graphs.get(n)
+        # one graph + static buffers per (N, launch stream): replays of one graph from two streams (bench.py --inflight > 1) would
+        # share the static buffers with nothing ordering them
+        key = (n, torch.cuda.current_stream(self.device).cuda_stream)
+        ent = self._encode_graphs.get(key)
         if ent is None:
             static_in = torch.empty_like(tiles)
             static_in.copy_(tiles)
@@ -308,7 +312,7 @@ class LeopardEngine:
                 static_out = self.project(self.vision_tower(static_in), n)
             if len(self._encode_graphs) >= 8:                                  # a handful of distinct N per workload; bound the pools
                 self._encode_graphs.pop(next(iter(self._encode_graphs)))
-            ent = self._encode_graphs[n] = (g, static_in, static_out)
+            ent = self._encode_graphs[key] = (g, static_in, static_out)
         g, static_in, static_out = ent
         static_in.copy_(tiles)
         g.replay()
@@ -471,10 +475,12 @@ class LeopardEngine:
         n_tiles = 0
         if visual_tokens is None and tiles is not None and tiles.shape[0] > 0:
             n_tiles = tiles.shape[0]
-            vit = self.vision_tower(tiles)
-            visual_tokens = self.project(vit, n_tiles)
             if keep_parts:
+                vit = self.vision_tower(tiles)
+                visual_tokens = self.project(vit, n_tiles)
                 parts["vit"] = vit
+            else:
+                visual_tokens = self.encode_images(tiles)
         elif visual_tokens is not None:
             n_tiles = visual_tokens.shape[0] // self.cfg.tokens_per_tile
         if keep_parts and visual_tokens is not None:
@@ -657,7 +663,7 @@ class LeopardEngine:
         visual = None
         if tiles:
             all_tiles = torch.cat(tiles, dim=0)
-            visual = self.project(self.vision_tower(all_tiles), all_tiles.shape[0])
+            visual = self.encode_images(all_tiles)                 # the graph-captured encode when `graph_encode` is set
         xs, seq_lens, row = [], [], 0
         for ids, t in samples:
             n = 0 if t is None else t.shape[0]
@@ -835,7 +841,7 @@ class LeopardEngine:
         visual = None
         if tiles:
             all_tiles = torch.cat(tiles, dim=0)
-            visual = self.project(self.vision_tower(all_tiles), all_tiles.shape[0])
+            visual = self.encode_images(all_tiles)
         xs, seq_lens, row = [], [], 0
         for ids, t in samples:
             n = 0 if t is None else t.shape[0]

@@ -153,12 +153,15 @@ class Idefics2ForConditionalGeneration:
         # stock Idefics2 generation_config suppresses <fake_token_around_image> and <image> (bad_words_ids): never generated
         self.bad_words_ids = tuple(int(b) for b in (bad_words_ids if bad_words_ids is not None
                                                     else (config.image_token_id - 1, config.image_token_id)))
-        self.patch_validity = "all"       # see unpad_images; set to "any" to reproduce transformers 4.4x on mixed-size samples
+        # see unpad_images.  "any" = the reference's own rule (`patches_subgrid.sum(...) > 0`: megatron_patch/model/idefics2/
+        # idefics_vlm_model.py:608, language_model_llama3.py:654, and the transformers 4.4x releases Leopard-Idefics2 ran with);
+        # "all" = transformers 5.x, kept for the golden fixture pinned to that version
+        self.patch_validity = "any"
         self._engine: Optional[Idefics2Engine] = None
         self.device = torch.device("cpu")
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype=torch.float16, ops: Optional[Ops] = None, patch_validity: str = "all", **unused):
+    def from_pretrained(cls, path: str, torch_dtype=torch.float16, ops: Optional[Ops] = None, patch_validity: str = "any", **unused):
         cfg = load_idefics2_config(path)
         eos, bad = (2, 32002), None
         gpath = os.path.join(path, "generation_config.json")
@@ -196,7 +199,7 @@ class Idefics2ForConditionalGeneration:
         return self._engine
 
     @staticmethod
-    def unpad_images(pixel_values: torch.Tensor, pixel_attention_mask: Optional[torch.Tensor], patch_validity: str = "all",
+    def unpad_images(pixel_values: torch.Tensor, pixel_attention_mask: Optional[torch.Tensor], patch_validity: str = "any",
                      patch: int = 14) -> List[torch.Tensor]:
         """[1, n, 3, H, W] (+ mask [1, n, H, W]) -> per-image fp32 [3, h', w']; an image that is entirely padding (all zeros) is
         dropped, as the third-party model does before its vision tower.
@@ -206,7 +209,8 @@ class Idefics2ForConditionalGeneration:
           "all"  a patch counts when ALL its pixels are real (`patch mask sum == patch_size**2`: transformers 5.x, the version the
                  golden fixture tests/golden/idefics2_tiny.npz is pinned to) -> floor(h / P) x floor(w / P) patches, remainder
                  pixels dropped;
-          "any"  a patch counts when ANY of its pixels is real (`> 0`: the 4.4x releases Leopard-Idefics2 was run with,
+          "any"  (default) a patch counts when ANY of its pixels is real (`> 0`: the reference's own model code,
+                 megatron_patch/model/idefics2/idefics_vlm_model.py:608, and the 4.4x releases Leopard-Idefics2 was run with,
                  requirements.txt:16) -> a partly zero-padded last patch row / column is kept wherever the common canvas has room
                  for it, i.e. for the smaller images of a mixed-size sample (fixture tests/golden/idefics2_tiny_any.npz).
         The crop returned here is (rows, cols) = patches x P in both cases, zero padding included under "any"."""

@@ -26,6 +26,12 @@ Two ways to use it, neither edits ``evaluations/``:
 (the second form works because ``hf_shim/sitecustomize.py`` calls ``install()`` at interpreter start).  ``rouge`` and
 ``editdistance`` (scorer dependencies, EVAL:13, eval_utils.py) get minimal fallbacks only when they are not installed.
 
+Precision: EVAL:373 asks for ``torch_dtype=torch.float32``; the engine computes in a 16-bit MFMA operand type with fp32
+accumulation and fp32 residual streams (``LEOPARD_AMD_COMPUTE_DTYPE`` = f16 (default) | bf16).  That narrowing is NOT silent: every
+``from_pretrained`` emits a ``UserWarning`` when the requested and the compute type differ and records both in
+``leopard_amd_run_info.json`` in the working directory — next to the shard files ``results_*`` the script writes — so that a result
+row can always be traced to the arithmetic that produced it.
+
 Smoke-run knobs (GPU-less containers / CI only; the product path needs none of them):
     LEOPARD_AMD_LIB             alternative C-ABI library (the CPU kernel-logic emulator build); implies host tensors
     LEOPARD_AMD_FORCE_DEVICE    device the model is built on, whatever the script asks for ("cpu" with the emulator)
@@ -53,6 +59,46 @@ def _device(requested):
     return os.environ.get("LEOPARD_AMD_FORCE_DEVICE") or requested
 
 
+def _compute_dtype(default):
+    import torch
+    name = os.environ.get("LEOPARD_AMD_COMPUTE_DTYPE", "").lower()
+    if not name:
+        return default
+    if name not in ("f16", "fp16", "float16", "bf16", "bfloat16"):
+        raise ValueError("LEOPARD_AMD_COMPUTE_DTYPE must be f16 or bf16")
+    return torch.bfloat16 if name.startswith("b") else torch.float16
+
+
+def _record_run_info(model_class: str, checkpoint: str, requested, compute) -> None:
+    """Side file of the result rows: what arithmetic the script's ``torch_dtype`` request was actually served with."""
+    import json
+    import warnings
+    req, cmp_ = str(requested).replace("torch.", ""), str(compute).replace("torch.", "")
+    if requested is not None and requested != compute:
+        warnings.warn(f"{model_class}.from_pretrained: torch_dtype={req} was requested; leopard_amd computes with {cmp_} MFMA operands "
+                      f"(fp32 accumulation, fp32 residual streams) — recorded in leopard_amd_run_info.json", UserWarning, stacklevel=3)
+    info = {"model_class": model_class, "checkpoint": str(checkpoint), "requested_torch_dtype": req, "compute_dtype": cmp_,
+            "accumulate_dtype": "float32", "residual_stream_dtype": "float32", "library": os.environ.get("LEOPARD_AMD_LIB") or "libleopard_amd.so",
+            "fallback_scorers": sorted(_FALLBACK_SCORERS)}
+    try:
+        with open("leopard_amd_run_info.json", "w") as f:
+            json.dump(info, f, indent=1)
+    except OSError:                                   # read-only working directory: the warning above still went out
+        pass
+
+
+_FALLBACK_SCORERS = set()
+
+
+def _warn_fallback_scorer(name: str) -> None:
+    import warnings
+    if name not in _FALLBACK_SCORERS:
+        _FALLBACK_SCORERS.add(name)
+        warnings.warn(f"the '{name}' package is not installed: leopard_amd's minimal stand-in is in use.  Scores computed with it are for "
+                      "smoke runs only and are NOT comparable with the reference's (install the real package for reportable numbers)",
+                      UserWarning, stacklevel=3)
+
+
 def _cap_tokens(n):
     cap = os.environ.get("LEOPARD_AMD_MAX_NEW_TOKENS")
     return min(int(n), int(cap)) if cap else int(n)
@@ -76,8 +122,11 @@ def _llava_class():
             super().__init__(config, lambda dev, dt: CheckpointSource(path, dev, dt), compute_dtype, ops)
 
         @classmethod
-        def from_pretrained(cls, path, torch_dtype=torch.float32, compute_dtype=torch.float16, ops=None, **unused):
+        def from_pretrained(cls, path, torch_dtype=torch.float32, compute_dtype=None, ops=None, **unused):
             cfg = load_config(path)
+            if compute_dtype is None:                     # a 16-bit request is honoured as is; fp32 (EVAL:373) is served in 16 bits, loudly
+                compute_dtype = _compute_dtype(torch_dtype if torch_dtype in (torch.float16, torch.bfloat16) else torch.float16)
+            _record_run_info("LlavaForConditionalGeneration", path, torch_dtype, compute_dtype)
             cls._pending = (path, compute_dtype, ops if ops is not None else _ops_from_env())
             try:
                 return cls(cfg)
@@ -102,8 +151,12 @@ def _idefics2_classes():
     class AutoModelForVision2Seq(IC.Idefics2ForConditionalGeneration):
         @classmethod
         def from_pretrained(cls, path, **kw):
+            import torch
             kw.setdefault("ops", _ops_from_env())
-            return super().from_pretrained(path, **kw)
+            req = kw.get("torch_dtype", torch.float16)
+            m = super().from_pretrained(path, **kw)
+            _record_run_info("AutoModelForVision2Seq", path, req, m.compute_dtype)
+            return m
 
         def to(self, device):
             return super().to(_device(device))
@@ -136,6 +189,7 @@ def _scorer_fallbacks():
                 return prev[-1]
 
             def get_scores(self, hyps, refs, avg=False):
+                _warn_fallback_scorer("rouge")
                 if isinstance(hyps, str):
                     hyps, refs = [hyps], [refs]
                 out = []
@@ -145,7 +199,8 @@ def _scorer_fallbacks():
                         p, rc = (overlap / nh if nh else 0.0), (overlap / nr if nr else 0.0)
                         return {"r": rc, "p": p, "f": (2 * p * rc / (p + rc) if p + rc else 0.0)}
                     uni = len(set(ht) & set(rt))
-                    out.append({"rouge-1": f(uni, len(set(ht)), len(set(rt))), "rouge-2": f(0, 1, 1),
+                    hb, rb = set(zip(ht, ht[1:])), set(zip(rt, rt[1:]))          # unique bigrams, as the package counts n-grams
+                    out.append({"rouge-1": f(uni, len(set(ht)), len(set(rt))), "rouge-2": f(len(hb & rb), len(hb), len(rb)),
                                 "rouge-l": f(self._lcs(ht, rt), len(ht), len(rt))})
                 if avg:
                     keys = out[0].keys() if out else []
@@ -159,6 +214,7 @@ def _scorer_fallbacks():
         m = types.ModuleType("editdistance")
 
         def _eval(a, b):
+            _warn_fallback_scorer("editdistance")             # (exact Levenshtein distance, as the package computes; warned all the same)
             prev = list(range(len(b) + 1))
             for i, x in enumerate(a, 1):
                 cur = [i]

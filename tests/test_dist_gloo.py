@@ -36,9 +36,12 @@ def _worker(rank, world, port, out):
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
     eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
     tiles = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (3, 28, 28, 3), dtype=np.uint8))
-    vis = D.encode_images_sharded(eng, tiles)
     full = eng.encode_images(tiles)
-    out.put((rank, mine, tmax, bool(torch.equal(vis, full)), tuple(vis.shape)))
+    vis16 = D.encode_images_sharded(eng, tiles)             # default: exchanged in the 16-bit compute type (half the bytes)
+    eng.tp_vision_gather_dtype = torch.float32              # parity runs: exchanged as fp32 -> bit-identical to one rank
+    vis = D.encode_images_sharded(eng, tiles)
+    ok = bool(torch.equal(vis, full)) and bool(torch.equal(vis16, full.to(torch.float16).float()))
+    out.put((rank, mine, tmax, ok, tuple(vis.shape)))
     D.barrier()
 
 

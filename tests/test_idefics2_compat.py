@@ -59,8 +59,11 @@ def test_processor_tensors():
     assert torch.equal(out["pixel_values"][0, 0, :, :30, :56], ref0)
     with pytest.raises(ValueError):
         proc(text="no image token", images=imgs)
-    un = IC.Idefics2ForConditionalGeneration.unpad_images(out["pixel_values"], out["pixel_attention_mask"])
+    un = IC.Idefics2ForConditionalGeneration.unpad_images(out["pixel_values"], out["pixel_attention_mask"], "all")
     assert [tuple(u.shape) for u in un] == [(3, 30, 56), (3, 40, 30)]
+    # the default is the reference's own rule (idefics_vlm_model.py:608, `> 0`): whole patches of the 40 x 56 canvas with any real pixel
+    un = IC.Idefics2ForConditionalGeneration.unpad_images(out["pixel_values"], out["pixel_attention_mask"])
+    assert [tuple(u.shape) for u in un] == [(3, 28, 56), (3, 28, 42)]
 
 
 def test_generate_through_the_surface_matches_oracle():
