@@ -204,6 +204,14 @@ int lmi_attn_decode_fwd(const void* q, const void* k, const void* v, void* out, 
                         int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
                         int dtype, void* stream);
 
+/* The same for a BATCH of decode sequences whose KV caches share one pooled buffer (several samples per GPU;
+ * the reference loop EVAL:448-454 is batch 1): sequence s owns cache rows [k_begin[s], k_begin[s] + k_len[s]); k_begin is static
+ * (slot * capacity), k_len advances on the device, so the launch can sit in a captured HIP graph. */
+int lmi_attn_decode_pool(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* k_begin, const int* k_len,
+                         int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                         int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                         int dtype, void* stream);
+
 /* RoPE (rotate-half; cos/sin fp32 [S, head_dim/2] built from position_ids and the llama3-scaled inverse
  * frequencies, rotary_pos_embedding.py:48-83,197-239) applied in place to the q and k heads of packed qkv rows
  * [S, ld]; when k_cache/v_cache are non-null also appends rotated K and V to the cache rows cache_pos0.. */
@@ -217,6 +225,11 @@ int lmi_rope_qk(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int hea
 int lmi_rope_qk_at(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all,
                    const float* sin_all, void* k_cache, void* v_cache, int ld_cache, const int* pos_dev, int dtype, void* stream);
 
+/* Batched decode: row s is sequence s's next token at position pos_rows_dev[s]; its rotated K and its V go to row
+ * s * cache_stride + pos_rows_dev[s] of the pooled caches (EVAL:291-320 per sequence). */
+int lmi_rope_qk_rows(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all, const float* sin_all,
+                     void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream);
+
 /* a10 — get_input_embeddings()(input_ids) + _merge_input_ids_with_image_features (EVAL:263,284-287; analogue
  * megatron_patch/model/llava/vlm_model.py:526-533): out fp32 [S, D]; src[s] >= 0 -> embed_table[ids[src[s]]],
  * src[s] < 0 -> visual_tokens[-src[s]-1] (fp32 [., ld_feats]).  ids, src: int64 on device. */
@@ -227,6 +240,17 @@ int lmi_embed_merge(const int64_t* ids, const int64_t* src, const void* embed_ta
  * and the decode step (EVAL:291-320).  epilogue: 0 store fp32, 1 store T, 2 fp32 +=, 3 SwiGLU (N/2 outputs). */
 int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, int epilogue,
              int dtype, void* stream);
+
+/* M <= 16 weight-streaming GEMM: the projections of a batched decode step (the weight stream of one token serves M tokens).
+ * out[M, .] = epilogue(X[M, K] . W[N, K]^T), X and W 16-bit, K % 128 == 0.  epilogue: LMI_SKINNY_STORE (T out [M, N]),
+ * LMI_SKINNY_RESIDUAL (fp32 out += ), LMI_SKINNY_SWIGLU (W rows interleaved [32 gate | 32 up]; T out [M, N/2]),
+ * LMI_SKINNY_STORE_F32. */
+#define LMI_SKINNY_STORE 0
+#define LMI_SKINNY_RESIDUAL 1
+#define LMI_SKINNY_SWIGLU 2
+#define LMI_SKINNY_STORE_F32 3
+int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int dtype,
+                    void* stream);
 
 /* Same with the RMSNorm of the decode step folded in: x is the fp32 residual row [K], norm_weight fp32 [K], and the row
  * fed to the product is T(norm_weight * (x * rsqrt(mean(x^2) + eps))) — the arithmetic of lmi_rmsnorm, without its launch.

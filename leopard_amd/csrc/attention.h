@@ -32,6 +32,8 @@ struct AttnArgs {
     void* out;                // [total_q, ...] head h at out + row*ldo + h*D
     const int* cu_q;          // [nseq+1]
     const int* cu_k;          // [nseq+1]
+    const int* k_len;         // optional [nseq] (LDS-DMA kernel only): sequence s's keys are rows [cu_k[s], cu_k[s] + k_len[s]) — a pooled,
+                              // strided KV cache of a decode batch, where cu_k holds the slots' first rows and only k_len changes per step
     int ldq, ldk, ldv, ldo;
     int n_heads, n_kv_heads;
     float scale;              // softmax scale (head_dim^-0.5)
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     const int qb = p.n_qblocks - 1 - rest % p.n_qblocks, seq = rest / p.n_qblocks;
     const int kvh = h_idx % p.n_kv_heads, head = kvh * (p.n_heads / p.n_kv_heads) + h_idx / p.n_kv_heads;
     const int q_beg = p.cu_q[seq], len_q = p.cu_q[seq + 1] - q_beg;
-    const int k_beg = p.cu_k[seq], len_k = p.cu_k[seq + 1] - k_beg;
+    const int k_beg = p.cu_k[seq], len_k = p.k_len ? p.k_len[seq] : p.cu_k[seq + 1] - k_beg;
     const int q0 = qb * BQ;
     if (q0 >= len_q) return;
     const int shift = len_k - len_q;

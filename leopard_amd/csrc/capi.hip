@@ -12,6 +12,7 @@
 #include "elementwise.h"
 #include "patch_embed.h"
 #include "gemm.h"
+#include "skinny.h"
 
 using namespace lmi;
 
@@ -403,6 +404,25 @@ int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, in
     return check_launch("lmi_attn_decode_fwd");
 }
 
+template <typename T>
+int skinny_impl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, void* stream) {
+    const int units = (epilogue == LMI_SKINNY_SWIGLU) ? N / 32 : N / 16;
+    switch (epilogue) {
+        case LMI_SKINNY_STORE: LMI_LAUNCH((skinny_gemm_kernel<T, SK_STORE_T>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+        case LMI_SKINNY_RESIDUAL: LMI_LAUNCH((skinny_gemm_kernel<T, SK_RESID_F32>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+        case LMI_SKINNY_SWIGLU: LMI_LAUNCH((skinny_gemm_kernel<T, SK_SWIGLU_T>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+        default: LMI_LAUNCH((skinny_gemm_kernel<T, SK_STORE_F32>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+    }
+    return check_launch("lmi_gemm_skinny");
+}
+
+template <typename T>
+int rope_rows_impl(void* qkv, int S, int ld, int nq, int nkv, int D, const float* c, const float* s, void* kc, void* vc, int ldc,
+                          long cache_stride, const int* pos, int grid, void* stream) {
+    LMI_LAUNCH((rope_rows_kernel<T>), dim3(grid), dim3(256), 0, stream, (T*)qkv, S, ld, nq, nkv, D, c, s, (T*)kc, (T*)vc, ldc, cache_stride, pos);
+    return check_launch("lmi_rope_qk_rows");
+}
+
 int rope_entry(const char* who, void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_table,
                       const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, const int* pos_dev,
                       int dtype, void* stream) {
@@ -717,7 +737,7 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
         return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: alignment");
     if (n_seq == 0 || max_seqlen_q == 0) return LMI_OK;
     AttnArgs a;
-    a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = nullptr;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
     a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr;
     a.check_k_extent = 1;
@@ -743,26 +763,26 @@ int64_t lmi_attn_decode_workspace_bytes(int q_rows, int n_heads, int head_dim, i
     return (int64_t)n * q_rows * n_heads * (head_dim + 2) * 4;
 }
 
-int lmi_attn_decode_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
-                        int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
-                        int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
-                        int dtype, void* stream) {
-    if (!q || !k || !v || !out || !cu_seqlens_q || !cu_seqlens_k || !workspace) return fail(LMI_EINVAL, "lmi_attn_decode_fwd: null pointer");
+static int attn_decode_entry(const char* who, const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
+                             const int* k_len, int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                             int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                             int dtype, void* stream) {
+    if (!q || !k || !v || !out || !cu_seqlens_q || !cu_seqlens_k || !workspace) return fail(LMI_EINVAL, "%s: null pointer", who);
     if (n_seq < 0 || max_seqlen_q < 0 || max_seqlen_k < 0 || q_rows < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads))
-        return fail(LMI_EINVAL, "lmi_attn_decode_fwd: bad sizes");
-    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_attn_decode_fwd: head_dim %d (only 128)", head_dim);
-    if (window < 0) return fail(LMI_EINVAL, "lmi_attn_decode_fwd: window must be >= 0");
+        return fail(LMI_EINVAL, "%s: bad sizes", who);
+    if (head_dim != 128) return fail(LMI_EINVAL, "%s: head_dim %d (only 128)", who, head_dim);
+    if (window < 0) return fail(LMI_EINVAL, "%s: window must be >= 0", who);
     if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) ||
         !aligned16(workspace))
-        return fail(LMI_EINVAL, "lmi_attn_decode_fwd: alignment");
+        return fail(LMI_EINVAL, "%s: alignment", who);
     const int64_t need = lmi_attn_decode_workspace_bytes(q_rows, n_heads, head_dim, max_seqlen_k);
-    if (workspace_bytes < need) return fail(LMI_EINVAL, "lmi_attn_decode_fwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    if (workspace_bytes < need) return fail(LMI_EINVAL, "%s: workspace %lld < %lld bytes", who, (long long)workspace_bytes, (long long)need);
     if (n_seq == 0 || max_seqlen_q == 0 || q_rows == 0) return LMI_OK;
     AttnArgs a;
-    a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = k_len;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
     if (((long)max_seqlen_k * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_k * ldv + head_dim) * 2 >= (1L << 32))
-        return fail(LMI_EINVAL, "lmi_attn_decode_fwd: one sequence's K / V rows span >= 4 GiB (max_seqlen_k %d, ldk %d, ldv %d)", max_seqlen_k, ldk, ldv);
+        return fail(LMI_EINVAL, "%s: one sequence's K / V rows span >= 4 GiB (max_seqlen_k %d, ldk %d, ldv %d)", who, max_seqlen_k, ldk, ldv);
     a.check_k_extent = 0;
     a.n_splits = decode_splits(max_seqlen_k, &a.split_tiles);
     a.part_rows = q_rows;
@@ -770,6 +790,49 @@ int lmi_attn_decode_fwd(const void* q, const void* k, const void* v, void* out, 
     a.part_ml = a.part_o + (size_t)a.n_splits * q_rows * n_heads * head_dim;
     LMI_DISPATCH_T(dtype, (attn_decode_impl<f16_t>(a, n_seq, max_seqlen_q, q_rows, out, ldo, stream)),
                    (attn_decode_impl<bf16_t>(a, n_seq, max_seqlen_q, q_rows, out, ldo, stream)));
+}
+
+int lmi_attn_decode_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
+                        int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                        int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                        int dtype, void* stream) {
+    return attn_decode_entry("lmi_attn_decode_fwd", q, k, v, out, cu_seqlens_q, cu_seqlens_k, nullptr, n_seq, max_seqlen_q, max_seqlen_k, q_rows,
+                             n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, window, workspace, workspace_bytes, dtype, stream);
+}
+
+int lmi_attn_decode_pool(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* k_begin, const int* k_len,
+                         int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                         int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                         int dtype, void* stream) {
+    if (!k_len) return fail(LMI_EINVAL, "lmi_attn_decode_pool: null k_len");
+    return attn_decode_entry("lmi_attn_decode_pool", q, k, v, out, cu_seqlens_q, k_begin, k_len, n_seq, max_seqlen_q, max_seqlen_k, q_rows,
+                             n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, window, workspace, workspace_bytes, dtype, stream);
+}
+
+int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int dtype,
+                    void* stream) {
+    if (!W || !X || !out) return fail(LMI_EINVAL, "lmi_gemm_skinny: null pointer");
+    if (M < 0 || M > 16 || N <= 0 || K <= 0 || (K % 128) || epilogue < LMI_SKINNY_STORE || epilogue > LMI_SKINNY_STORE_F32 ||
+        (N % (epilogue == LMI_SKINNY_SWIGLU ? 64 : 16)))
+        return fail(LMI_EINVAL, "lmi_gemm_skinny: need M <= 16, K %% 128 == 0, N %% 16 == 0 (SwiGLU: N %% 64 == 0) (M=%d N=%d K=%d)", M, N, K);
+    if ((ldw & 7) || (ldx & 7) || ldw < K || ldx < K || !aligned16(W) || !aligned16(X) ||
+        ((epilogue == LMI_SKINNY_RESIDUAL || epilogue == LMI_SKINNY_STORE_F32) ? !aligned16(out) && ((uintptr_t)out & 3) : ((uintptr_t)out & 1)))
+        return fail(LMI_EINVAL, "lmi_gemm_skinny: rows must be 16-byte aligned (ldw, ldx multiples of 8 and >= K)");
+    if (M == 0) return LMI_OK;
+    LMI_DISPATCH_T(dtype, skinny_impl<f16_t>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream),
+                   skinny_impl<bf16_t>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream));
+}
+
+int lmi_rope_qk_rows(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all, const float* sin_all,
+                     void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream) {
+    if (!qkv || !cos_all || !sin_all || !k_cache || !v_cache || !pos_rows_dev || S < 0 || (head_dim & 15) || (ld & 7) || (ld_cache & 7) ||
+        cache_stride <= 0 || !aligned16(qkv) || !aligned16(k_cache) || !aligned16(v_cache))
+        return fail(LMI_EINVAL, "lmi_rope_qk_rows: bad argument");
+    if (S == 0) return LMI_OK;
+    const long work = (long)S * ((n_q_heads + n_kv_heads) * (head_dim / 16) + n_kv_heads * head_dim / 8);
+    const int grid = grid_for(work, 256);
+    LMI_DISPATCH_T(dtype, (rope_rows_impl<f16_t>(qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, ld_cache, (long)cache_stride, pos_rows_dev, grid, stream)),
+                   (rope_rows_impl<bf16_t>(qkv, S, ld, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, ld_cache, (long)cache_stride, pos_rows_dev, grid, stream)));
 }
 
 int lmi_rope_qk(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_table,

@@ -65,6 +65,11 @@ template <int N> LMI_DEV void wait_vmcnt_barrier() { asm volatile("s_waitcnt vmc
 LMI_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 LMI_DEV f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// D[16x16] += A[16x32] * B[32x16].  Lane l supplies A[l&15][8*(l>>4)+j] and B[8*(l>>4)+j][l&15], j=0..7; receives
+// D[4*(l>>4)+r][l&15], r=0..3.  (Skinny-M decode GEMMs: 16 weight rows x up to 16 batch rows per instruction.)
+LMI_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+LMI_DEV f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 // async 16-byte global -> LDS copy through a buffer resource: LDS destination = lds_wave_base + lane*16 (wave-uniform base);
 // source byte = base + voffset (per lane) + soffset (wave-uniform), both 32-bit; bytes at or beyond num_records read as zero
 // (raw-buffer range check), so ragged tile tails need no address clamp.
@@ -267,6 +272,24 @@ inline f32x16 emu_mfma32(V8 a, V8 b, f32x16 c) {
     hipemu::wave_sync();
     return c;
 }
+template <typename V8>
+inline f32x4 emu_mfma16(V8 a, V8 b, f32x4 c) {
+    struct Slot { float a[8], b[8]; };
+    Slot* s = (Slot*)hipemu::wave_buf();
+    const int l = lane_id();
+    for (int j = 0; j < 8; ++j) { s[l].a[j] = (float)a[j]; s[l].b[j] = (float)b[j]; }
+    hipemu::wave_sync();
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc += s[row + 16 * (k >> 3)].a[k & 7] * s[col + 16 * (k >> 3)].b[k & 7];
+        c[r] = acc;
+    }
+    hipemu::wave_sync();
+    return c;
+}
+inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return emu_mfma16(a, b, c); }
+inline f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return emu_mfma16(a, b, c); }
 inline f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return emu_mfma32(a, b, c); }
 inline f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return emu_mfma32(a, b, c); }
 

@@ -1,0 +1,154 @@
+// skinny.h — out[M, N] = epilogue( X[M, K] . W[N, K]^T ) for M <= 16: the projections of a BATCHED decode step
+// (several samples per GPU; reference loop EVAL:448-454 is batch 1).
+//
+// A decode step is bound by the weight stream (16 GB of 16-bit weights per token for Llama-3.1-8B); with B sequences in flight the
+// same stream serves B tokens.  One workgroup = 16 weight rows (32 for SwiGLU: 16 gate + their 16 up rows), 8 waves that split K in
+// 128-element steps (wave w takes steps w, w + 8, ...).  Per step a lane loads 64 contiguous bytes of "its" weight row and 64 bytes
+// of "its" batch row — lane (i, g) = (l & 15, l >> 4): row i, k-range [32 c + 8 g, + 8) of 32-k block c = 0..3 — which is exactly the
+// v_mfma_f32_16x16x32 operand layout, so the fragments go from global memory / L2 straight into the matrix pipe: no LDS staging, no
+// shuffles, 4 MFMAs per step, D[n][m] in 4 accumulator registers.  Lanes of batch rows >= M load nothing (zeros).  The 8 partial
+// tiles meet in LDS, are summed in wave order (deterministic) and the epilogue runs on 256 threads.
+// Why the batch rows are not staged in LDS: X is M x K x 2 bytes (224 KiB at K = 14336, M = 8) per workgroup either way; from L2 it
+// costs (M / 16) of the weight stream's VMEM issue slots and nothing else.
+// Requirements: K % 128 == 0, N % 16 == 0 (SwiGLU: N % 64 == 0, rows interleaved [32 gate | 32 up] as weights.py lays gate/up out),
+// 16-byte aligned rows.
+#pragma once
+#include "lmi_device.h"
+
+namespace lmi {
+
+enum { SK_STORE_T = 0, SK_RESID_F32 = 1, SK_SWIGLU_T = 2, SK_STORE_F32 = 3 };
+
+template <typename T, int EPI>
+__global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo) {
+    typedef typename vec_of<T>::x8 T8;
+    constexpr int NW = (EPI == SK_SWIGLU_T) ? 2 : 1;               // weight row blocks per workgroup (gate, up)
+    constexpr int DEPTH = (EPI == SK_SWIGLU_T) ? 2 : 3;            // k-steps of loads in flight per wave (<= 128 VGPRs: two workgroups per CU)
+    __shared__ float part[8][NW][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int unit = blockIdx.x;
+    // first weight row of block b: plain = 16 rows per unit; SwiGLU = unit u -> 64-row group u >> 1, half u & 1: gate rows at +16 * half,
+    // their up partners 32 rows further
+    const int row0 = (EPI == SK_SWIGLU_T) ? (unit >> 1) * 64 + (unit & 1) * 16 : unit * 16;
+    const T* wrow[NW];
+#pragma unroll
+    for (int b = 0; b < NW; ++b) wrow[b] = W + (long)(row0 + 32 * b + i) * ldw + 8 * g;
+    const T* xrow = X + (long)i * ldx + 8 * g;
+    const bool has_x = i < M;
+    const int nsteps = K >> 7;
+    const int my_steps = (nsteps - wave + 7) >> 3;                 // steps wave, wave + 8, ...
+    T8 wv[DEPTH][NW][4], xv[DEPTH][4];
+    auto load = [&](int slot, int s) {
+        const int k0 = (wave + 8 * s) * 128;
+#pragma unroll
+        for (int b = 0; b < NW; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wv[slot][b][c] = *(const T8*)(wrow[b] + k0 + 32 * c);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (has_x) xv[slot][c] = *(const T8*)(xrow + k0 + 32 * c);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[slot][c][e] = (T)0.0f;
+            }
+        }
+    };
+    f32x4 acc[NW];
+#pragma unroll
+    for (int b = 0; b < NW; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < my_steps) load(d, d);
+    for (int base = 0; base < my_steps; base += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int s = base + d;
+            if (s < my_steps) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int b = 0; b < NW; ++b) acc[b] = mfma16(wv[d][b][c], xv[d][c], acc[b]);
+                if (s + DEPTH < my_steps) load(d, s + DEPTH);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NW; ++b) *(f32x4*)part[wave][b][lane] = acc[b];
+    __syncthreads();
+    // D[n][m]: lane l, register r -> n = 4 (l >> 4) + r, m = l & 15.  Thread t < 256 finishes element (l = t & 63, r = t >> 6).
+    if (tid < 256) {
+        const int l = tid & 63, r = tid >> 6;
+        const int n = 4 * (l >> 4) + r, m = l & 15;
+        float v[NW];
+#pragma unroll
+        for (int b = 0; b < NW; ++b) {
+            float s = part[0][b][l][r];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) s += part[w][b][l][r];     // fixed order: results do not depend on timing
+            v[b] = s;
+        }
+        if (m < M) {
+            if (EPI == SK_SWIGLU_T) {
+                const float gt = v[0], up = v[NW - 1];
+                ((T*)out)[(long)m * ldo + (unit >> 1) * 32 + (unit & 1) * 16 + n] = (T)(gt / (1.0f + fexp(-gt)) * up);
+            } else if (EPI == SK_STORE_T) {
+                ((T*)out)[(long)m * ldo + row0 + n] = (T)v[0];
+            } else if (EPI == SK_STORE_F32) {
+                ((float*)out)[(long)m * ldo + row0 + n] = v[0];
+            } else {
+                ((float*)out)[(long)m * ldo + row0 + n] += v[0];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE + KV append for the B rows of a batched decode step: row s is sequence s's next token at position pos[s] (device memory:
+// the step is graph-captured); its rotated K and its V go to row s * cache_stride + pos[s] of the pooled caches.
+// Same arithmetic per element as rope_kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rope_rows_kernel(T* qkv, int S, int ld, int n_q, int n_kv, int D, const float* cosT, const float* sinT,
+                                 T* k_cache, T* v_cache, int ld_cache, long cache_stride, const int* pos) {
+    typedef typename vec_of<T>::x8 T8;
+    const int half = D >> 1, cpr = half >> 3;
+    const int rot_heads = n_q + n_kv;
+    const int per_tok = rot_heads * cpr + n_kv * (D >> 3);
+    const long total = (long)S * per_tok;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(idx / per_tok);
+        int w = (int)(idx - (long)s * per_tok);
+        const int p = pos[s];
+        T* row = qkv + (long)s * ld;
+        const long crow = (long)s * cache_stride + p;
+        if (w < rot_heads * cpr) {
+            const int h = w / cpr, c = w - h * cpr;
+            T* p1 = row + h * D + c * 8;
+            T* p2 = p1 + half;
+            const T8 a = *(const T8*)p1, b = *(const T8*)p2;
+            const float* cs = cosT + (long)p * half + c * 8;
+            const float* sn = sinT + (long)p * half + c * 8;
+            T8 oa, ob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x1 = (float)a[e], x2 = (float)b[e];
+                oa[e] = (T)(x1 * cs[e] - x2 * sn[e]);
+                ob[e] = (T)(x2 * cs[e] + x1 * sn[e]);
+            }
+            *(T8*)p1 = oa;
+            *(T8*)p2 = ob;
+            if (h >= n_q) {
+                T* kc = k_cache + crow * ld_cache + (h - n_q) * D + c * 8;
+                *(T8*)kc = oa;
+                *(T8*)(kc + half) = ob;
+            }
+        } else {
+            w -= rot_heads * cpr;
+            const int h = w / (D >> 3), c = w - h * (D >> 3);
+            *(T8*)(v_cache + crow * ld_cache + h * D + c * 8) = *(const T8*)(row + (n_q + n_kv + h) * D + c * 8);
+        }
+    }
+}
+
+}  // namespace lmi

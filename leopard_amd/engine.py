@@ -829,14 +829,139 @@ class LeopardEngine:
                                 set(int(e) for e in eos_token_id))
         return torch.tensor([out], dtype=torch.long, device=input_ids.device)
 
+    # ------------------------------------------------------------------------------------------------
+    # f4: batched decode.  B sequences advance together: ONE pass over the weights per step serves B tokens (lmi_gemm_skinny),
+    # their KV caches are slots of one pooled buffer per layer (slot b = rows [b * capacity, (b + 1) * capacity)), positions and
+    # key counts live in device memory, and the whole step is ONE captured HIP graph per (B, capacity).
+    # ------------------------------------------------------------------------------------------------
+    MAX_DECODE_BATCH = 16              # rows of one lmi_gemm_skinny launch (one 16x16x32 MFMA column block)
+
+    def _batch_decode_supported(self) -> bool:
+        """lmi_gemm_skinny needs K % 128 == 0 and N % 16 == 0 (gate/up: % 64); the pooled decode attention head_dim 128."""
+        W, tc = self.W, self.cfg.text_config
+        (H, KV), hd, D = self._llm_heads(), tc.head_dim, tc.hidden_size
+        return (hd == 128 and D % 128 == 0 and W.llm_ff % 128 == 0 and (2 * W.llm_ff) % 64 == 0 and ((H + 2 * KV) * hd) % 16 == 0 and
+                W.lm_head.shape[0] % 16 == 0 and D % 16 == 0)
+
+    def _batch_state(self, B: int, need: int):
+        """Static buffers + pooled KV cache + captured graph of a B-sequence decode step (kept per engine and reused: the graph reads
+        positions / key counts from device memory and its launch geometry depends on (B, capacity) only)."""
+        states = getattr(self, "_batch_states", None)
+        if states is None:
+            states = self._batch_states = {}
+        st = states.get(B)
+        if st is not None and st.capacity >= need:
+            return st
+        W, tc, dev = self.W, self.cfg.text_config, self.device
+        (H, KV), hd, D = self._llm_heads(), tc.head_dim, tc.hidden_size
+        cap = (need + 1023) // 1024 * 1024
+
+        class St:
+            pass
+        st = St()
+        st.B, st.capacity = B, cap
+        n_layers = len(W.llm_layers)
+        st.k = [torch.zeros(B * cap, KV * hd, dtype=self.dtype, device=dev) for _ in range(n_layers)]
+        st.v = [torch.zeros(B * cap, KV * hd, dtype=self.dtype, device=dev) for _ in range(n_layers)]
+        st.tok = torch.zeros(B, dtype=torch.int64, device=dev)
+        st.src = torch.arange(B, dtype=torch.int64, device=dev)
+        st.pos = torch.zeros(B, dtype=torch.int32, device=dev)
+        st.k_len = torch.ones(B, dtype=torch.int32, device=dev)
+        st.k_begin = (torch.arange(B, dtype=torch.int32) * cap).to(dev)
+        st.cu_q = torch.arange(B + 1, dtype=torch.int32, device=dev)
+        st.x = self._empty(B, D, dtype=torch.float32)
+        st.h, st.qkv, st.att = self._empty(B, D), self._empty(B, (H + 2 * KV) * hd), self._empty(B, H * hd)
+        st.gu = self._empty(B, W.llm_ff)
+        st.logits = self._empty(B, W.lm_head.shape[0], dtype=torch.float32)
+        st.cos, st.sin = self.rope_tables(torch.arange(cap))
+        st.ws = torch.empty(self.ops.decode_workspace_elems(B, H, hd, cap), dtype=torch.float32, device=dev)
+        st.graph = None
+        states[B] = st
+        return st
+
+    def _batch_decode_body(self, st):
+        """One decode step for the B sequences of ``st`` (everything here is host-value free: graph-capturable)."""
+        ops, W, tc = self.ops, self.W, self.cfg.text_config
+        (H, KV), hd = self._llm_heads(), tc.head_dim
+        qw, eps = H * hd, tc.rms_norm_eps
+        ops.embed_merge(st.tok, st.src, W.embed, None, st.x)
+        for i, L in enumerate(W.llm_layers):
+            ops.rmsnorm(st.x, L.in_norm, st.h, eps)
+            ops.gemm_skinny(L.qkv_w, st.h, st.qkv, 0)
+            ops.rope_qk_rows(st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos)
+            ops.attention_decode_pool(st.qkv[:, :qw], st.k[i], st.v[i], st.att, st.cu_q, st.k_begin, st.k_len, st.capacity, H, KV, hd,
+                                      hd ** -0.5, st.ws, window=tc.sliding_window or 0)
+            ops.gemm_skinny(L.o_w, st.att, st.x, 1)
+            ops.rmsnorm(st.x, L.post_norm, st.h, eps)
+            ops.gemm_skinny(L.gu_w, st.h, st.gu, 2)
+            ops.gemm_skinny(L.down_w, st.gu, st.x, 1)
+        # head: one pass over lm_head for all B rows (lmi_lm_head_last streams the 1 GB head once PER row)
+        ops.rmsnorm(st.x, W.final_norm, st.h, eps)
+        ops.gemm_skinny(W.lm_head, st.h, st.logits, 3)
+        if self.suppress_tokens is not None:
+            st.logits.index_fill_(1, self.suppress_tokens, float("-inf"))
+        torch.argmax(st.logits[:, :tc.vocab_size], dim=1, out=st.tok)
+        st.pos.add_(1)
+        st.k_len.add_(1)
+
+    def _batch_decode_run(self, st):
+        if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs:
+            self._batch_decode_body(st)
+            return
+        if st.graph is None:
+            keep = (st.tok.clone(), st.pos.clone(), st.k_len.clone())
+            side = torch.cuda.Stream(device=self.device)               # warm-up outside capture (function attributes, allocator)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self._batch_decode_body(st)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.k_len.copy_(keep[2])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._batch_decode_body(st)
+            st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.k_len.copy_(keep[2])      # capture does not execute
+            st.graph = g
+        st.graph.replay()
+
+    def _greedy_loop_batch(self, st, prompts: List[List[int]], first: List[int], seq_lens: List[int], max_new_tokens: int, eos) -> List[List[int]]:
+        """EVAL:448-452 for B sequences at once: every sequence follows exactly the batch-1 rule (emit, stop at eos / max_new_tokens);
+        finished sequences keep riding along in the batch (their slots are private) and are ignored."""
+        B = st.B
+        outs = [list(p) for p in prompts]
+        nxt = [int(f) for f in first]
+        done = [False] * B
+        st.tok.copy_(torch.tensor(nxt, dtype=torch.int64))
+        st.pos.copy_(torch.tensor(seq_lens, dtype=torch.int32))
+        st.k_len.copy_(torch.tensor([s + 1 for s in seq_lens], dtype=torch.int32))
+        for step in range(max_new_tokens):
+            for j in range(B):
+                if not done[j]:
+                    outs[j].append(nxt[j])
+                    if nxt[j] in eos or step == max_new_tokens - 1:
+                        done[j] = True
+            if all(done):
+                break
+            self._batch_decode_run(st)
+            nxt = [int(t) for t in st.tok.tolist()]
+        return outs
+
     @torch.no_grad()
     def generate_batch(self, samples: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], max_new_tokens: int = 128,
                        eos_token_id: Sequence[int] = (128001, 128009)) -> List[torch.Tensor]:
         """Several samples per call (batching with per-sample cu_seqlens instead of one sample per generate()):
         ONE packed prefill — all ViT inputs through the tower together, all merged sequences in one varlen causal pass that also
-        writes every sample's K/V into a pooled cache — then each sample's K/V rows move to a cache of its own (a device copy)
-        and its greedy continuation runs on the captured decode step.  Results are identical to per-sample ``generate``."""
+        writes every sample's K/V into a packed cache — then each sample's K/V rows move to its slot of the pooled decode cache (a
+        device copy) and ALL samples continue greedily together, one captured decode step per token for the whole batch
+        (``_batch_decode_body``: the weight stream of a step is shared by the batch).  Same tokens as per-sample ``generate``."""
         assert self.tp_size == 1, "batched generation is a single-rank feature (replicas scale it out)"
+        if len(samples) > self.MAX_DECODE_BATCH:
+            outs = []
+            for i in range(0, len(samples), self.MAX_DECODE_BATCH):
+                outs += self.generate_batch(samples[i:i + self.MAX_DECODE_BATCH], max_new_tokens, eos_token_id)
+            return outs
+        if len(samples) == 1:
+            ids, t = samples[0]
+            return [self.generate(ids, t, max_new_tokens, eos_token_id)]
         tiles = [t for _, t in samples if t is not None and t.shape[0] > 0]
         visual = None
         if tiles:
@@ -850,17 +975,30 @@ class LeopardEngine:
             x = self.embed_merge(ids, vt)
             xs.append(x)
             seq_lens.append(x.shape[0])
-        pool = KVCache(self.cfg, sum(seq_lens), self.dtype, self.device)
-        last, _ = self.llm_prefill(torch.cat(xs, dim=0), seq_lens, cache=pool)
+        packed = KVCache(self.cfg, sum(seq_lens), self.dtype, self.device)
+        last, _ = self.llm_prefill(torch.cat(xs, dim=0), seq_lens, cache=packed)
         first = [self.first_token(last[j]) for j in range(last.shape[0])]
         eos = set(int(e) for e in eos_token_id)
-        outs, off = [], 0
-        for (ids, _), S, nxt in zip(samples, seq_lens, first):
-            cache = KVCache(self.cfg, S + max_new_tokens, self.dtype, self.device)
-            for i in range(len(cache.k)):
-                self.ops.kv_append(pool.k[i][off:off + S], pool.v[i][off:off + S], cache.k[i], cache.v[i], 0)
-            cache.length = S
+        if not self._batch_decode_supported():
+            # shapes the skinny-M kernels do not cover (toy configurations): the samples continue one after another on the engine's ONE
+            # generation cache and its captured batch-1 step
+            outs, off = [], 0
+            for (ids, _), S, nxt in zip(samples, seq_lens, first):
+                cache = self._generation_cache(S + max_new_tokens)
+                for i in range(len(cache.k)):
+                    self.ops.kv_append(packed.k[i][off:off + S], packed.v[i][off:off + S], cache.k[i], cache.v[i], 0)
+                cache.length = S
+                off += S
+                out = self._greedy_loop([int(t) for t in ids.reshape(-1).tolist()], nxt, cache, max_new_tokens, eos)
+                outs.append(torch.tensor([out], dtype=torch.long, device=ids.device))
+            return outs
+        st = self._batch_state(len(samples), max(seq_lens) + max_new_tokens)
+        off = 0
+        for j, S in enumerate(seq_lens):
+            for i in range(len(packed.k)):
+                self.ops.kv_append(packed.k[i][off:off + S], packed.v[i][off:off + S], st.k[i], st.v[i], j * st.capacity)
             off += S
-            out = self._greedy_loop([int(t) for t in ids.reshape(-1).tolist()], nxt, cache, max_new_tokens, eos)
-            outs.append(torch.tensor([out], dtype=torch.long, device=ids.device))
-        return outs
+        del packed
+        prompts = [[int(t) for t in ids.reshape(-1).tolist()] for ids, _ in samples]
+        outs = self._greedy_loop_batch(st, prompts, first, seq_lens, max_new_tokens, eos)
+        return [torch.tensor([o], dtype=torch.long, device=ids.device) for o, (ids, _) in zip(outs, samples)]

@@ -150,6 +150,33 @@ class Ops:
                                                  workspace.numel() * workspace.element_size(), _DT[q.dtype], self._stream(out)))
         return out
 
+    def attention_decode_pool(self, q, k, v, out, cu_q, k_begin, k_len, max_seqlen_k, n_heads, n_kv_heads, head_dim, scale,
+                              workspace: torch.Tensor, window=0):
+        """Split-KV decode attention for a batch whose caches share one pooled buffer: sequence s owns rows
+        [k_begin[s], k_begin[s] + k_len[s]) of k / v (int32 device tensors; k_len advances on the device)."""
+        n_seq = cu_q.numel() - 1
+        self._check(self.lib.lmi_attn_decode_pool(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(cu_q), _ptr(k_begin), _ptr(k_len), n_seq, 1,
+                                                  int(max_seqlen_k), q.shape[0], n_heads, n_kv_heads, head_dim, q.stride(0), k.stride(0),
+                                                  v.stride(0), out.stride(0), float(scale), int(window), _ptr(workspace),
+                                                  workspace.numel() * workspace.element_size(), _DT[q.dtype], self._stream(out)))
+        return out
+
+    def rope_qk_rows(self, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, cache_stride, pos_rows):
+        """Batched decode: row s rotated at position pos_rows[s] (int32, device); K / V appended at row s * cache_stride + pos_rows[s]."""
+        self._check(self.lib.lmi_rope_qk_rows(_ptr(qkv), qkv.shape[0], qkv.stride(0), n_q_heads, n_kv_heads, head_dim, _ptr(cos_all),
+                                              _ptr(sin_all), _ptr(k_cache), _ptr(v_cache), k_cache.stride(0), int(cache_stride),
+                                              _ptr(pos_rows), _DT[qkv.dtype], self._stream(qkv)))
+        return qkv
+
+    def gemm_skinny(self, w, x, out, epilogue=0):
+        """out[M <= 16, .] = epilogue(x @ w.T): the projections of a batched decode step.  epilogue: 0 store T, 1 fp32 +=,
+        2 SwiGLU (w rows interleaved [32 gate | 32 up], out [M, N/2]), 3 store fp32."""
+        N, K = w.shape
+        M = x.shape[0]
+        self._check(self.lib.lmi_gemm_skinny(_ptr(w), _ptr(x), _ptr(out), M, N, K, w.stride(0), x.stride(0), out.stride(0), int(epilogue),
+                                             _DT[w.dtype], self._stream(out)))
+        return out
+
     def decode_workspace_elems(self, q_rows, n_heads, head_dim, max_seqlen_k) -> int:
         n = int(self.lib.lmi_attn_decode_workspace_bytes(q_rows, n_heads, head_dim, max_seqlen_k))
         if n < 0:

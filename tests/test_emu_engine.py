@@ -103,3 +103,31 @@ def test_prefill_batch_equals_per_sample_prefill(setup):
     for i, (ids, tiles) in enumerate(samples):
         one = eng.prefill(ids, tiles)
         assert torch.equal(one.logits_last, logits[i])
+
+
+def test_generate_batch_decodes_the_batch_together_and_equals_per_sample_generate(setup):
+    """f4 batched decode: one packed prefill, then ALL samples advance together through the pooled KV cache and the skinny-M
+    projections (lmi_gemm_skinny / lmi_rope_qk_rows / lmi_attn_decode_pool) — same tokens as per-sample generate(), with samples of
+    different lengths, one of them stopping early at its eos."""
+    ops, cfg, _ = setup
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    assert eng._batch_decode_supported()
+    rng = np.random.default_rng(6)
+    samples = [(torch.tensor([[5, 250, 9, 250, 17]]), torch.from_numpy(rng.integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))),
+               (torch.tensor([[7, 8, 9]]), None),
+               (torch.tensor([[250, 3]]), torch.from_numpy(rng.integers(0, 256, (1, 28, 28, 3), dtype=np.uint8)))]
+    singles = [eng.generate(ids, tiles, max_new_tokens=5, eos_token_id=()) for ids, tiles in samples]
+    eos = (int(singles[1][0, samples[1][0].shape[1] + 1]),)          # sample 1's SECOND new token: it stops there, the others go on
+    singles = [eng.generate(ids, tiles, max_new_tokens=5, eos_token_id=eos) for ids, tiles in samples]
+    calls = []
+    body = eng._batch_decode_body
+    eng._batch_decode_body = lambda st: (calls.append(st.B), body(st))[1]
+    batch = eng.generate_batch(samples, max_new_tokens=5, eos_token_id=eos)
+    assert calls and set(calls) == {3} and len(calls) <= 4          # one step per token for the WHOLE batch, not per sample
+    for one, got in zip(singles, batch):
+        assert torch.equal(one, got)
+    assert singles[1].shape[1] < samples[1][0].shape[1] + 5         # the early stop really happened
+    st = eng._batch_states[3]
+    again = eng.generate_batch(samples, max_new_tokens=5, eos_token_id=eos)      # state (pool, buffers) reused, same result
+    assert eng._batch_states[3] is st and all(torch.equal(a, b) for a, b in zip(batch, again))

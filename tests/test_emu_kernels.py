@@ -574,3 +574,69 @@ def test_lm_head_last_keeps_the_normalised_row_in_fp32(ops, dtype, K, N, n_rows)
     ops.lm_head_last(w, x, None, None, 0.0, out2)                     # rows 0..n-1, no normalisation
     ref2 = x[:n_rows].double() @ w.double().T
     assert (out2.double() - ref2).abs().max() <= 2e-5 * ref2.abs().max()
+
+
+@pytest.mark.parametrize("dtype_pair", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1, 32, 128), (5, 48, 512), (8, 64, 1792), (16, 16, 1152 + 128)])
+def test_gemm_skinny_all_epilogues(ops, dtype_pair, M, N, K):
+    """lmi_gemm_skinny (M <= 16 rows against streamed weights: batched decode): every epilogue vs fp32, K steps that do not divide
+    evenly over the 8 waves, rows >= M never touched."""
+    dtype = dtype_pair
+    x, w = rnd((M, K), dtype, 3), rnd((N, K), dtype, 4, 0.1)
+    ref = x.float() @ w.float().T
+    t = tol(dtype) * max(1.0, ref.abs().max().item())
+    out = torch.full((M + 1, N), 7.0, dtype=dtype)
+    ops.gemm_skinny(w, x, out[:M], 0)
+    assert (out[:M].float() - ref).abs().max() <= t and bool((out[M] == 7.0).all())
+    o32 = torch.zeros(M, N)
+    ops.gemm_skinny(w, x, o32, 3)
+    assert (o32 - ref).abs().max() <= 1e-3 * max(1.0, ref.abs().max().item())
+    acc = rnd((M, N), torch.float32, 5)
+    acc0 = acc.clone()
+    ops.gemm_skinny(w, x, acc, 1)
+    assert (acc - (acc0 + ref)).abs().max() <= 1e-3 * max(1.0, ref.abs().max().item())
+    if N % 64 == 0:
+        F = N // 2
+        lv = ref.view(M, N // 64, 2, 32)
+        want = (torch.nn.functional.silu(lv[:, :, 0]) * lv[:, :, 1]).reshape(M, F)
+        o = torch.zeros(M, F, dtype=dtype)
+        ops.gemm_skinny(w, x, o, 2)
+        assert (o.float() - want).abs().max() <= tol(dtype) * max(1.0, want.abs().max().item())
+
+
+def test_rope_rows_equals_rope_at_per_row(ops):
+    """lmi_rope_qk_rows (row s at its own device position, K / V into slot s of a pooled cache) == lmi_rope_qk_at row by row."""
+    dtype, H, KV, hd, cap, B = torch.float16, 2, 1, 128, 12, 3
+    qkv = rnd((B, (H + 2 * KV) * hd), dtype, 1)
+    f = torch.arange(cap).float().reshape(-1, 1) * (1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    pos = torch.tensor([4, 0, 11], dtype=torch.int32)
+    kp, vp = torch.zeros(B * cap, KV * hd, dtype=dtype), torch.zeros(B * cap, KV * hd, dtype=dtype)
+    got = qkv.clone()
+    ops.rope_qk_rows(got, H, KV, hd, cos, sin, kp, vp, cap, pos)
+    for s in range(B):
+        one = qkv[s:s + 1].clone()
+        kc, vc = torch.zeros(cap, KV * hd, dtype=dtype), torch.zeros(cap, KV * hd, dtype=dtype)
+        ops.rope_qk_at(one, H, KV, hd, cos, sin, kc, vc, pos[s:s + 1].clone())
+        assert torch.equal(one[0], got[s])
+        assert torch.equal(kp[s * cap:(s + 1) * cap], kc) and torch.equal(vp[s * cap:(s + 1) * cap], vc)
+
+
+def test_attention_decode_pool_equals_per_sequence_decode(ops):
+    """lmi_attn_decode_pool (B sequences in slots of one pooled cache, lengths in a device array) == lmi_attn_decode_fwd per sequence."""
+    dtype, H, KV, hd, cap = torch.float16, 4, 2, 128, 200
+    lens = [130, 1, 77]
+    B = len(lens)
+    q = rnd((B, H * hd), dtype, 2)
+    kp, vp = rnd((B * cap, KV * hd), dtype, 3), rnd((B * cap, KV * hd), dtype, 4)
+    ws = torch.zeros(ops.decode_workspace_elems(B, H, hd, cap))
+    out = torch.zeros(B, H * hd, dtype=dtype)
+    cu_q = torch.arange(B + 1, dtype=torch.int32)
+    k_begin = (torch.arange(B, dtype=torch.int32) * cap)
+    ops.attention_decode_pool(q, kp, vp, out, cu_q, k_begin, torch.tensor(lens, dtype=torch.int32), cap, H, KV, hd, hd ** -0.5, ws)
+    for s, L in enumerate(lens):
+        one = torch.zeros(1, H * hd, dtype=dtype)
+        ws1 = torch.zeros(ops.decode_workspace_elems(1, H, hd, cap))
+        ops.attention_decode(q[s:s + 1], kp[s * cap:(s + 1) * cap], vp[s * cap:(s + 1) * cap], one, torch.tensor([0, 1], dtype=torch.int32),
+                             torch.tensor([0, L], dtype=torch.int32), 1, cap, H, KV, hd, hd ** -0.5, ws1)
+        assert torch.equal(one[0], out[s]), s

@@ -344,3 +344,62 @@ def test_gemv_rmsnorm_equals_rmsnorm_then_gemv(ops):
     assert torch.equal(a, b)
     ref = w.float() @ h[0].float()
     check(a, ref, dtype, k=2, what="gemv_rmsnorm")
+
+
+# ---- batched decode: skinny-M projections, per-row RoPE into a pooled cache, pooled split-KV attention ----------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+def test_gemm_skinny_llama_decode_shapes(ops, dtype, M):
+    """lmi_gemm_skinny at the four projection shapes of a Llama-3.1-8B decode step, every epilogue, vs fp32 on the device; three
+    launches each must agree bit for bit (the partial tiles are summed in a fixed order: no atomics)."""
+    for name, N, K, epi in (("qkv", 6144, 4096, 0), ("o", 4096, 4096, 1), ("gate_up", 28672, 4096, 2), ("down", 4096, 14336, 1), ("head", 8192, 4096, 3)):
+        x, w = rnd((M, K), dtype, 11, 1.0), rnd((N, K), dtype, 12, 0.02)
+        lin = x.float() @ w.float().T
+        if epi == 2:
+            lv = lin.view(M, N // 64, 2, 32)
+            ref = (torch.nn.functional.silu(lv[:, :, 0]) * lv[:, :, 1]).reshape(M, N // 2)
+            outs = [torch.zeros(M, N // 2, dtype=dtype, device=DEV) for _ in range(3)]
+        elif epi == 1:
+            base = rnd((M, N), torch.float32, 13)
+            ref = base + lin
+            outs = [base.clone() for _ in range(3)]
+        else:
+            ref = lin
+            outs = [torch.zeros(M, N, dtype=dtype if epi == 0 else torch.float32, device=DEV) for _ in range(3)]
+        for o in outs:
+            ops.gemm_skinny(w, x, o, epi)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), name
+        check(outs[0], ref, dtype if epi in (0, 2) else torch.float16, k=4.0, what=f"skinny {name} M={M}")
+
+
+def test_rope_rows_and_decode_pool_vs_per_sequence(ops):
+    """lmi_rope_qk_rows / lmi_attn_decode_pool (B sequences in slots of one pooled cache) == lmi_rope_qk_at / lmi_attn_decode_fwd
+    sequence by sequence, bit for bit, at the Llama head geometry and a C3-sized slot."""
+    dtype, H, KV, hd, cap = torch.float16, 32, 8, 128, 7424
+    lens = [7187, 1, 300, 7423, 64]
+    B = len(lens)
+    qkv = rnd((B, (H + 2 * KV) * hd), dtype, 21)
+    f = torch.arange(cap, device=DEV).float().reshape(-1, 1) * (1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=DEV).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    kp, vp = rnd((B * cap, KV * hd), dtype, 22), rnd((B * cap, KV * hd), dtype, 23)
+    kp1, vp1 = kp.clone(), vp.clone()
+    pos = torch.tensor([l - 1 for l in lens], dtype=torch.int32, device=DEV)
+    got = qkv.clone()
+    ops.rope_qk_rows(got, H, KV, hd, cos, sin, kp, vp, cap, pos)
+    out = torch.zeros(B, H * hd, dtype=dtype, device=DEV)
+    ws = torch.zeros(ops.decode_workspace_elems(B, H, hd, cap), device=DEV)
+    cu_q = torch.arange(B + 1, dtype=torch.int32, device=DEV)
+    k_begin = (torch.arange(B, dtype=torch.int32) * cap).to(DEV)
+    ops.attention_decode_pool(got[:, :H * hd], kp, vp, out, cu_q, k_begin, torch.tensor(lens, dtype=torch.int32, device=DEV), cap, H, KV, hd,
+                              hd ** -0.5, ws)
+    for s, L in enumerate(lens):
+        one = qkv[s:s + 1].clone()
+        kc, vc = kp1[s * cap:(s + 1) * cap], vp1[s * cap:(s + 1) * cap]
+        ops.rope_qk_at(one, H, KV, hd, cos, sin, kc, vc, pos[s:s + 1].clone())
+        assert torch.equal(one[0], got[s]) and torch.equal(kc, kp[s * cap:(s + 1) * cap]) and torch.equal(vc, vp[s * cap:(s + 1) * cap])
+        o1 = torch.zeros(1, H * hd, dtype=dtype, device=DEV)
+        ws1 = torch.zeros(ops.decode_workspace_elems(1, H, hd, cap), device=DEV)
+        ops.attention_decode(one[:, :H * hd], kc, vc, o1, torch.tensor([0, 1], dtype=torch.int32, device=DEV),
+                             torch.tensor([0, L], dtype=torch.int32, device=DEV), 1, cap, H, KV, hd, hd ** -0.5, ws1)
+        assert torch.equal(o1[0], out[s]), s

@@ -352,6 +352,48 @@ def test_prefill_batch_equals_per_sample_prefill(ops):
 
 
 @pytest.mark.gpu
+def test_generate_batch_decodes_together_and_equals_per_sample_generate(ops):
+    """f4: generate_batch = one packed prefill + ONE captured decode step per token for the whole batch (pooled KV cache, skinny-M
+    projections).  Per sample: the first new token is bit-identical by construction (same prefill); the continuation is compared with
+    the batch-1 generate() — the projections sum in a different order (MFMA tiles vs FMA chains), so a token may only differ where the
+    batch-1 logits' top-2 gap is below the 16-bit noise; the test asserts equality and, where it fails, that it was such a near tie."""
+    from leopard_amd.engine import KVCache
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    shapes = [(1, 800, 500, 3), (2, 1344, 896, 5), (1, 336, 336, 7), (1, 364, 364, 9)]
+    samples = []
+    for n, w, h, seed in shapes:
+        u8, ids, _ = sample_inputs(cfg, n, w, h, seed=seed)
+        samples.append((ids, torch.from_numpy(u8).to(DEV)))
+    T = 6
+    singles = [eng.generate(ids, tiles, max_new_tokens=T, eos_token_id=()) for ids, tiles in samples]
+    steps = []
+    body = eng._batch_decode_body
+    eng._batch_decode_body = lambda st: (steps.append(st.B), body(st))[1]
+    batch = eng.generate_batch(samples, max_new_tokens=T, eos_token_id=())
+    eng._batch_decode_body = body
+    assert set(steps) == {4} and len(steps) == 2                       # warm-up + capture: afterwards the graph replays (no Python body)
+    st = eng._batch_states[4]
+    assert st.graph is not None
+    for (ids, tiles), one, got in zip(samples, singles, batch):
+        S_in = ids.shape[1]
+        assert got.shape == one.shape and int(got[0, S_in]) == int(one[0, S_in])
+        if not torch.equal(one, got):
+            j = int((one[0] != got[0]).nonzero()[0])
+            cache = KVCache(cfg, one.shape[1] + 256 * 8, torch.float16, DEV)
+            res = eng.prefill(ids, tiles, cache=cache)
+            lg = None
+            nxt = int(one[0, S_in])
+            for t in range(S_in + 1, j + 1):
+                lg = eng.decode_step(nxt, cache).clone()
+                nxt = int(one[0, t])
+            top2 = lg.topk(2).values
+            assert float(top2[0] - top2[1]) <= 2e-3 * float(lg.abs().max()), (j, top2)
+    again = eng.generate_batch(samples, max_new_tokens=T, eos_token_id=())
+    assert all(torch.equal(a, b) for a, b in zip(batch, again)) and eng._batch_states[4] is st
+
+
+@pytest.mark.gpu
 def test_c5_size_batch_properties(ops):
     """BASELINE config C5 size (8 samples x 8 images of 1344x896 -> 320 ViT inputs, 8 x 6861 tokens in one packed pass) at the
     mid depth: every sample of the packed batch reproduces its own single-sample prefill bit for bit, and equal samples give
