@@ -45,6 +45,7 @@ struct AttnArgs {
     int n_splits, split_tiles, part_rows;
     float* part_o;            // [n_splits, part_rows, n_heads, D]
     float* part_ml;           // [n_splits, part_rows, n_heads, 2]  (m, l)
+    int gqa_pack;             // LDS-DMA kernel, decode: a workgroup's 4 waves take the 4 query heads of ONE kv head (32 query rows per block)
     int check_k_extent;       // 1 = the launcher could not bound a sequence's K / V extent (< 4 GiB): the kernel checks (and traps)
 };
 
@@ -316,21 +317,29 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     // ---- 1-D grid -> (sequence, query block, head).  Heads vary fastest so that (a) the heavy late causal blocks of ALL
     // heads are dispatched first and the light ones fill the tail, and (b) workgroup b runs on XCD b % 8 and takes kv head
     // b % n_kv_heads: with 8 kv heads each XCD's L2 serves one kv head's K/V stream to every query head that shares it.
+    // GQA-packed decode (p.gqa_pack; decode launchers set it when n_heads == NW * n_kv_heads and there are <= 32 query rows per
+    // sequence): the workgroup belongs to one KV head and its NW waves take that head's NW query heads — every wave has real rows
+    // (a plain decode block has one real row in wave 0 and three idle waves) and the K / V tiles are DMA'd once for the group
+    // instead of once per query head.
     const int bid = (int)blockIdx.x;
-    const int h_idx = bid % p.n_heads;
-    int rest = bid / p.n_heads, split = 0;
+    const bool pack = p.gqa_pack != 0;
+    const int grid_heads = pack ? p.n_kv_heads : p.n_heads;
+    const int h_idx = bid % grid_heads;
+    int rest = bid / grid_heads, split = 0;
     if (p.n_splits > 1) { split = rest % p.n_splits; rest /= p.n_splits; }
     const int qb = p.n_qblocks - 1 - rest % p.n_qblocks, seq = rest / p.n_qblocks;
-    const int kvh = h_idx % p.n_kv_heads, head = kvh * (p.n_heads / p.n_kv_heads) + h_idx / p.n_kv_heads;
+    const int kvh = h_idx % p.n_kv_heads;
+    const int head = pack ? kvh * NW + wave : kvh * (p.n_heads / p.n_kv_heads) + h_idx / p.n_kv_heads;
     const int q_beg = p.cu_q[seq], len_q = p.cu_q[seq + 1] - q_beg;
     const int k_beg = p.cu_k[seq], len_k = p.k_len ? p.k_len[seq] : p.cu_k[seq + 1] - k_beg;
-    const int q0 = qb * BQ;
+    const int bq = pack ? 32 : BQ;                                 // query rows per workgroup
+    const int q0 = qb * bq;
     if (q0 >= len_q) return;
     const int shift = len_k - len_q;
     int kv_end = len_k;
-    if (CAUSAL) kv_end = imin(len_k, q0 + BQ + shift);
+    if (CAUSAL) kv_end = imin(len_k, q0 + bq + shift);
     const int n_tiles = (kv_end + ATT_BKV - 1) / ATT_BKV;
-    const int wave_q_lo = q0 + wave * 32, wave_q_hi = wave_q_lo + 31;
+    const int wave_q_lo = pack ? q0 : q0 + wave * 32, wave_q_hi = wave_q_lo + 31;
     // tiles this wave computes: the later ones are fully masked for its 32 rows (it still issues its DMA pieces and
     // joins the barriers for the other waves in the drain loop below)
     int my_tiles = n_tiles;
@@ -341,7 +350,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
     my_tiles = imin(my_tiles, t_end);
     if (wave_q_lo >= len_q) my_tiles = t_begin;                    // all 32 rows of this wave are past the sequence: feed and sync only
 
-    const int my_q = q0 + wave * 32 + fr;
+    const int my_q = wave_q_lo + fr;
     const T* q_row = (const T*)p.q + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldq + head * D;
     T8 qf[NKS];
 #pragma unroll

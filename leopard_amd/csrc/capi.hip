@@ -241,6 +241,7 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     return check_launch("lmi_attn_varlen_fwd");
 }
 std::atomic<int> g_attn_lds_pad{0};                      // experiment knob: extra dynamic LDS per workgroup (lowers residency)
+std::atomic<int> g_attn_gqa_pack{1};         // decode: 1 = a workgroup's waves take the query heads of one kv head (A/B knob attn.gqa_pack)
 std::atomic<int> g_attn_dma{1};                          // 1 = LDS-DMA kernel (production), 0 = register-staged kernel (cross-checks)
 
 template <typename T, int D, bool CAUSAL>
@@ -395,8 +396,10 @@ template <typename T>
 int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, int ldo, void* stream) {
     static std::atomic<uint64_t> attr_done{0};
     allow_big_lds(attn_fwd_dma_kernel<T, 128, true>, 160 * 1024, attr_done);
-    a.n_qblocks = (max_q + ATT_BQ - 1) / ATT_BQ;
-    LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true>), dim3(a.n_qblocks * a.n_heads * n_seq * a.n_splits), dim3(ATT_THREADS),
+    // GQA-packed blocks when a kv head serves exactly 4 query heads (Llama-3.1-8B, Mistral-7B) and a sequence has at most 32 query rows
+    a.gqa_pack = (g_attn_gqa_pack.load() && a.n_heads == 4 * a.n_kv_heads && max_q <= 32) ? 1 : 0;
+    a.n_qblocks = a.gqa_pack ? (max_q + 31) / 32 : (max_q + ATT_BQ - 1) / ATT_BQ;
+    LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true>), dim3(a.n_qblocks * (a.gqa_pack ? a.n_kv_heads : a.n_heads) * n_seq * a.n_splits), dim3(ATT_THREADS),
                AttnDmaGeom<128>::SMEM, stream, a);
     const long items = (long)q_rows * a.n_heads;
     LMI_LAUNCH((attn_combine_kernel<T, 128>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, (const float*)a.part_o,
@@ -467,6 +470,7 @@ int lmi_set_option(const char* key, int value) {
             }
     }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "attn.gqa_pack")) { g_attn_gqa_pack = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.lds_pad")) { g_attn_lds_pad = value < 0 ? 0 : (value > 90 * 1024 ? 90 * 1024 : value); return LMI_OK; }
     return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);
 }
@@ -739,7 +743,7 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = nullptr;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
-    a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr;
+    a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr; a.gqa_pack = 0;
     a.check_k_extent = 1;
     if (cu_seqlens_k == cu_seqlens_q) {                              // self-attention: the longest key sequence is max_seqlen_q
         if (((long)max_seqlen_q * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_q * ldv + head_dim) * 2 >= (1L << 32))

@@ -640,3 +640,31 @@ def test_attention_decode_pool_equals_per_sequence_decode(ops):
         ops.attention_decode(q[s:s + 1], kp[s * cap:(s + 1) * cap], vp[s * cap:(s + 1) * cap], one, torch.tensor([0, 1], dtype=torch.int32),
                              torch.tensor([0, L], dtype=torch.int32), 1, cap, H, KV, hd, hd ** -0.5, ws1)
         assert torch.equal(one[0], out[s]), s
+
+
+def test_attention_decode_gqa_pack_is_bit_identical_to_head_per_block(ops):
+    """Decode blocks packed by kv head (4 waves = the 4 query heads that share it; attn.gqa_pack, the default when n_heads == 4 n_kv_heads)
+    give the same bits as one block per query head: the same per-row arithmetic, only the wave that runs it changes."""
+    dtype, H, KV, hd, cap = torch.float16, 8, 2, 128, 260
+    lens, B = [259, 70], 2
+    q = rnd((B, H * hd), dtype, 5)
+    kp, vp = rnd((B * cap, KV * hd), dtype, 6), rnd((B * cap, KV * hd), dtype, 7)
+    cu_q = torch.arange(B + 1, dtype=torch.int32)
+    k_begin = (torch.arange(B, dtype=torch.int32) * cap)
+    outs = []
+    try:
+        for pack in (1, 0):
+            ops.set_option("attn.gqa_pack", pack)
+            ws = torch.zeros(ops.decode_workspace_elems(B, H, hd, cap))
+            out = torch.zeros(B, H * hd, dtype=dtype)
+            ops.attention_decode_pool(q, kp, vp, out, cu_q, k_begin, torch.tensor(lens, dtype=torch.int32), cap, H, KV, hd, hd ** -0.5, ws)
+            outs.append(out)
+    finally:
+        ops.set_option("attn.gqa_pack", 1)
+    assert torch.equal(outs[0], outs[1])
+    for s, L in enumerate(lens):                                   # and both are right
+        qs = q[s].float().view(H, hd)
+        ks = kp[s * cap:s * cap + L].float().view(L, KV, hd).transpose(0, 1).repeat_interleave(H // KV, 0)
+        vs = vp[s * cap:s * cap + L].float().view(L, KV, hd).transpose(0, 1).repeat_interleave(H // KV, 0)
+        ref = (torch.softmax((qs[:, None, :] @ ks.transpose(-1, -2)) * hd ** -0.5, -1) @ vs).reshape(-1)
+        assert (outs[0][s].float() - ref).abs().max() <= 3e-3
