@@ -409,6 +409,7 @@ def measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler):
                            f"sequence-parallel norms ({eng.tp_chunks} row chunks, all-gather + reduce-scatter per half layer in "
                            f"{'fp32' if eng.tp_comm_dtype == torch.float32 else args.dtype}), column-parallel head",
             "backend": eng.comm.backend, "rccl_ranks": eng.comm.ranks_seen(),
+            "comm_strict": os.environ.get("LMI_COMM_STRICT") == "1",
             "comm_bytes_per_step_per_rank": int((eng.comm.sent_bytes - sent0) / args.steps),
             "prefill_mfma_frac_of_n_gpus": round(fl["total"] / 1e12 / (elapsed / args.steps) / (MFMA_PEAK_TFLOPS * world), 4)}
 
@@ -452,6 +453,10 @@ def main():
     torch.cuda.set_device(dev)
     from leopard_amd import dist as D
     if world > 1:
+        if not one_device:
+            # the one-sample-on-all-ranks figure must come from RCCL through the C ABI (backend "rccl (lmi_comm)", rccl_ranks == N) or
+            # not at all: without this the fallback to torch.distributed's group would be silent but for one field of the line
+            os.environ.setdefault("LMI_COMM_STRICT", "1")
         D.init(backend="gloo" if one_device else "nccl", device=dev)     # RCCL over xGMI
 
     from leopard_amd.engine import KVCache, LeopardEngine

@@ -59,6 +59,10 @@ int lmi_abi_version(void);
  * Unknown keys and out-of-range values return LMI_EINVAL. */
 int lmi_set_option(const char* key, int value);
 
+/* Diagnostics (tools/overlap_probe.py): 16-byte grid-stride copy on exactly n_workgroups workgroups of 256 threads, no LDS — a
+ * stand-in for a collective's transport kernel when measuring what runs beside the GEMMs.  Not used by the product path. */
+int lmi_debug_copy(const void* src, void* dst, int64_t bytes, int n_workgroups, void* stream);
+
 /* Deterministic synthetic parameters (no checkpoints exist offline): element i = f(seed, i, kind); bit-identical
  * to leopard_amd/synth.py.  out_dtype in {LMI_F16, LMI_BF16, LMI_F32}. */
 int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dtype, void* stream);

@@ -475,6 +475,14 @@ int lmi_set_option(const char* key, int value) {
     return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);
 }
 
+int lmi_debug_copy(const void* src, void* dst, int64_t bytes, int n_workgroups, void* stream) {
+    if (!src || !dst || bytes < 0 || (bytes & 15) || n_workgroups <= 0 || !aligned16(src) || !aligned16(dst))
+        return fail(LMI_EINVAL, "lmi_debug_copy: bad argument (bytes %% 16 == 0, 16-byte aligned pointers, n_workgroups > 0)");
+    if (bytes == 0) return LMI_OK;
+    LMI_LAUNCH(debug_copy_kernel, dim3(n_workgroups), dim3(256), 0, stream, (const u32x4*)src, (u32x4*)dst, (long)(bytes >> 4));
+    return check_launch("lmi_debug_copy");
+}
+
 int lmi_fill_synthetic(void* out, int64_t n, uint32_t seed, int kind, int out_dtype, void* stream) {
     if (!out || n < 0 || kind < 0 || kind > 2) return fail(LMI_EINVAL, "lmi_fill_synthetic: bad argument");
     if (n == 0) return LMI_OK;

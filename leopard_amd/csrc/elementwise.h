@@ -469,6 +469,15 @@ __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void*
 }
 
 // ------------------------------------------------------------------------------------------------
+// lmi_debug_copy: grid-stride 16-byte copy on a caller-chosen number of 256-thread workgroups.  Diagnostics only
+// (tools/overlap_probe.py): a stand-in for a collective's transport kernel — few workgroups, no LDS, few registers — to observe
+// whether such a kernel gets CU time beside a GEMM that holds one 128 KiB-LDS workgroup on every CU.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) debug_copy_kernel(const u32x4* src, u32x4* dst, long n16) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // lmi_quantize_fp8: out[m, d] = fp8_e4m3(x[m, d] * scale) — the hand-over of an activation to an fp8 GEMM operand (static
 // per-tensor power-of-two scale).  8 elements per lane per step (32 / 16 bytes in, 8 bytes out); HBM-bound.
 // ------------------------------------------------------------------------------------------------

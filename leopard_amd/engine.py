@@ -108,6 +108,7 @@ class LeopardEngine:
                 raise RuntimeError(f"tensor-parallel weights (tp_size {weights.tp_size}) need an initialised process group of that size")
         self.tp_chunks = 2             # row chunks per layer under TP: chunk c's collectives overlap chunk c+1's GEMMs
         self.tp_comm_dtype = None      # dtype of the reduce-scattered partial products: None = the compute type, torch.float32 = exact sums
+        self.tp_decode_graph = True    # TP decode: capture the step (with its RCCL all-reduces) in a HIP graph when the communicator is RcclComm
         self.tp_vision_gather_dtype = None   # all-gather of the projected visual tokens: None = the compute type (58 MB at C3), torch.float32 = bit-identical to one rank
         self._comm_stream = None
         self.graph_encode = False      # capture the vision encode per ViT-input count in a HIP graph (BASELINE config 5)
@@ -749,7 +750,12 @@ class LeopardEngine:
         st.cu_k[1:].add_(1)
 
     def _decode_run(self, st, cache: KVCache):
-        if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs or self.tp_size > 1:   # no collectives inside a captured graph
+        # Tensor parallel: the step holds 2 all-reduces per layer.  Through RcclComm they are plain stream-ordered RCCL launches, which
+        # HIP graph capture records like any kernel (RCCL supports capture; tests/test_gpu_dist.py captures and replays
+        # lmi_allreduce on the device), so the step stays ONE graph replay per token; over a torch.distributed group (gloo in the
+        # CPU tests, host-staged) it cannot be captured and runs eagerly.
+        tp_capturable = self.tp_size == 1 or (type(self.comm).__name__ == "RcclComm" and self.tp_decode_graph)
+        if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs or not tp_capturable:
             self._decode_body(st, cache)
             return
         if st.graph is None:

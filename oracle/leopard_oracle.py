@@ -60,6 +60,9 @@ class _Emu:
     fp32_head = True      # the HIP path feeds the last-token lm_head the fp32 normalised row (lmi_lm_head_last)
     fused = True          # production Llama schedule (lmi_gemm_ex / lmi_rmsnorm_rope): the RMSNorm operand is rounded as
                           # T(x * gamma) BEFORE the row scale, and q / k are rounded once, after the rotation
+    exact_sites = frozenset()   # split-operand study (tools/split_operand_study.py): hand-over sites treated as EXACT, i.e. as if the
+                          # operand were handed over as a hi + lo pair of 16-bit values: "norm" (LayerNorm / RMSNorm outputs feeding
+                          # q|k|v, fc1, gate/up), "attn_out" (o_proj / out_proj operand), "mlp_act" (GELU / SwiGLU output feeding fc2 / down_proj)
     operand_dtype = None  # fp8 schedule (BASELINE config 5): the A operands AND the weights of the ViT / LLM layer linears are
                           # float8_e4m3fn with per-tensor power-of-two scales; everything else stays at ``dtype``
     _wcache: dict = {}
@@ -80,8 +83,10 @@ def _fp8_round(x: Tensor) -> Tensor:
     return (x * s).clamp(-448.0, 448.0).to(_Emu.operand_dtype).to(torch.float32) / s
 
 
-def _qa(x: Tensor) -> Tensor:
+def _qa(x: Tensor, site: str = "") -> Tensor:
     """Hand-over point that is the A operand of a ViT / LLM layer linear (norm outputs, attention output, GELU / SwiGLU output)."""
+    if site and site in _Emu.exact_sites:
+        return x
     return _q(x) if _Emu.operand_dtype is None else _fp8_round(x)
 
 
@@ -101,18 +106,21 @@ def _tr(name: str, x: Tensor) -> None:
 
 
 class emulate_rounding:
-    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None):
-        self.dtype, self.trace, self.operand_dtype = dtype, trace, operand_dtype
+    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None, exact_sites=()):
+        self.dtype, self.trace, self.operand_dtype, self.exact_sites = dtype, trace, operand_dtype, frozenset(exact_sites)
 
     def __enter__(self):
         self._old = (_Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused)
+        self._old_sites = _Emu.exact_sites
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype = self.dtype, self.trace, self.operand_dtype
+        _Emu.exact_sites = self.exact_sites
         if self.operand_dtype is not None:
             _Emu.fused = False               # the fp8 schedule keeps the norms as launches of their own (lmi_norm_fp8)
         return self
 
     def __exit__(self, *exc):
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused = self._old
+        _Emu.exact_sites = self._old_sites
         _Emu._wcache.clear()
         return False
 
@@ -255,17 +263,17 @@ def siglip_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, prefix: str = "vi
     N, T, D = x.shape
     H, hd = vc.num_attention_heads, vc.head_dim
     r = x
-    h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], vc.layer_norm_eps))
+    h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], vc.layer_norm_eps), "norm")
     q = _q(F.linear(h, _wq(W[p + "self_attn.q_proj.weight"]), W[p + "self_attn.q_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
     k = _q(F.linear(h, _wq(W[p + "self_attn.k_proj.weight"]), W[p + "self_attn.k_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
     v = _q(F.linear(h, _wq(W[p + "self_attn.v_proj.weight"]), W[p + "self_attn.v_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)      # full (non-causal) attention per tile
     a = _softmax_q(s)
-    o = _qa(_q(torch.matmul(a, v))).transpose(1, 2).reshape(N, T, D)
+    o = _qa(torch.matmul(a, v) if "attn_out" in _Emu.exact_sites else _q(torch.matmul(a, v)), "attn_out").transpose(1, 2).reshape(N, T, D)
     x = r + F.linear(o, _wq(W[p + "self_attn.out_proj.weight"]), W[p + "self_attn.out_proj.bias"])
     r = x
-    h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], vc.layer_norm_eps))
-    h = _qa(gelu_tanh(F.linear(h, _wq(W[p + "mlp.fc1.weight"]), W[p + "mlp.fc1.bias"])))
+    h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], vc.layer_norm_eps), "norm")
+    h = _qa(gelu_tanh(F.linear(h, _wq(W[p + "mlp.fc1.weight"]), W[p + "mlp.fc1.bias"])), "mlp_act")
     return r + F.linear(h, _wq(W[p + "mlp.fc2.weight"]), W[p + "mlp.fc2.bias"])
 
 
@@ -392,6 +400,8 @@ def rms_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
 
 def _rms_norm_q(x: Tensor, w: Tensor, eps: float, first: bool) -> Tensor:
     """rms_norm followed by the hand-over rounding of the HIP path (identity without emulate_rounding)."""
+    if "norm" in _Emu.exact_sites:
+        return rms_norm(x, w, eps)
     if _Emu.dtype is None or not _Emu.fused or first:
         return _qa(rms_norm(x, w, eps))
     v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
@@ -429,13 +439,14 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
             causal = causal & (ar[s0:s1, None] - ar[None, :s1] < tc.sliding_window)
         sc = sc.masked_fill(~causal, float("-inf"))
         o[:, :, s0:s1] = torch.matmul(_softmax_q(sc), vv[:, :, :s1])
-    o = _qa(_q(o.transpose(1, 2).reshape(B, S, H * hd)))
+    o = o.transpose(1, 2).reshape(B, S, H * hd)
+    o = _qa(o if "attn_out" in _Emu.exact_sites else _q(o), "attn_out")
     x = r + F.linear(o, _wq(W[p + "self_attn.o_proj.weight"]))
     r = x
     h = _rms_norm_q(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps, first=False)
     g = F.linear(h, _wq(W[p + "mlp.gate_proj.weight"]))
     u = F.linear(h, _wq(W[p + "mlp.up_proj.weight"]))
-    return r + F.linear(_qa(F.silu(g) * u), _wq(W[p + "mlp.down_proj.weight"]))       # XFMR:136-139
+    return r + F.linear(_qa(F.silu(g) * u, "mlp_act"), _wq(W[p + "mlp.down_proj.weight"]))       # XFMR:136-139
 
 
 def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tensor], cfg,

@@ -96,6 +96,27 @@ def _rccl_worker(out):
         comm.broadcast(ar, 0, side)
         side.synchronize()
         res[str(dt)] = bool(torch.equal(ag, x) and torch.equal(rs, x) and torch.equal(ar, x))
+    # graph capture of the C-ABI collectives (what the tensor-parallel decode step relies on): capture all-reduce + all-gather between two
+    # elementwise kernels, replay twice, compare with the eager sequence
+    x = torch.randn(1, 4096, device=dev)
+    y, g_out = x.clone(), torch.empty(1, 4096, device=dev)
+    cap = torch.cuda.Stream(device=dev)
+    cap.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(cap):
+        comm.all_reduce(y, cap)                           # warm-up outside capture (RCCL channel setup)
+    torch.cuda.current_stream(dev).wait_stream(cap)
+    y.copy_(x)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s_ = torch.cuda.current_stream(dev)
+        y.mul_(2.0)
+        comm.all_reduce(y, s_)
+        comm.all_gather(g_out, y, s_)
+        g_out.add_(1.0)
+    y.copy_(x)
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    res["graph"] = bool(torch.equal(y, x * 4.0) and torch.equal(g_out, x * 4.0 + 1.0))
     res["sent"] = comm.sent_bytes                     # one rank: nothing goes on a link
     comm.destroy()
     dist.destroy_process_group()
@@ -114,4 +135,5 @@ def test_rccl_c_abi_single_rank_communicator():
     p.join(timeout=120)
     assert p.exitcode == 0
     assert res["ranks"] == 1 and res["backend"].startswith("rccl")
+    assert res["graph"], "lmi_allreduce / lmi_allgather inside a captured HIP graph did not replay correctly"
     assert res["torch.float16"] and res["torch.bfloat16"] and res["torch.float32"] and res["sent"] == 0

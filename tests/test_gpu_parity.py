@@ -428,7 +428,7 @@ def test_graph_captured_encode_is_bit_identical(ops):
         eng.graph_encode = True
         got = eng.encode_images(tiles)
         assert torch.equal(got, want)
-    assert sorted(eng._encode_graphs) == [3, 7]
+    assert sorted(k[0] for k in eng._encode_graphs) == [3, 7]            # one graph per (ViT-input count, launch stream)
     u8, ids, _ = sample_inputs(cfg, 1, 800, 500)
     a = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV)).logits_last.clone()
     eng.graph_encode = False

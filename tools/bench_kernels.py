@@ -57,6 +57,13 @@ def bench_gemm(args):
         ops.set_option("gemm.group_m", args.group_m)
     ops.set_option("gemm.order", args.order)
     base = SMALL_SHAPES if args.small else GEMM_SHAPES
+    if args.extra_shapes:                                       # "name:M,N,K,epilogue;..."  epilogue: store | resid | swiglu
+        epi_of = {"store": _lib.EPI_STORE, "resid": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU}
+        base = []
+        for item in args.extra_shapes.split(";"):
+            name, spec = item.split(":")
+            m, n, k, e = spec.split(",")
+            base.append((name, int(m), int(n), int(k), epi_of[e], 0))
     shapes = base if args.only < 0 else [base[args.only]]
     for name, M, N, K, epi, act in shapes:
         a = (torch.randn(M, K, generator=g)).to(dtype).to(DEV)
@@ -131,6 +138,7 @@ if __name__ == "__main__":
     ap.add_argument("--group-m", type=int, default=0)
     ap.add_argument("--order", type=int, default=0)
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--extra-shapes", default="", help='custom shapes instead of the C3 set: "name:M,N,K,store|resid|swiglu;..."')
     ap.add_argument("--lds-pad", type=int, default=0)
     ap.add_argument("--lib", default="", help="A/B: path of another build of libleopard_amd.so")
     ap.add_argument("--only", type=int, default=-1, help="index of a single GEMM shape")
