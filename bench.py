@@ -159,6 +159,32 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def roofline_from_timer(ops, run_once, passes: int, fp8: bool):
+    """HIP-event timing of every GEMM-family launch of `passes` runs of `run_once` on the launch stream -> the `roofline` object
+    of the bench line (bound = MFMA; the family is priced against the dense peak of ITS operand type)."""
+    timer = GemmTimer()
+    inner = timer.wrap(ops)
+    torch.cuda.synchronize()
+    for _ in range(passes):
+        run_once()
+    peak, family, rest = MFMA_PEAK_TFLOPS, "lmi::gemm_kernel / gemm_stagger_kernel (all epilogues, incl. the fused RMSNorm / RoPE / KV-append ones)", None
+    if fp8:
+        rest = timer.use_fp8_family()
+        peak, family = MFMA_PEAK_FP8_TFLOPS, "lmi::gemm_kernel / gemm_stagger_kernel, fp8 e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4), all epilogues"
+    gflops, gms, n = timer.summary()
+    dominant = timer.dominant(peak)
+    timer.unwrap(ops, inner)
+    achieved = (gflops / n) / (gms / n * 1e-3) / 1e12
+    r = {"bound": "mfma", "kernel": family, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+         "traffic": None, "traffic_unit": "HBM-side bytes per launch (PMC)", "algorithmic_bytes_per_launch": round(timer.bytes / n),
+         "kernel_source_hash": kernel_source_hash(), "dominant": dominant, "launches_per_step": n // passes,
+         "avg_launch_ms": round(gms / n, 4), "gemm_ms_per_step": round(gms / passes, 2)}
+    if rest is not None:
+        r["f16_gemms_left"] = {"launches_per_step": rest[2] // passes, "ms_per_step": round(rest[1] / passes, 2),
+                               "achieved": round(rest[0] / (rest[1] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS}
+    return r
+
+
 def cpu_baseline_c1(cfg, ops, dev):
     """the CPU oracle's END-TO-END prefill of config C1 (1 x 336x336 image + 32-token question, S = 228,
     27 SigLIP + 32 Llama-3.1-8B layers, fp32, same synthetic parameters) on the host cores: 1 warm-up (the bounded sample of
@@ -221,6 +247,44 @@ def cpu_baseline_sample(cfg):
     return tflops, t
 
 
+def idefics2_flops(cfg, n_img: int, P: int, S: int) -> float:
+    """Algorithmic FLOPs (2 x MACs) of a Leopard-Idefics2 prefill: n_img images of P patches each, S text + latent tokens."""
+    v, t, pc = cfg.vision_config, cfg.text_config, cfg.perceiver_config
+    d, ff, Dt, L = v.hidden_size, v.intermediate_size, t.hidden_size, pc.n_latents
+    vit = 2 * P * v.patch_dim * d + v.num_hidden_layers * (2 * P * (4 * d * d + 2 * d * ff) + 4 * P * P * d)
+    mp = 2 * P * (2 * d * t.intermediate_size + t.intermediate_size * Dt)
+    qd, kd = pc.n_heads * pc.head_dim, pc.num_key_value_heads * pc.head_dim
+    perc = pc.depth * (2 * L * Dt * qd + 2 * (P + L) * Dt * 2 * kd + 4 * L * (P + L) * qd + 2 * L * qd * Dt + 2 * L * 3 * Dt * 4 * Dt)
+    qkv = Dt * (t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim
+    llm = t.num_hidden_layers * (2 * S * (qkv + Dt * Dt + 3 * Dt * t.intermediate_size) + 2 * t.num_attention_heads * t.head_dim * S * (S + 1)) + 2 * Dt * t.vocab_size
+    return float(n_img * (vit + mp + perc) + llm)
+
+
+def cpu_baseline_idefics2():
+    """The Idefics2 CPU oracle (oracle/idefics2_oracle.py) timed on the host cores on a bounded sample: ONE 1344x896 image (-> 980x653,
+    3220 patches) + 38 text tokens through full-width layers at reduced depth (2 NaViT + 2 perceiver + 2 Mistral layers, 8k vocabulary);
+    median of 3 after 1 warm-up -> host TFLOP/s, which the caller scales to the C4 sample by algorithmic FLOPs."""
+    from PIL import Image
+    from leopard_amd.config import idefics2_mid_config
+    from leopard_amd.synth import idefics2_state_dict_numpy
+    from oracle import idefics2_oracle as IO
+    cfg = idefics2_mid_config()
+    Wt = IO.weights_from_numpy(idefics2_state_dict_numpy(cfg))
+    pix = [IO.image_processor(Image.fromarray(synth_image_u8(0, 1344, 896)), cfg.longest_edge)]
+    L = cfg.perceiver_config.n_latents
+    rng = np.random.default_rng(0)
+    ids = torch.tensor([rng.integers(3, 7000, 6).tolist() + [cfg.image_token_id] * L + rng.integers(3, 7000, 32).tolist()])
+    P = (pix[0].shape[1] // cfg.vision_config.patch_size) * (pix[0].shape[2] // cfg.vision_config.patch_size)
+    IO.prefill_logits(ids, pix, Wt, cfg, last_only=True)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        IO.prefill_logits(ids, pix, Wt, cfg, last_only=True)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[1]
+    return idefics2_flops(cfg, 1, P, ids.shape[1]) / t / 1e12, t
+
+
 FP8_DETAIL = ("fp8 e4m3fn operands (static power-of-two scales, fp32 accumulate) for the qkv / out / fc1 / fc2 linears of the 27 SigLIP "
               "layers and the qkv / o / gate-up / down linears of the 32 Llama layers; f16 attention, patch embed, projector; fp32 "
               "residual stream, norms and head")
@@ -246,7 +310,9 @@ def metric_name(args) -> str:
 
 def bench_c5(args, dev, dtype, rank, world, D):
     """BASELINE config 5 shape: a batch of 8 samples x 8 images of 1344x896 (40 ViT inputs and 6861 tokens per sample), all 8
-    samples in ONE packed pass (LeopardEngine.prefill_batch), 16-bit compute (the fp8 variant of that config is not built)."""
+    samples in ONE packed pass (LeopardEngine.prefill_batch).  --dtype fp8 = the configuration as BASELINE.json words it (e4m3
+    operands for the ViT / LLM layer linears); --graph-encode replays the vision encode from a HIP graph (prefill_batch ->
+    encode_images)."""
     from leopard_amd.engine import LeopardEngine
     from leopard_amd.gpu_tiler import GpuTiler
     from leopard_amd.ops import Ops
@@ -290,9 +356,19 @@ def bench_c5(args, dev, dtype, rank, world, D):
            "config": {"workload": f"C5 shape: {n_samples} samples x {n_img} x (1344x896) -> {n_tiles} ViT inputs, "
                                   f"{sum(seq_lens)} tokens packed in one varlen pass; SigLIP-SO400M + Llama-3.1-8B prefill to "
                                   "last-token logits; synthetic seeded weights", "parallelism": f"sample-sharded x{world}"},
-           "graph_encode": bool(args.graph_encode),
+           "graph_encode": bool(args.graph_encode), "encode_graphs_captured": len(eng._encode_graphs),
            "algorithmic_tflop_per_step": round(fl / 1e12, 2),
-           "prefill_mfma_frac": round(fl / 1e12 / (elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4)}
+           "prefill_mfma_frac": round(fl / 1e12 / (elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4),
+           "prefill_mfma_frac_note": "algorithmic FLOPs / time against the 2.5 PF dense 16-bit peak" +
+                                     (" (mixed-precision step: the fp8 linears' own roofline is below)" if args.dtype == "fp8" else "")}
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = roofline_from_timer(ops, lambda: eng.prefill_batch(samples), 1, args.dtype == "fp8")
+        out["roofline"]["traffic_source"] = "not collected for this workload"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        tflops, t = cpu_baseline_sample(cfg)
+        out["cpu_baseline"] = {"value": round(n_samples * n_img / (fl / 1e12 / tflops), 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"CPU oracle (oracle/leopard_oracle.py): 2 SigLIP layers x 2 tiles + 1 Llama layer at S=1024 ({t:.2f} s, "
+                                         f"{tflops:.3f} TFLOP/s on {torch.get_num_threads()} host threads), scaled to the batch ({fl / 1e12:.0f} TFLOP) by algorithmic FLOPs"}
     if rank == 0:
         print(json.dumps(out), flush=True)
 
@@ -343,15 +419,7 @@ def bench_idefics2(args, dev, dtype, rank, world, D):
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(res.logits_last).all()
-    v, t, pc = cfg.vision_config, cfg.text_config, cfg.perceiver_config
-    P, d, ff, Dt = 3220, v.hidden_size, v.intermediate_size, t.hidden_size
-    vit = 2 * P * v.patch_dim * d + v.num_hidden_layers * (2 * P * (4 * d * d + 2 * d * ff) + 4 * P * P * d)
-    mp = 2 * P * (2 * d * t.intermediate_size + t.intermediate_size * Dt)
-    qd, kd = pc.n_heads * pc.head_dim, pc.num_key_value_heads * pc.head_dim
-    perc = pc.depth * (2 * L * Dt * qd + 2 * (P + L) * Dt * 2 * kd + 4 * L * (P + L) * qd + 2 * L * qd * Dt + 2 * L * 3 * Dt * 4 * Dt)
-    qkv = Dt * (t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim
-    llm = t.num_hidden_layers * (2 * S * (qkv + Dt * Dt + 3 * Dt * t.intermediate_size) + 2 * t.num_attention_heads * t.head_dim * S * (S + 1)) + 2 * Dt * t.vocab_size
-    total = n_img * (vit + mp + perc) + llm
+    total = idefics2_flops(cfg, n_img, 3220, S)
     out = {"metric": "multi-image prefill images/sec (Leopard-Idefics2, 4x1344x896 per sample)",
            "value": round((1 if tp else world) * n_img * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -365,6 +433,15 @@ def bench_idefics2(args, dev, dtype, rank, world, D):
            "prefill_mfma_frac": round(total / 1e12 / (elapsed / args.steps) / (MFMA_PEAK_TFLOPS * (world if tp else 1)), 4)}
     if tp:
         out.update({"backend": eng.comm.backend, "rccl_ranks": eng.comm.ranks_seen(), "comm_bytes_per_step": int(eng.comm.sent_bytes / (args.steps + args.warmup)) * world})
+    if rank == 0 and not tp and not args.no_roofline:
+        out["roofline"] = roofline_from_timer(ops, step, 1, False)
+        out["roofline"]["traffic_source"] = "not collected for this workload"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        tflops, t = cpu_baseline_idefics2()
+        out["cpu_baseline"] = {"value": round(n_img / (total / 1e12 / tflops), 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"Idefics2 CPU oracle (fp32 PyTorch restatement, oracle/idefics2_oracle.py) on one 1344x896 image + 38 tokens through "
+                                         f"2 + 2 + 2 full-width layers: {t:.2f} s = {tflops:.3f} TFLOP/s on {torch.get_num_threads()} host threads, scaled to "
+                                         f"the C4 sample ({total / 1e12:.1f} TFLOP) by algorithmic FLOPs"}
     if rank == 0:
         print(json.dumps(out), flush=True)
 
@@ -609,23 +686,12 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        timer = GemmTimer()
-        inner = timer.wrap(ops)
-        torch.cuda.synchronize()
-        for _ in range(min(args.steps, 2)):
+        def once():
             with torch.cuda.stream(ctxs[0].stream):
                 ctxs[0].cache.length = 0
                 eng.prefill(ctxs[0].ids, ctxs[0].tiles, cache=ctxs[0].cache)
-        peak, family, rest = MFMA_PEAK_TFLOPS, "lmi::gemm_kernel / gemm_stagger_kernel (all epilogues, incl. the fused RMSNorm / RoPE / KV-append ones)", None
-        if args.dtype == "fp8":
-            rest = timer.use_fp8_family()
-            peak, family = MFMA_PEAK_FP8_TFLOPS, "lmi::gemm_kernel / gemm_stagger_kernel, fp8 e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4), all epilogues"
-        gflops, gms, n = timer.summary()
-        dominant = timer.dominant(peak)
-        timer.unwrap(ops, inner)
-        per_launch_flops = gflops / n
-        avg_ms = gms / n
-        achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12
+        passes = min(args.steps, 2)
+        rl = roofline_from_timer(ops, once, passes, args.dtype == "fp8")
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes over this very command (tools/collect_traffic.sh ->
         # tools/hbm_traffic.py).  The committed summary is stamped with the hash of the kernel sources it was measured on and is
         # reported only when that hash matches the sources in this tree: a stale summary is refused (traffic = null).
@@ -639,16 +705,8 @@ def main():
                 traffic_note = f"profiles/gemm_hbm_traffic.json is stale (measured on kernel sources {tj.get('kernel_source_hash')}); refused"
         if args.dtype == "fp8":
             traffic, traffic_note = None, "the committed PMC summary describes the f16 step; not collected for the fp8 line"
-        out["roofline"] = {"bound": "mfma", "kernel": family, "achieved": round(achieved, 1),
-                           "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                           "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": traffic_note,
-                           "algorithmic_bytes_per_launch": round(timer.bytes / n),
-                           "kernel_source_hash": kernel_source_hash(), "dominant": dominant,
-                           "launches_per_step": n // min(args.steps, 2),
-                           "avg_launch_ms": round(avg_ms, 4), "gemm_ms_per_step": round(gms / min(args.steps, 2), 2)}
-        if rest is not None:
-            out["roofline"]["f16_gemms_left"] = {"launches_per_step": rest[2] // min(args.steps, 2), "ms_per_step": round(rest[1] / min(args.steps, 2), 2),
-                                                 "achieved": round(rest[0] / (rest[1] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS}
+        rl["traffic"], rl["traffic_source"] = traffic, traffic_note
+        out["roofline"] = rl
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tflops, t = cpu_baseline_sample(cfg)                   # doubles as the warm-up of the timed C1 runs
         del eng, W, ctxs

@@ -63,6 +63,7 @@ class _Emu:
     exact_sites = frozenset()   # split-operand study (tools/split_operand_study.py): hand-over sites treated as EXACT, i.e. as if the
                           # operand were handed over as a hi + lo pair of 16-bit values: "norm" (LayerNorm / RMSNorm outputs feeding
                           # q|k|v, fc1, gate/up), "attn_out" (o_proj / out_proj operand), "mlp_act" (GELU / SwiGLU output feeding fc2 / down_proj)
+    fp8_block = 0         # 0 = per-tensor fp8 scales (what the engine does); 32 = per-32-element E8M0 block scales (study only)
     operand_dtype = None  # fp8 schedule (BASELINE config 5): the A operands AND the weights of the ViT / LLM layer linears are
                           # float8_e4m3fn with per-tensor power-of-two scales; everything else stays at ``dtype``
     _wcache: dict = {}
@@ -75,7 +76,14 @@ def _q(x: Tensor) -> Tensor:
 
 def _fp8_round(x: Tensor) -> Tensor:
     """Per-tensor power-of-two scale that puts amax in [112, 224], saturating e4m3 rounding, back to fp32 (the engine's static
-    scales differ from this only in the exponent they pick, which does not change a floating-point format's relative error)."""
+    scales differ from this only in the exponent they pick, which does not change a floating-point format's relative error).
+    With ``_Emu.fp8_block`` = 32 the scale is per 32 consecutive elements of the contraction (last) axis instead — the E8M0 block
+    scale v_mfma_scale_f32_32x32x64_f8f6f4 applies per lane (tools/fp8_scale_study.py)."""
+    if _Emu.fp8_block and x.shape[-1] % _Emu.fp8_block == 0:
+        b = x.reshape(*x.shape[:-1], x.shape[-1] // _Emu.fp8_block, _Emu.fp8_block)
+        amax = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        sc = torch.exp2(torch.floor(torch.log2(224.0 / amax)))
+        return ((b * sc).clamp(-448.0, 448.0).to(_Emu.operand_dtype).to(torch.float32) / sc).reshape(x.shape)
     amax = float(x.abs().max())
     if amax == 0.0:
         return x
@@ -106,12 +114,14 @@ def _tr(name: str, x: Tensor) -> None:
 
 
 class emulate_rounding:
-    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None, exact_sites=()):
+    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None, exact_sites=(), fp8_block: int = 0):
         self.dtype, self.trace, self.operand_dtype, self.exact_sites = dtype, trace, operand_dtype, frozenset(exact_sites)
+        self.fp8_block = fp8_block
 
     def __enter__(self):
         self._old = (_Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused)
-        self._old_sites = _Emu.exact_sites
+        self._old_sites, self._old_block = _Emu.exact_sites, _Emu.fp8_block
+        _Emu.fp8_block = self.fp8_block
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype = self.dtype, self.trace, self.operand_dtype
         _Emu.exact_sites = self.exact_sites
         if self.operand_dtype is not None:
@@ -120,7 +130,7 @@ class emulate_rounding:
 
     def __exit__(self, *exc):
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused = self._old
-        _Emu.exact_sites = self._old_sites
+        _Emu.exact_sites, _Emu.fp8_block = self._old_sites, self._old_block
         _Emu._wcache.clear()
         return False
 
