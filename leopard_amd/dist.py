@@ -44,6 +44,14 @@ def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -
         os.environ.setdefault("MASTER_PORT", "29500")
         want = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if want == "nccl":
+            # LMI_TP_COMM_CUS: upper bound on the workgroups (CUs) RCCL's transport kernels take — RCCL's own knob NCCL_MAX_NCHANNELS,
+            # set before any communicator exists.  The tensor-parallel prefill runs its exchanges on a side stream UNDER GEMMs that hold
+            # one 128 KiB-LDS workgroup on every CU; tools/overlap_probe.py (profiles/r03_overlap_probe.txt) shows that a transport-like
+            # kernel of <= 64 workgroups is co-scheduled beside them at full rate and what it costs the GEMMs, which is where the
+            # default comes from.  Unset = RCCL's own choice.
+            cus = os.environ.get("LMI_TP_COMM_CUS")
+            if cus:
+                os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(cus)))
             kw = {"device_id": device} if device is not None else {}
             dist.init_process_group("nccl", rank=rank, world_size=world, **kw)
             probe = torch.ones(1, device=device if device is not None else "cuda")

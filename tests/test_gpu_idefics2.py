@@ -47,8 +47,10 @@ def test_window_and_d96_kernels(ops):
         assert (o.float() - ref).abs().max() <= 3e-3, use_tr
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2.5e-3), (torch.bfloat16, 2.0e-2)])
-def test_idefics2_mid_prefill_vs_oracle(ops, dtype, tol):
+# tolerances = measured x 1.25 (profiles/r03_gpu_test_idefics2.txt: fp16 image features 1.14e-3 / logits 1.05e-3, bf16 7.12e-3 / 9.35e-3;
+# normalised by the maximum magnitude), replacing the hand-picked 2.5e-3 / 2e-2 of round 2
+@pytest.mark.parametrize("dtype,tol_f,tol_l", [(torch.float16, 1.43e-3, 1.32e-3), (torch.bfloat16, 8.9e-3, 1.17e-2)])
+def test_idefics2_mid_prefill_vs_oracle(ops, dtype, tol_f, tol_l):
     from PIL import Image
     from leopard_amd.idefics2 import Idefics2Engine, Idefics2SynthSource, Idefics2Weights, preprocess_image_u8
     from oracle import idefics2_oracle as IO
@@ -70,7 +72,7 @@ def test_idefics2_mid_prefill_vs_oracle(ops, dtype, tol):
     a = (res.logits_all.cpu() - logits[0]).abs().max().item() / logits.abs().max().item()
     print(f"[idefics2 mid {dtype}] normalised-max error: image features {f:.2e}, logits {a:.2e} (|logit| max {logits.abs().max():.2f})")
     assert res.n_tiles == 2 and res.seq_len == ids.shape[1]
-    assert f <= tol and a <= tol
+    assert f <= tol_f and a <= tol_l
     assert int(res.logits_last.argmax()) == int(logits[0, -1].argmax())
 
 
