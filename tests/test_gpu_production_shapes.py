@@ -566,3 +566,50 @@ def test_kv_append_on_device(ops):
     ops.kv_append(pk[1000:8187], pv[1000:8187], kc, vc, 100)
     assert torch.equal(kc[100:7287], pk[1000:8187]) and torch.equal(vc[100:7287], pv[1000:8187])
     assert bool((kc[:100] == 0).all()) and bool((kc[7287:] == 0).all())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_folded_rmsnorm_over_six_decades_of_row_scale(ops, dtype):
+    """The folded RMSNorm hands over T(x * gamma) WITHOUT the row scale (the consumer applies rstd to its accumulators), so in fp16 the
+    operand spans the raw dynamic range of the residual stream instead of O(1) normalised values.  Rows of the stream scaled by 1e-3,
+    1 and 1e3 (massive-activation rows next to tiny early-layer ones), producer (o_proj shape) -> consumer (gate/up + SwiGLU):
+    the result must be as close to fp32 as the UNFUSED schedule (rmsnorm launch -> plain GEMM) on every row class — the fold may not
+    cost precision anywhere in that range — and finite everywhere."""
+    from leopard_amd.weights import interleave_gate_up
+    M, D, F = 1536, 4096, 2048
+    g = torch.Generator(device=DEV).manual_seed(191)
+    att = (torch.randn(M, D, generator=g, device=DEV)).to(dtype)
+    wo = (torch.randn(D, D, generator=g, device=DEV) * 0.02).to(dtype)
+    wgu = (torch.randn(2 * F, D, generator=g, device=DEV) * 0.02).to(dtype)
+    wi = interleave_gate_up(wgu[:F], wgu[F:])
+    gamma = torch.rand(D, generator=g, device=DEV) + 0.5
+    scale = torch.ones(M, 1, device=DEV)
+    scale[:512] = 1e-3
+    scale[1024:] = 1e3
+    x0 = torch.randn(M, D, generator=g, device=DEV) * scale
+    att = (att.float() * scale).to(dtype)                          # the o_proj increment follows the row's scale, as in a real stream
+    eps_n = 1e-5
+    # fused: producer writes T(x * gamma) + row partials, consumer scales its accumulators
+    x = x0.clone()
+    h = torch.empty(M, D, dtype=dtype, device=DEV)
+    sq = torch.empty(M, D // 64, device=DEV)
+    ops.gemm_ex(att, wo, x, epilogue=_lib.EPI_RESIDUAL, norm_out=h, norm_gamma=gamma, rowsq_out=sq)
+    fused = torch.empty(M, F, dtype=dtype, device=DEV)
+    ops.gemm_ex(h, wi, fused, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq, norm_dim=D, norm_eps=eps_n)
+    # unfused: residual GEMM, rmsnorm launch, plain GEMM
+    x2 = x0.clone()
+    ops.gemm(att, wo, x2, epilogue=_lib.EPI_RESIDUAL)
+    h2 = torch.empty(M, D, dtype=dtype, device=DEV)
+    ops.rmsnorm(x2, gamma, h2, eps_n)
+    unfused = torch.empty(M, F, dtype=dtype, device=DEV)
+    ops.gemm(h2, wi, unfused, epilogue=_lib.EPI_SWIGLU)
+    assert torch.equal(x, x2) and torch.isfinite(h.float()).all() and torch.isfinite(fused.float()).all()
+    xr = x0.double() + att.double() @ wo.double().T
+    hr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps_n) * gamma.double()
+    lin = hr @ wgu.double().T
+    ref = (torch.nn.functional.silu(lin[:, :F]) * lin[:, F:]).float()
+    for name, rows in (("1e-3", slice(0, 512)), ("1", slice(512, 1024)), ("1e3", slice(1024, M))):
+        ef = ((fused[rows].float() - ref[rows]).pow(2).mean().sqrt() / ref[rows].pow(2).mean().sqrt()).item()
+        eu = ((unfused[rows].float() - ref[rows]).pow(2).mean().sqrt() / ref[rows].pow(2).mean().sqrt()).item()
+        print(f"[folded norm, {dtype}, row scale {name}] rel RMS vs fp64: fused {ef:.3e}, unfused {eu:.3e}")
+        assert ef <= 1.5 * eu + 1e-6, (name, ef, eu)
