@@ -111,7 +111,6 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
 // configs C1 / C2, Idefics2's text side) are decided by the tile count instead: cost = tiles per CU x tile area / the geometry's
 // relative efficiency on large problems (256x256 staggered 1.0, 256x128 0.85, 128x128 0.75, 64x128 0.55; tools/sweep_fp8_cfg.py and
 // the round-1 sweeps).  Every C3 / C5 shape has >= 464 tiles and evaluates to its class geometry, so the headline path is unchanged.
-std::atomic<int> g_gemm_split_tail{1};       // lmi_set_option("gemm.split_tail", 0) = never split the last column tile off (A/B)
 std::atomic<int> g_gemm_auto_small{1};                  // lmi_set_option("gemm.auto_small", 0) = class rules only (A/B)
 int choose_gemm_cfg(const GemmArgs& a) {
     const int forced = g_gemm_cfg.load(std::memory_order_relaxed);
@@ -460,7 +459,6 @@ int lmi_set_option(const char* key, int value) {
     }
     if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "gemm.auto_small")) { g_gemm_auto_small = value ? 1 : 0; return LMI_OK; }
-    if (!strcmp(key, "gemm.split_tail")) { g_gemm_split_tail = value < 0 ? 0 : (value > 2 ? 2 : value); return LMI_OK; }
     {
         struct { const char* key; std::atomic<int>* var; } classes[] = {{"gemm.wide", &g_gemm_wide}, {"gemm.short_k", &g_gemm_short},
                                                           {"gemm.narrow_n", &g_gemm_narrow}, {"gemm.small", &g_gemm_small}};
@@ -625,36 +623,9 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     if (a_bytes >= (1L << 32) || w_bytes >= (1L << 32))
         return fail(LMI_EINVAL, "%s: operand extent >= 4 GiB (A %ld, W %ld bytes)", who, a_bytes, w_bytes);
     a.a_bytes = (unsigned)a_bytes; a.w_bytes = (unsigned)w_bytes;
-    // Tail split (gemm.split_tail, default on): when the 256x256 schedule's LAST column tile pushes the tile count just past a multiple
-    // of the 256 CUs (SigLIP q|k|v at C3: 111 x 14 = 1554 tiles = 6.07 rounds -> 7; fc1: 1887 = 7.37 -> 8), the columns of that last
-    // tile are computed by a second, small launch on a finer geometry (111 x 13 = 1443 = 5.64 -> 6 rounds + a 128- / 256-column strip).
-    // Same arithmetic per output element (the K loop of an element does not depend on the tile geometry): results are bit-identical.
-    // Plain epilogues only (no paired columns, no folded-norm producer, no position table: their column indexing spans N).
-    const int cfg_main = choose_gemm_cfg(a);
-    if (g_gemm_split_tail.load() && (cfg_main == 5 || cfg_main == 7) && a_mode == LMI_A_PLAIN && !addmat && !x.norm_out &&
-        (epilogue == LMI_EPI_STORE || epilogue == LMI_EPI_RESIDUAL || epilogue == LMI_EPI_STORE_F32)) {
-        const long tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
-        const long rounds_all = (tiles_m * tiles_n + 255) / 256, rounds_main = (tiles_m * (tiles_n - 1) + 255) / 256;
-        if (tiles_n >= 3 && (rounds_main < rounds_all || g_gemm_split_tail.load() == 2)) {      // 2 = always (tests)
-            const int n_main = (int)(tiles_n - 1) * 256, n_tail = N - n_main;
-            GemmArgs m = a, t = a;
-            m.N = n_main;
-            m.w_bytes = (unsigned)(((long)(n_main - 1) * ldw + K) * 2);
-            t.N = n_tail;
-            t.W = (const char*)W + (long)n_main * ldw * 2;
-            t.w_bytes = (unsigned)(((long)(n_tail - 1) * ldw + K) * 2);
-            t.out = (char*)out + (long)n_main * (epilogue == LMI_EPI_STORE ? 2 : 4);
-            if (bias) t.bias = bias + n_main;
-            if (dtype == LMI_F16) {
-                const int rc = dispatch_gemm<f16_t>(m, epilogue, act, a_mode, stream);
-                return rc ? rc : dispatch_gemm<f16_t>(t, epilogue, act, a_mode, stream);
-            }
-            if (dtype == LMI_BF16) {
-                const int rc = dispatch_gemm<bf16_t>(m, epilogue, act, a_mode, stream);
-                return rc ? rc : dispatch_gemm<bf16_t>(t, epilogue, act, a_mode, stream);
-            }
-        }
-    }
+    // (Measured and dropped, profiles/r03_ab_tail_split_and_prologue.txt: computing the last 256-column tile of SigLIP q|k|v / fc1 with a
+    // second, finer launch so that the tile count drops from 6.07 / 7.37 to 5.64 / 6.94 rounds of 256 workgroups — 0.13 % SLOWER over the
+    // C3 step.  An almost-empty last round is cheap on this part: the idle CUs draw no power and the rest clock up.)
     LMI_DISPATCH_T(dtype, dispatch_gemm<f16_t>(a, epilogue, act, a_mode, stream),
                    dispatch_gemm<bf16_t>(a, epilogue, act, a_mode, stream));
 }
