@@ -178,6 +178,13 @@ int lmi_quantize_fp8(const void* x, int x_dtype, void* out, int M, int D, int ld
  * of the next fp8 GEMM (SigLIP fc1 -> fc2, Llama gate/up -> down) without a separate quantisation pass. */
 int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
                  int scale_exp, int out_dtype, float out_scale, void* stream);
+/* fp8 schedule: q | k | v projection on e4m3 operands with RoPE and the KV-cache append in the epilogue (the fp8 counterpart of
+ * lmi_rmsnorm_rope; A8 is the already normalised operand lmi_norm_fp8 wrote, Wqkv8 the fp8 weight in weights.rope_permute_rows order).
+ * qkv / caches are 16-bit (out_dtype LMI_F16 | LMI_BF16); accumulators are multiplied by 2^scale_exp first. */
+int lmi_rope_qkv_fp8(const void* A8, const void* Wqkv8, void* qkv, int scale_exp, const float* cos_table, const float* sin_table, void* k_cache,
+                     void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int lda, int ldw, int ldo,
+                     int out_dtype, void* stream);
+
 /* LayerNorm (b != null) / RMSNorm (b == null) of the fp32 stream written straight as an fp8 GEMM operand: out = fp8(norm(x) * out_scale). */
 int lmi_norm_fp8(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps, float out_scale,
                  void* stream);
@@ -195,6 +202,13 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
                         const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads,
                         int head_dim, int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window,
                         int use_tr, int dtype, void* stream);
+
+/* The same attention with the output written as the NEXT GEMM's fp8 operand: out_fp8[row, h * head_dim + d] = e4m3(O * out_scale)
+ * (uint8, row stride ldo8), straight from the fp32 accumulators — the fp8 schedule's o_proj operand without a 16-bit round trip and a
+ * conversion launch (BASELINE configs[4]).  LDS-DMA kernel only (head_dim 72 / 96 / 128). */
+int lmi_attn_varlen_fwd_fp8(const void* q, const void* k, const void* v, void* out_fp8, int ldo8, float out_scale, const int* cu_seqlens_q,
+                            const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                            int ldq, int ldk, int ldv, float scale, int causal, int window, int dtype, void* stream);
 
 /* a12 (next row f2: the decode loop) — the same attention for a few query rows against a long KV cache: the key range is
  * split over workgroups (512 keys each, at most 64 splits), partial (O, max, sum) go to `workspace` and are merged.

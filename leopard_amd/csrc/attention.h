@@ -45,6 +45,9 @@ struct AttnArgs {
     int n_splits, split_tiles, part_rows;
     float* part_o;            // [n_splits, part_rows, n_heads, D]
     float* part_ml;           // [n_splits, part_rows, n_heads, 2]  (m, l)
+    void* out_fp8;            // LDS-DMA kernel, optional: instead of `out`, write e4m3(O * out_fp8_scale) bytes [total_q, ...] (row stride ldo8) —
+    float out_fp8_scale;      // the o_proj operand of the fp8 schedule straight from the attention epilogue (no conversion launch)
+    int ldo8;
     int gqa_pack;             // LDS-DMA kernel, decode: a workgroup's 4 waves take the 4 query heads of ONE kv head (32 query rows per block)
     int check_k_extent;       // 1 = the launcher could not bound a sequence's K / V extent (< 4 GiB): the kernel checks (and traps)
 };
@@ -572,6 +575,27 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         return;
     }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (p.out_fp8) {
+        // fp8 operand of the next GEMM: 4 e4m3 bytes per dword; after the half-wave exchange the low lane owns d = db*32 + 16qp + 0..7
+        // and the high one + 8..15 — 8 contiguous bytes per lane
+        const float sc = inv * p.out_fp8_scale;
+        uint8_t* o8 = (uint8_t*)p.out_fp8 + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldo8 + head * D;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                unsigned a = 0, b = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a |= (unsigned)to_fp8(o_acc[db][8 * qp + e] * sc) << (8 * e);
+                    b |= (unsigned)to_fp8(o_acc[db][8 * qp + 4 + e] * sc) << (8 * e);
+                }
+                swap_hi_lo(a, b);
+                const int d = db * 32 + 16 * qp + 8 * fh;
+                if (my_q < len_q && d < D) *(u32x2*)(o8 + d) = u32x2{a, b};
+            }
+        return;
+    }
     T* o_row = (T*)p.out + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldo + head * D;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)

@@ -690,6 +690,32 @@ int lmi_rmsnorm_rope(const void* A, const void* Wqkv, void* qkv, const float* ro
                       LMI_A_PLAIN, 0, dtype, stream, x);
 }
 
+int lmi_rope_qkv_fp8(const void* A8, const void* Wqkv8, void* qkv, int scale_exp, const float* cos_table, const float* sin_table, void* k_cache,
+                     void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int lda, int ldw, int ldo,
+                     int out_dtype, void* stream) {
+    if (!A8 || !Wqkv8 || !qkv || !cos_table || !sin_table) return fail(LMI_EINVAL, "lmi_rope_qkv_fp8: null pointer");
+    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_rope_qkv_fp8: head_dim %d (only 128: a wave's 64 columns hold half a head)", head_dim);
+    const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
+    if (M < 0 || n_q_heads <= 0 || n_kv_heads <= 0 || K <= 0 || (K % 128) || (lda & 15) || (ldw & 15) || (ldo & 7) || !aligned16(A8) || !aligned16(Wqkv8) ||
+        !aligned16(qkv) || ((k_cache != nullptr) != (v_cache != nullptr)) || (k_cache && ((ld_cache & 7) || !aligned16(k_cache) || !aligned16(v_cache))) ||
+        !aligned16(cos_table) || !aligned16(sin_table) || scale_exp < -120 || scale_exp > 120)
+        return fail(LMI_EINVAL, "lmi_rope_qkv_fp8: bad argument (K %% 128 == 0, lda / ldw %% 16 == 0, ldo %% 8 == 0, 16-byte aligned pointers)");
+    if (M == 0) return LMI_OK;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A8; a.W = Wqkv8; a.out = qkv;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
+    const int e = 127 + scale_exp;
+    a.scale_e8m0 = e | (e << 8) | (e << 16) | (e << 24);
+    a.out_scale = 1.0f;
+    a.rope_cos = cos_table; a.rope_sin = sin_table; a.k_cache = k_cache; a.v_cache = v_cache; a.ld_cache = ld_cache; a.cache_pos0 = cache_pos0;
+    a.rope_q = n_q_heads * head_dim; a.rope_k = n_kv_heads * head_dim;
+    const long a_bytes = ((long)(M - 1) * lda + K), w_bytes = ((long)(N - 1) * ldw + K);
+    if (a_bytes >= (1L << 32) || w_bytes >= (1L << 32)) return fail(LMI_EINVAL, "lmi_rope_qkv_fp8: operand extent >= 4 GiB");
+    a.a_bytes = (unsigned)a_bytes; a.w_bytes = (unsigned)w_bytes;
+    LMI_DISPATCH_T(out_dtype, (launch_gemm_fp8<f16_t, EPI_QKV_ROPE_T, ACT_NONE>(a, stream)), (launch_gemm_fp8<bf16_t, EPI_QKV_ROPE_T, ACT_NONE>(a, stream)));
+}
+
 int lmi_norm_fp8(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps, float out_scale,
                  void* stream) {
     if (ldo & 15) return fail(LMI_EINVAL, "lmi_norm_fp8: ldo must be a multiple of 16 (fp8 GEMM operand rows)");
@@ -739,26 +765,29 @@ int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int
     LMI_DISPATCH_T(out_dtype, dispatch_gemm_fp8<f16_t>(a, epilogue, act, stream), dispatch_gemm_fp8<bf16_t>(a, epilogue, act, stream));
 }
 
-int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,
-                        const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
-                        int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream) {
-    if (!q || !k || !v || !out || !cu_seqlens_q || !cu_seqlens_k) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: null pointer");
+static int attn_varlen_entry(const char* who, const void* q, const void* k, const void* v, void* out, void* out_fp8, int ldo8, float out_fp8_scale,
+                             const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                             int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream) {
+    if (!q || !k || !v || (!out && !out_fp8) || !cu_seqlens_q || !cu_seqlens_k) return fail(LMI_EINVAL, "%s: null pointer", who);
     if (n_seq < 0 || max_seqlen_q < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads))
-        return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: bad head counts (%d, %d)", n_heads, n_kv_heads);
+        return fail(LMI_EINVAL, "%s: bad head counts (%d, %d)", who, n_heads, n_kv_heads);
     if (head_dim != 128 && head_dim != 96 && head_dim != 72)
-        return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: head_dim %d not in {72, 96, 128}", head_dim);
-    if (window < 0) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: window must be >= 0");
-    if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out))
-        return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: alignment");
+        return fail(LMI_EINVAL, "%s: head_dim %d not in {72, 96, 128}", who, head_dim);
+    if (window < 0) return fail(LMI_EINVAL, "%s: window must be >= 0", who);
+    if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || !aligned16(q) || !aligned16(k) || !aligned16(v) || (out && !aligned16(out)))
+        return fail(LMI_EINVAL, "%s: alignment", who);
+    if (out_fp8 && (!use_tr || !g_attn_dma.load() || (ldo8 & 7) || ((uintptr_t)out_fp8 & 7) || !(out_fp8_scale > 0.f)))
+        return fail(LMI_EINVAL, "%s: the fp8 output needs the LDS-DMA kernel (use_tr), ldo8 %% 8 == 0, an 8-byte aligned pointer and a positive scale", who);
     if (n_seq == 0 || max_seqlen_q == 0) return LMI_OK;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = nullptr;
+    a.out_fp8 = out_fp8; a.ldo8 = ldo8; a.out_fp8_scale = out_fp8_scale;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
     a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr; a.gqa_pack = 0;
     a.check_k_extent = 1;
     if (cu_seqlens_k == cu_seqlens_q) {                              // self-attention: the longest key sequence is max_seqlen_q
         if (((long)max_seqlen_q * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_q * ldv + head_dim) * 2 >= (1L << 32))
-            return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: one sequence's K / V rows span >= 4 GiB (max_seqlen %d, ldk %d, ldv %d)", max_seqlen_q, ldk, ldv);
+            return fail(LMI_EINVAL, "%s: one sequence's K / V rows span >= 4 GiB (max_seqlen %d, ldk %d, ldv %d)", who, max_seqlen_q, ldk, ldv);
         a.check_k_extent = 0;
     }
     if (head_dim == 128)
@@ -769,6 +798,22 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
                        (dispatch_attn<bf16_t, 96>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
     LMI_DISPATCH_T(dtype, (dispatch_attn<f16_t, 72>(a, n_seq, max_seqlen_q, causal, use_tr, stream)),
                    (dispatch_attn<bf16_t, 72>(a, n_seq, max_seqlen_q, causal, use_tr, stream)));
+}
+
+int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q,
+                        const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                        int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream) {
+    if (!out) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: null pointer");
+    return attn_varlen_entry("lmi_attn_varlen_fwd", q, k, v, out, nullptr, 0, 0.f, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads, n_kv_heads,
+                             head_dim, ldq, ldk, ldv, ldo, scale, causal, window, use_tr, dtype, stream);
+}
+
+int lmi_attn_varlen_fwd_fp8(const void* q, const void* k, const void* v, void* out_fp8, int ldo8, float out_scale, const int* cu_seqlens_q,
+                            const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                            int ldq, int ldk, int ldv, float scale, int causal, int window, int dtype, void* stream) {
+    if (!out_fp8) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd_fp8: null pointer");
+    return attn_varlen_entry("lmi_attn_varlen_fwd_fp8", q, k, v, nullptr, out_fp8, ldo8, out_scale, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads,
+                             n_kv_heads, head_dim, ldq, ldk, ldv, 0, scale, causal, window, 1, dtype, stream);
 }
 
 int64_t lmi_attn_decode_workspace_bytes(int q_rows, int n_heads, int head_dim, int max_seqlen_k) {
@@ -795,6 +840,7 @@ static int attn_decode_entry(const char* who, const void* q, const void* k, cons
     if (n_seq == 0 || max_seqlen_q == 0 || q_rows == 0) return LMI_OK;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = k_len;
+    a.out_fp8 = nullptr; a.ldo8 = 0; a.out_fp8_scale = 0.f;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
     if (((long)max_seqlen_k * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_k * ldv + head_dim) * 2 >= (1L << 32))
         return fail(LMI_EINVAL, "%s: one sequence's K / V rows span >= 4 GiB (max_seqlen_k %d, ldk %d, ldv %d)", who, max_seqlen_k, ldk, ldv);

@@ -116,6 +116,7 @@ class LeopardEngine:
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
+        self.fp8_fused = True          # fp8 schedule: attention writes the fp8 o_proj operand, q|k|v GEMM does RoPE + KV append (False: separate launches)
         self._fp8 = None               # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
         self._rec = None               # calibration recorder callable((tower, layer, site), operand tensor)
         tc = cfg.text_config
@@ -245,12 +246,16 @@ class LeopardEngine:
         att = self._empty(M, D)
         cu = self._vit_cu_cache[n]
         scale = hd ** -0.5
+        fused = self.fp8_fused and self.use_tr and not self.ops.emulated_non_dma()
         for li, (L, Q) in enumerate(zip(W.vit_layers, P.vit)):
             ops.norm_fp8(x, L.ln1_w, L.ln1_b, h8, vc.layer_norm_eps, 2.0 ** Q.act["h1"])
             ops.gemm_fp8(h8, Q.lin["qkv"].w8, qkv, bias=L.qkv_b, scale_exp=Q.out_exp("h1", "qkv"))
-            ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, cu, cu, T, H, H, hd, scale, False,
-                          self.use_tr)
-            ops.quantize_fp8(att, att8, 2.0 ** Q.act["att"])
+            if fused:
+                ops.attention_fp8out(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att8, 2.0 ** Q.act["att"], cu, cu, T, H, H, hd, scale, False)
+            else:
+                ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, cu, cu, T, H, H, hd, scale, False,
+                              self.use_tr)
+                ops.quantize_fp8(att, att8, 2.0 ** Q.act["att"])
             ops.gemm_fp8(att8, Q.lin["o"].w8, x, bias=L.o_b, epilogue=_lib.EPI_RESIDUAL, scale_exp=Q.out_exp("att", "o"))
             ops.norm_fp8(x, L.ln2_w, L.ln2_b, h8, vc.layer_norm_eps, 2.0 ** Q.act["h2"])
             ops.gemm_fp8(h8, Q.lin["fc1"].w8, ff8, bias=L.fc1_b, act=_lib.ACT_GELU_TANH, scale_exp=Q.out_exp("h2", "fc1"),
@@ -430,13 +435,22 @@ class LeopardEngine:
         qkv = self._empty(S, qw + 2 * kw)
         att = self._empty(S, qw)
         scale = hd ** -0.5
+        fused = self.fp8_fused and self.use_tr and not self.ops.emulated_non_dma()
         for i, (L, Q) in enumerate(zip(W.llm_layers, P.llm)):
             ops.norm_fp8(x, L.in_norm, None, h8, tc.rms_norm_eps, 2.0 ** Q.act["h1"])
-            ops.gemm_fp8(h8, Q.lin["qkv"].w8, qkv, scale_exp=Q.out_exp("h1", "qkv"))
-            ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
-            ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
-                          True, self.use_tr, window=tc.sliding_window or 0)
-            ops.quantize_fp8(att, att8, 2.0 ** Q.act["att"])
+            if fused and hd == 128 and "qkv_rope" in Q.lin:
+                ops.rope_qkv_fp8(h8, Q.lin["qkv_rope"].w8, qkv, Q.out_exp("h1", "qkv"), cos, sin, cache.k[i] if cache else None,
+                                 cache.v[i] if cache else None, 0, H, KV, hd)
+            else:
+                ops.gemm_fp8(h8, Q.lin["qkv"].w8, qkv, scale_exp=Q.out_exp("h1", "qkv"))
+                ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
+            if fused:
+                ops.attention_fp8out(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att8, 2.0 ** Q.act["att"], cu, cu, max_len, H, KV, hd, scale,
+                                     True, window=tc.sliding_window or 0)
+            else:
+                ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
+                              True, self.use_tr, window=tc.sliding_window or 0)
+                ops.quantize_fp8(att, att8, 2.0 ** Q.act["att"])
             ops.gemm_fp8(att8, Q.lin["o"].w8, x, epilogue=_lib.EPI_RESIDUAL, scale_exp=Q.out_exp("att", "o"))
             ops.norm_fp8(x, L.post_norm, None, h8, tc.rms_norm_eps, 2.0 ** Q.act["h2"])
             ops.gemm_fp8(h8, Q.lin["gu"].w8, gu8, epilogue=_lib.EPI_SWIGLU, scale_exp=Q.out_exp("h2", "gu"),

@@ -4,6 +4,9 @@ row a5/a11 at reduced operand precision.  NEVER the headline: bench.py reports i
 What is fp8: the A operand and the weight of the four linears of every ViT layer (qkv, out_proj, fc1, fc2) and every LLM layer
 (qkv, o_proj, gate/up, down_proj), multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 with fp32 accumulation (lmi_gemm_fp8).
 What is not: the residual stream (fp32), q / k / v, the attention (16-bit), the patch embed, the projector, the head, the decode.
+Hand-overs are fused into the producers: LayerNorm / RMSNorm write fp8 (lmi_norm_fp8), GELU / SwiGLU epilogues write fp8, the attention
+kernel writes its output as the o_proj operand (lmi_attn_varlen_fwd_fp8), and the Llama q|k|v GEMM rotates and appends to the KV cache
+in its epilogue (lmi_rope_qkv_fp8) — no conversion or RoPE launches are left (engine.fp8_fused = False restores them for A/B).
 
 Scales are static powers of two (an E8M0 exponent the MFMA applies for free):
   * weights: per tensor, amax mapped into (224, 448];
@@ -89,6 +92,9 @@ def calibrate(engine, samples, headroom: float = 2.0) -> Fp8Plan:
     for li, L in enumerate(W.llm_layers):
         lay = Fp8Layer(lin={"qkv": quantize_linear(ops, L.qkv_w), "o": quantize_linear(ops, L.o_w),
                             "gu": quantize_linear(ops, L.gu_w), "down": quantize_linear(ops, L.down_w)})
+        if getattr(L, "qkv_w_rope", None) is not None:      # the same rows in rope_permute_rows order: q|k|v + RoPE + KV append in ONE fp8 launch
+            lay.lin["qkv_rope"] = quantize_linear(ops, L.qkv_w_rope)
+            assert lay.lin["qkv_rope"].e == lay.lin["qkv"].e
         for s in LLM_SITES:
             lay.act[s] = pow2_exp(amax.get(("llm", li, s), 0.0), headroom)
         plan.llm.append(lay)

@@ -284,6 +284,27 @@ class Ops:
                                           epilogue, act, int(scale_exp), dt, float(out_scale), self._stream(out)))
         return out
 
+    def attention_fp8out(self, q, k, v, out8, out_scale: float, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, scale, causal, window=0):
+        """lmi_attn_varlen_fwd_fp8: the attention output written as e4m3(O * out_scale) bytes (uint8 [total_q, n_heads * head_dim])."""
+        n_seq = cu_q.numel() - 1
+        self._check(self.lib.lmi_attn_varlen_fwd_fp8(_ptr(q), _ptr(k), _ptr(v), _ptr(out8), out8.stride(0), float(out_scale), _ptr(cu_q), _ptr(cu_k),
+                                                     n_seq, int(max_seqlen_q), n_heads, n_kv_heads, head_dim, q.stride(0), k.stride(0), v.stride(0),
+                                                     float(scale), int(bool(causal)), int(window), _DT[q.dtype], self._stream(out8)))
+        return out8
+
+    def rope_qkv_fp8(self, a8, w8_rope, qkv, scale_exp: int, cos, sin, k_cache, v_cache, cache_pos0, n_q_heads, n_kv_heads, head_dim):
+        """lmi_rope_qkv_fp8: qkv = [RoPE(q), RoPE(k), v] of 2^scale_exp * (a8 @ w8_rope^T) on fp8 operands, K / V appended to the cache."""
+        M, K = a8.shape[0], w8_rope.shape[1]
+        ldc = 0 if k_cache is None else k_cache.stride(0)
+        self._check(self.lib.lmi_rope_qkv_fp8(_ptr(a8), _ptr(w8_rope), _ptr(qkv), int(scale_exp), _ptr(cos), _ptr(sin), _ptr(k_cache), _ptr(v_cache), ldc,
+                                              int(cache_pos0), M, n_q_heads, n_kv_heads, head_dim, K, a8.stride(0), w8_rope.stride(0), qkv.stride(0),
+                                              _DT[qkv.dtype], self._stream(qkv)))
+        return qkv
+
+    def emulated_non_dma(self) -> bool:
+        """(engine helper) the fp8-output attention exists in the LDS-DMA kernel only; it is the production kernel everywhere."""
+        return False
+
     def norm_fp8(self, x, w, b, out8, eps, out_scale: float):
         """out8 (uint8 / float8 [M, D]) = fp8(norm(x) * out_scale): LayerNorm when b is given, RMSNorm when b is None."""
         M, D = x.shape

@@ -165,7 +165,7 @@ def test_engine_fp8_schedule_matches_fp8_emulating_oracle(ops):
     calib = torch.from_numpy(np.random.default_rng(9).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
     base = eng.prefill(ids, u8, all_logits=True).logits_all.clone()
     plan = eng.enable_fp8([(torch.tensor([[3, 250, 250, 8]]), calib)])
-    assert len(plan.vit) == 2 and len(plan.llm) == 2 and set(plan.llm[0].lin) == {"qkv", "o", "gu", "down"}
+    assert len(plan.vit) == 2 and len(plan.llm) == 2 and set(plan.llm[0].lin) == {"qkv", "qkv_rope", "o", "gu", "down"}
     assert all(l.w8.dtype == torch.uint8 for lay in plan.vit + plan.llm for l in lay.lin.values())
     got = eng.prefill(ids, u8, all_logits=True).logits_all
     pix = torch.from_numpy(siglip_normalize(u8.numpy()))
@@ -180,5 +180,27 @@ def test_engine_fp8_schedule_matches_fp8_emulating_oracle(ops):
     assert measured > 3 * e16                              # the fp8 schedule really ran (an fp16 path would be far more accurate)
     assert 0.5 * predicted <= measured <= 2.0 * predicted, (predicted, measured)
     assert (got - emu).abs().max().item() / scale <= 2.0 * predicted
+    # fused hand-overs (default: the attention kernel writes the fp8 o_proj operand, the q|k|v GEMM rotates + appends K / V) vs the
+    # separate conversion / RoPE launches: the same values up to ONE rounding order (fp32 -> e4m3 directly instead of via the 16-bit type)
+    calls = []
+    for name in ("quantize_fp8", "rope_qk", "attention_fp8out", "rope_qkv_fp8"):
+        fn = getattr(ops, name)
+        setattr(ops, name, (lambda f, n: (lambda *a, **k: (calls.append(n), f(*a, **k))[1]))(fn, name))
+    try:
+        cache = __import__("leopard_amd.engine", fromlist=["KVCache"]).KVCache(cfg, 64, dtype, "cpu")
+        eng.prefill(ids, u8, cache=cache)
+        assert "attention_fp8out" in calls and "rope_qkv_fp8" in calls and "quantize_fp8" not in calls and "rope_qk" not in calls
+        k_fused = cache.k[1][:cache.length].clone()
+        eng.fp8_fused = False
+        calls.clear()
+        cache.length = 0
+        unf = eng.prefill(ids, u8, cache=cache, all_logits=True).logits_all
+        assert "quantize_fp8" in calls and "rope_qk" in calls and "attention_fp8out" not in calls
+        assert (unf - got).abs().max().item() / scale <= predicted           # two fp8 roundings apart at most
+        assert (cache.k[1][:cache.length].float() - k_fused.float()).abs().max().item() <= 0.25 * k_fused.float().abs().max().item()
+    finally:
+        eng.fp8_fused = True
+        for name in ("quantize_fp8", "rope_qk", "attention_fp8out", "rope_qkv_fp8"):
+            delattr(ops, name)
     eng.fp8 = None                                         # reverts to the 16-bit schedule bit for bit
     assert torch.equal(eng.prefill(ids, u8, all_logits=True).logits_all, base)

@@ -613,3 +613,68 @@ def test_folded_rmsnorm_over_six_decades_of_row_scale(ops, dtype):
         eu = ((unfused[rows].float() - ref[rows]).pow(2).mean().sqrt() / ref[rows].pow(2).mean().sqrt()).item()
         print(f"[folded norm, {dtype}, row scale {name}] rel RMS vs fp64: fused {ef:.3e}, unfused {eu:.3e}")
         assert ef <= 1.5 * eu + 1e-6, (name, ef, eu)
+
+
+def _fp8_dequant(u8):
+    return u8.view(F8).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [("llama", 7187, 32, 8, 128, True), ("siglip", 42 * 676, 16, 16, 72, False)], ids=lambda s: s[0])
+def test_attention_fp8_output_vs_attention_then_quantize(ops, dtype, shape):
+    """lmi_attn_varlen_fwd_fp8 (the fp8 schedule's o_proj operand written by the attention epilogue) vs the 16-bit attention followed by
+    lmi_quantize_fp8: the same values up to the order of the two roundings — every byte within one e4m3 step, >= 90 % identical."""
+    _, S, H, KV, hd, causal = shape
+    g = torch.Generator(device=DEV).manual_seed(311)
+    qkv = (torch.randn(S, (H + 2 * KV) * hd, generator=g, device=DEV)).to(dtype)
+    qw, kw = H * hd, KV * hd
+    if causal:
+        cu = torch.tensor([0, S], dtype=torch.int32, device=DEV)
+        mx = S
+    else:
+        cu = torch.arange(0, S + 1, 676, dtype=torch.int32, device=DEV)
+        mx = 676
+    scale_out = 64.0
+    att = torch.empty(S, qw, dtype=dtype, device=DEV)
+    ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, mx, H, KV, hd, hd ** -0.5, causal, True)
+    want = torch.zeros(S, qw, dtype=torch.uint8, device=DEV)
+    ops.quantize_fp8(att, want, scale_out)
+    got = torch.full((S, qw), 0x7F, dtype=torch.uint8, device=DEV)
+    ops.attention_fp8out(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], got, scale_out, cu, cu, mx, H, KV, hd, hd ** -0.5, causal)
+    torch.cuda.synchronize()
+    a, b = _fp8_dequant(got), _fp8_dequant(want)
+    assert torch.isfinite(a).all()
+    step = torch.maximum(b.abs(), torch.full_like(b, 2.0 ** -6)) * 2.0 ** -3          # one e4m3 mantissa step at that magnitude
+    assert bool(((a - b).abs() <= step * 1.001).all())
+    assert float((got == want).float().mean()) >= 0.90
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [7187, 566])
+def test_rope_qkv_fp8_vs_gemm_fp8_then_rope(ops, dtype, M):
+    """lmi_rope_qkv_fp8 (fp8 q|k|v GEMM with RoPE + KV append in the epilogue, rope-permuted weight rows) vs lmi_gemm_fp8 followed by
+    lmi_rope_qk: q / k rotated from the fp32 accumulators (one rounding) vs from the rounded 16-bit values (two) — equal within two
+    roundings of the output type; v and the V cache bit-identical."""
+    from leopard_amd.weights import rope_permute_rows
+    H, KV, hd, K = 32, 8, 128, 4096
+    N = (H + 2 * KV) * hd
+    g = torch.Generator(device=DEV).manual_seed(313 + M)
+    a8 = torch.randn(M, K, generator=g, device=DEV).to(F8)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.25).to(F8)
+    w_u8 = w.view(torch.uint8)
+    w_rope = torch.cat([rope_permute_rows(w_u8[:(H + KV) * hd]), w_u8[(H + KV) * hd:]], dim=0).contiguous()
+    f = torch.arange(M, device=DEV).float().reshape(-1, 1) * (1.0 / (500000.0 ** (torch.arange(0, hd, 2, device=DEV).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    ref = torch.empty(M, N, dtype=dtype, device=DEV)
+    ops.gemm_fp8(a8.view(torch.uint8), w.view(torch.uint8), ref, scale_exp=-6)
+    kc0, vc0 = torch.zeros(M + 8, KV * hd, dtype=dtype, device=DEV), torch.zeros(M + 8, KV * hd, dtype=dtype, device=DEV)
+    ops.rope_qk(ref, H, KV, hd, cos, sin, kc0, vc0, 3)
+    got = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    kc, vc = torch.zeros_like(kc0), torch.zeros_like(vc0)
+    ops.rope_qkv_fp8(a8.view(torch.uint8), w_rope, got, -6, cos, sin, kc, vc, 3, H, KV, hd)
+    torch.cuda.synchronize()
+    qk = (H + KV) * hd
+    assert torch.equal(got[:, qk:], ref[:, qk:]) and torch.equal(vc, vc0)
+    e = rel_err(got[:, :qk], ref[:, :qk].float())
+    assert e <= 3 * eps(dtype), e
+    assert torch.equal(kc[3:3 + M], got[:, H * hd:qk]) and bool((kc[:3] == 0).all())
