@@ -179,7 +179,7 @@ def roofline_from_timer(ops, run_once, passes: int, fp8: bool):
          "traffic": None, "traffic_unit": "HBM-side bytes per launch (PMC)", "algorithmic_bytes_per_launch": round(timer.bytes / n),
          "kernel_source_hash": kernel_source_hash(), "dominant": dominant, "launches_per_step": n // passes,
          "avg_launch_ms": round(gms / n, 4), "gemm_ms_per_step": round(gms / passes, 2)}
-    if rest is not None:
+    if rest is not None and rest[2] > 0:
         r["f16_gemms_left"] = {"launches_per_step": rest[2] // passes, "ms_per_step": round(rest[1] / passes, 2),
                                "achieved": round(rest[0] / (rest[1] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS}
     return r
@@ -362,7 +362,13 @@ def bench_c5(args, dev, dtype, rank, world, D):
            "prefill_mfma_frac_note": "algorithmic FLOPs / time against the 2.5 PF dense 16-bit peak" +
                                      (" (mixed-precision step: the fp8 linears' own roofline is below)" if args.dtype == "fp8" else "")}
     if rank == 0 and not args.no_roofline:
-        out["roofline"] = roofline_from_timer(ops, lambda: eng.prefill_batch(samples), 1, args.dtype == "fp8")
+        def eager_pass():                       # launches replayed from the captured encode graph cannot be bracketed by events: time the eager form
+            keep, eng.graph_encode = eng.graph_encode, False
+            try:
+                eng.prefill_batch(samples)
+            finally:
+                eng.graph_encode = keep
+        out["roofline"] = roofline_from_timer(ops, eager_pass, 1, args.dtype == "fp8")
         out["roofline"]["traffic_source"] = "not collected for this workload"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tflops, t = cpu_baseline_sample(cfg)

@@ -262,12 +262,14 @@ int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, 
 /* M <= 16 weight-streaming GEMM: the projections of a batched decode step (the weight stream of one token serves M tokens).
  * out[M, .] = epilogue(X[M, K] . W[N, K]^T), X and W 16-bit, K % 128 == 0.  epilogue: LMI_SKINNY_STORE (T out [M, N]),
  * LMI_SKINNY_RESIDUAL (fp32 out += ), LMI_SKINNY_SWIGLU (W rows interleaved [32 gate | 32 up]; T out [M, N/2]),
- * LMI_SKINNY_STORE_F32. */
+ * LMI_SKINNY_STORE_F32.  packed = 1: W is the same matrix pre-arranged in the MFMA operand order (1-KiB blocks [16-row group][k-step of 128]
+ * [32-k chunk][lane][8 elements]; leopard_amd.weights.skinny_pack), ldw == K: every wave load is one coalesced 1-KiB request instead
+ * of 64 scattered 16-byte pieces. */
 #define LMI_SKINNY_STORE 0
 #define LMI_SKINNY_RESIDUAL 1
 #define LMI_SKINNY_SWIGLU 2
 #define LMI_SKINNY_STORE_F32 3
-int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int dtype,
+int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed, int dtype,
                     void* stream);
 
 /* Same with the RMSNorm of the decode step folded in: x is the fp32 residual row [K], norm_weight fp32 [K], and the row

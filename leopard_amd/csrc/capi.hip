@@ -407,14 +407,14 @@ int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, in
     return check_launch("lmi_attn_decode_fwd");
 }
 
-template <typename T>
+template <typename T, bool PACKED>
 int skinny_impl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, void* stream) {
     const int units = (epilogue == LMI_SKINNY_SWIGLU) ? N / 32 : N / 16;
     switch (epilogue) {
-        case LMI_SKINNY_STORE: LMI_LAUNCH((skinny_gemm_kernel<T, SK_STORE_T>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
-        case LMI_SKINNY_RESIDUAL: LMI_LAUNCH((skinny_gemm_kernel<T, SK_RESID_F32>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
-        case LMI_SKINNY_SWIGLU: LMI_LAUNCH((skinny_gemm_kernel<T, SK_SWIGLU_T>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
-        default: LMI_LAUNCH((skinny_gemm_kernel<T, SK_STORE_F32>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+        case LMI_SKINNY_STORE: LMI_LAUNCH((skinny_gemm_kernel<T, SK_STORE_T, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+        case LMI_SKINNY_RESIDUAL: LMI_LAUNCH((skinny_gemm_kernel<T, SK_RESID_F32, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+        case LMI_SKINNY_SWIGLU: LMI_LAUNCH((skinny_gemm_kernel<T, SK_SWIGLU_T, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+        default: LMI_LAUNCH((skinny_gemm_kernel<T, SK_STORE_F32, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
     }
     return check_launch("lmi_gemm_skinny");
 }
@@ -870,18 +870,21 @@ int lmi_attn_decode_pool(const void* q, const void* k, const void* v, void* out,
                              n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, window, workspace, workspace_bytes, dtype, stream);
 }
 
-int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int dtype,
+int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed, int dtype,
                     void* stream) {
     if (!W || !X || !out) return fail(LMI_EINVAL, "lmi_gemm_skinny: null pointer");
     if (M < 0 || M > 16 || N <= 0 || K <= 0 || (K % 128) || epilogue < LMI_SKINNY_STORE || epilogue > LMI_SKINNY_STORE_F32 ||
         (N % (epilogue == LMI_SKINNY_SWIGLU ? 64 : 16)))
         return fail(LMI_EINVAL, "lmi_gemm_skinny: need M <= 16, K %% 128 == 0, N %% 16 == 0 (SwiGLU: N %% 64 == 0) (M=%d N=%d K=%d)", M, N, K);
-    if ((ldw & 7) || (ldx & 7) || ldw < K || ldx < K || !aligned16(W) || !aligned16(X) ||
+    if ((ldw & 7) || (ldx & 7) || ldw < K || ldx < K || (packed && ldw != K) || !aligned16(W) || !aligned16(X) ||
         ((epilogue == LMI_SKINNY_RESIDUAL || epilogue == LMI_SKINNY_STORE_F32) ? !aligned16(out) && ((uintptr_t)out & 3) : ((uintptr_t)out & 1)))
         return fail(LMI_EINVAL, "lmi_gemm_skinny: rows must be 16-byte aligned (ldw, ldx multiples of 8 and >= K)");
     if (M == 0) return LMI_OK;
-    LMI_DISPATCH_T(dtype, skinny_impl<f16_t>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream),
-                   skinny_impl<bf16_t>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream));
+    if (packed)
+        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)),
+                       (skinny_impl<bf16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)));
+    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)),
+                   (skinny_impl<bf16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)));
 }
 
 int lmi_rope_qk_rows(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all, const float* sin_all,

@@ -10,6 +10,11 @@
 // tiles meet in LDS, are summed in wave order (deterministic) and the epilogue runs on 256 threads.
 // Why the batch rows are not staged in LDS: X is M x K x 2 bytes (224 KiB at K = 14336, M = 8) per workgroup either way; from L2 it
 // costs (M / 16) of the weight stream's VMEM issue slots and nothing else.
+// Weight layout.  In the nn.Linear layout a wave instruction gathers 64 separate 16-byte pieces (adjacent lanes = adjacent ROWS):
+// the address path takes one lane per clock, 64 cycles per KiB, and the kernel is bound by VMEM issue (~4 TB/s) instead of HBM.
+// PACKED = true reads weights pre-arranged in the MFMA operand order (leopard_amd.weights.skinny_pack, done once at load):
+// block (16-row group r, k-step s, 32-k chunk c) is 1 KiB with lane l's 16 bytes at l * 16 — one fully coalesced 1-KiB request
+// per instruction.  Both layouts give the same bits.
 // Requirements: K % 128 == 0, N % 16 == 0 (SwiGLU: N % 64 == 0, rows interleaved [32 gate | 32 up] as weights.py lays gate/up out),
 // 16-byte aligned rows.
 #pragma once
@@ -19,7 +24,7 @@ namespace lmi {
 
 enum { SK_STORE_T = 0, SK_RESID_F32 = 1, SK_SWIGLU_T = 2, SK_STORE_F32 = 3 };
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool PACKED>
 __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo) {
     typedef typename vec_of<T>::x8 T8;
     constexpr int NW = (EPI == SK_SWIGLU_T) ? 2 : 1;               // weight row blocks per workgroup (gate, up)
@@ -31,9 +36,12 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
     // first weight row of block b: plain = 16 rows per unit; SwiGLU = unit u -> 64-row group u >> 1, half u & 1: gate rows at +16 * half,
     // their up partners 32 rows further
     const int row0 = (EPI == SK_SWIGLU_T) ? (unit >> 1) * 64 + (unit & 1) * 16 : unit * 16;
+    const int nsteps_all = K >> 7;
     const T* wrow[NW];
 #pragma unroll
-    for (int b = 0; b < NW; ++b) wrow[b] = W + (long)(row0 + 32 * b + i) * ldw + 8 * g;
+    for (int b = 0; b < NW; ++b)
+        wrow[b] = PACKED ? W + (long)((row0 + 32 * b) >> 4) * nsteps_all * 2048 + lane * 8      // 16-row group x k-steps x 4 KiB
+                         : W + (long)(row0 + 32 * b + i) * ldw + 8 * g;
     const T* xrow = X + (long)i * ldx + 8 * g;
     const bool has_x = i < M;
     const int nsteps = K >> 7;
@@ -44,7 +52,8 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
 #pragma unroll
         for (int b = 0; b < NW; ++b)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) wv[slot][b][c] = *(const T8*)(wrow[b] + k0 + 32 * c);
+            for (int c = 0; c < 4; ++c)
+                wv[slot][b][c] = PACKED ? *(const T8*)(wrow[b] + (long)(wave + 8 * s) * 2048 + c * 512) : *(const T8*)(wrow[b] + k0 + 32 * c);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (has_x) xv[slot][c] = *(const T8*)(xrow + k0 + 32 * c);

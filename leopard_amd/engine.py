@@ -116,6 +116,7 @@ class LeopardEngine:
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
+        self.skinny_packed = True      # batched decode: stream the projections from a copy in the MFMA operand order (coalesced 1-KiB loads)
         self.fp8_fused = True          # fp8 schedule: attention writes the fp8 o_proj operand, q|k|v GEMM does RoPE + KV append (False: separate launches)
         self._fp8 = None               # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
         self._rec = None               # calibration recorder callable((tower, layer, site), operand tensor)
@@ -899,25 +900,39 @@ class LeopardEngine:
         states[B] = st
         return st
 
+    def _skinny_weights(self):
+        """The decode projections + the head in lmi_gemm_skinny's packed (MFMA operand) order — a second copy of the 16-bit LLM weights
+        (15 GB for Llama-3.1-8B; the part has 288 GB), built on the first batched decode and shared by every batch size."""
+        pk = getattr(self, "_skinny_pack", None)
+        if pk is None:
+            from .weights import skinny_pack
+            W = self.W
+            pk = self._skinny_pack = {"layers": [(skinny_pack(L.qkv_w), skinny_pack(L.o_w), skinny_pack(L.gu_w), skinny_pack(L.down_w))
+                                                 for L in W.llm_layers], "head": skinny_pack(W.lm_head)}
+        return pk
+
     def _batch_decode_body(self, st):
         """One decode step for the B sequences of ``st`` (everything here is host-value free: graph-capturable)."""
         ops, W, tc = self.ops, self.W, self.cfg.text_config
         (H, KV), hd = self._llm_heads(), tc.head_dim
         qw, eps = H * hd, tc.rms_norm_eps
         ops.embed_merge(st.tok, st.src, W.embed, None, st.x)
+        pk = self._skinny_weights() if self.skinny_packed else None
         for i, L in enumerate(W.llm_layers):
+            qkv_w, o_w, gu_w, down_w = pk["layers"][i] if pk else (L.qkv_w, L.o_w, L.gu_w, L.down_w)
+            packed = pk is not None
             ops.rmsnorm(st.x, L.in_norm, st.h, eps)
-            ops.gemm_skinny(L.qkv_w, st.h, st.qkv, 0)
+            ops.gemm_skinny(qkv_w, st.h, st.qkv, 0, packed)
             ops.rope_qk_rows(st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos)
             ops.attention_decode_pool(st.qkv[:, :qw], st.k[i], st.v[i], st.att, st.cu_q, st.k_begin, st.k_len, st.capacity, H, KV, hd,
                                       hd ** -0.5, st.ws, window=tc.sliding_window or 0)
-            ops.gemm_skinny(L.o_w, st.att, st.x, 1)
+            ops.gemm_skinny(o_w, st.att, st.x, 1, packed)
             ops.rmsnorm(st.x, L.post_norm, st.h, eps)
-            ops.gemm_skinny(L.gu_w, st.h, st.gu, 2)
-            ops.gemm_skinny(L.down_w, st.gu, st.x, 1)
+            ops.gemm_skinny(gu_w, st.h, st.gu, 2, packed)
+            ops.gemm_skinny(down_w, st.gu, st.x, 1, packed)
         # head: one pass over lm_head for all B rows (lmi_lm_head_last streams the 1 GB head once PER row)
         ops.rmsnorm(st.x, W.final_norm, st.h, eps)
-        ops.gemm_skinny(W.lm_head, st.h, st.logits, 3)
+        ops.gemm_skinny(pk["head"] if pk else W.lm_head, st.h, st.logits, 3, pk is not None)
         if self.suppress_tokens is not None:
             st.logits.index_fill_(1, self.suppress_tokens, float("-inf"))
         torch.argmax(st.logits[:, :tc.vocab_size], dim=1, out=st.tok)

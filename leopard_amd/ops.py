@@ -168,13 +168,13 @@ class Ops:
                                               _ptr(pos_rows), _DT[qkv.dtype], self._stream(qkv)))
         return qkv
 
-    def gemm_skinny(self, w, x, out, epilogue=0):
+    def gemm_skinny(self, w, x, out, epilogue=0, packed=False):
         """out[M <= 16, .] = epilogue(x @ w.T): the projections of a batched decode step.  epilogue: 0 store T, 1 fp32 +=,
-        2 SwiGLU (w rows interleaved [32 gate | 32 up], out [M, N/2]), 3 store fp32."""
+        2 SwiGLU (w rows interleaved [32 gate | 32 up], out [M, N/2]), 3 store fp32.  packed: w is weights.skinny_pack(w) (same shape)."""
         N, K = w.shape
         M = x.shape[0]
         self._check(self.lib.lmi_gemm_skinny(_ptr(w), _ptr(x), _ptr(out), M, N, K, w.stride(0), x.stride(0), out.stride(0), int(epilogue),
-                                             _DT[w.dtype], self._stream(out)))
+                                             int(bool(packed)), _DT[w.dtype], self._stream(out)))
         return out
 
     def decode_workspace_elems(self, q_rows, n_heads, head_dim, max_seqlen_k) -> int:

@@ -95,6 +95,16 @@ def rope_permute_rows(w: torch.Tensor, head_dim: int = 128) -> torch.Tensor:
     return w.view(n, head_dim, -1)[:, idx].reshape(w.shape).contiguous()
 
 
+def skinny_pack(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] weight -> the same elements in lmi_gemm_skinny's packed order (N % 16 == 0, K % 128 == 0): 1-KiB blocks
+    [16-row group r][k-step s of 128][32-k chunk c][lane l = 16 g + i][8 elements] with element (r, s, c, g, i, j) = w[16 r + i, 128 s + 32 c + 8 g + j]
+    — exactly what lane l of a wave feeds v_mfma_f32_16x16x32 as its A operand, so a wave-wide load is one contiguous 1-KiB request."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 128 == 0
+    v = w.contiguous().view(N // 16, 16, K // 128, 4, 4, 8)            # (r, i, s, c, g, j)
+    return v.permute(0, 2, 3, 4, 1, 5).contiguous().view(N, K)          # (r, s, c, g, i, j)
+
+
 @dataclass
 class VitLayerW:
     ln1_w: torch.Tensor; ln1_b: torch.Tensor

@@ -595,6 +595,11 @@ def test_gemm_skinny_all_epilogues(ops, dtype_pair, M, N, K):
     acc0 = acc.clone()
     ops.gemm_skinny(w, x, acc, 1)
     assert (acc - (acc0 + ref)).abs().max() <= 1e-3 * max(1.0, ref.abs().max().item())
+    from leopard_amd.weights import skinny_pack
+    wp = skinny_pack(w)                                            # the packed (MFMA operand order) copy gives the same bits
+    outp = torch.zeros(M, N, dtype=dtype)
+    ops.gemm_skinny(wp, x, outp, 0, packed=True)
+    assert torch.equal(outp, out[:M])
     if N % 64 == 0:
         F = N // 2
         lv = ref.view(M, N // 64, 2, 32)
@@ -602,6 +607,9 @@ def test_gemm_skinny_all_epilogues(ops, dtype_pair, M, N, K):
         o = torch.zeros(M, F, dtype=dtype)
         ops.gemm_skinny(w, x, o, 2)
         assert (o.float() - want).abs().max() <= tol(dtype) * max(1.0, want.abs().max().item())
+        op = torch.zeros(M, F, dtype=dtype)
+        ops.gemm_skinny(wp, x, op, 2, packed=True)
+        assert torch.equal(op, o)
 
 
 def test_rope_rows_equals_rope_at_per_row(ops):

@@ -366,8 +366,10 @@ def test_gemm_skinny_llama_decode_shapes(ops, dtype, M):
         else:
             ref = lin
             outs = [torch.zeros(M, N, dtype=dtype if epi == 0 else torch.float32, device=DEV) for _ in range(3)]
-        for o in outs:
-            ops.gemm_skinny(w, x, o, epi)
+        from leopard_amd.weights import skinny_pack
+        wp = skinny_pack(w)
+        for j, o in enumerate(outs):                               # launches 0, 1: row-major weights; launch 2: the packed copy — same bits
+            ops.gemm_skinny(wp if j == 2 else w, x, o, epi, packed=(j == 2))
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), name
         check(outs[0], ref, dtype if epi in (0, 2) else torch.float16, k=4.0, what=f"skinny {name} M={M}")

@@ -5,7 +5,7 @@
 
 Builds the engine once (bench.py's C3 sample), then alternates the variants round by round (variant x round, so that clock /
 temperature drift hits every arm alike); each measurement = `steps` prefill steps between two device synchronisations.  A variant is
-`name:key=value,key=value` over lmi_set_option keys; every key any variant sets is reset to its default before each arm.  Prints the
+`name:key=value,key=value` over lmi_set_option keys (or `eng.<attribute>=0|1` for engine switches such as eng.fp8_fused); every key any variant sets is reset to its default before each arm.  Prints the
 per-round ms per step and the median per variant, and checks that every arm's last-position logits equal the first arm's within 2e-2
 (the options are speed-only; identical kernels give identical bits, variants that change the summation order do not)."""
 import argparse
@@ -39,7 +39,7 @@ def main():
     from leopard_amd.ops import Ops
     from leopard_amd.weights import EngineWeights, SynthSource
     dev = torch.device("cuda:0")
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16         # fp8: e4m3 layer linears over an f16 engine
     cfg = full_config()
     ops = Ops()
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
@@ -51,6 +51,10 @@ def main():
     n_tiles = u8.shape[0]
     S = ids.shape[1] + n_tiles * (cfg.tokens_per_tile - 1)
     cache = KVCache(cfg, S, dtype, dev)
+    if args.dtype == "fp8":
+        class _A:
+            width, height = 1344, 896
+        bench.enable_fp8(eng, cfg, _A)
 
     variants = []
     for v in args.variant or ["base:"]:
