@@ -74,7 +74,8 @@ typedef GemmCfg<256, 128, 4, 2, 2> Cfg3;   //  96 KiB LDS
 typedef GemmCfg<128, 256, 2, 4, 3> Cfg4;   // 144 KiB LDS, wave tile 64x64, 3-slot ring
 typedef GemmCfg<64, 128, 2, 2, 3> CfgS;    //  72 KiB LDS, 256 threads, wave tile 32x64: small-M problems
 typedef GemmCfg<64, 128, 2, 2, 6> CfgS6;   // 144 KiB LDS: 5 k-tiles in flight for latency-bound weight streaming at small M
-constexpr int kNumGemmCfg = 10;             // 0-4 ring geometries; 5-7 staggered 256x256 schedules; 8-9 small-M rings
+typedef GemmCfg<384, 128, 4, 2, 2> CfgM;   // 128 KiB LDS, wave tile 96x64: M-complete tiles for 256 < M <= 384 (every weight tile is fetched ONCE)
+constexpr int kNumGemmCfg = 11;             // 0-4 ring geometries; 5-7 staggered 256x256 schedules; 8-9 small-M rings; 10 M-complete 384x128
 std::atomic<int> g_gemm_cfg{-1};            // -1 = choose per shape (options are process-wide; relaxed atomics: launches on other threads read them)
 std::atomic<int> g_gemm_group_m{GEMM_GROUP_M};
 std::atomic<int> g_gemm_order{0};
@@ -111,10 +112,14 @@ int launch_gemm_stagger(const GemmArgs& a, void* stream) {
 // configs C1 / C2, Idefics2's text side) are decided by the tile count instead: cost = tiles per CU x tile area / the geometry's
 // relative efficiency on large problems (256x256 staggered 1.0, 256x128 0.85, 128x128 0.75, 64x128 0.55; tools/sweep_fp8_cfg.py and
 // the round-1 sweeps).  Every C3 / C5 shape has >= 464 tiles and evaluates to its class geometry, so the headline path is unchanged.
+std::atomic<int> g_gemm_mid_m{1};            // lmi_set_option("gemm.mid_m", 0) = 64x128 tiles for every M < 512 (A/B)
 std::atomic<int> g_gemm_auto_small{1};                  // lmi_set_option("gemm.auto_small", 0) = class rules only (A/B)
 int choose_gemm_cfg(const GemmArgs& a) {
     const int forced = g_gemm_cfg.load(std::memory_order_relaxed);
     if (forced >= 0) return forced;
+    // 256 < M <= 384 (Idefics2's text side: S = 312) on a wide N: one M-complete 384x128 tile per 128 weight rows — the weights are streamed
+    // once instead of once per 64-row tile (5x at M = 312); narrower N leaves too few tiles for 256 CUs and stays on the 64x128 ring
+    if (g_gemm_mid_m.load() && a.M > 256 && a.M <= 384 && a.N >= 128 * 160) return 10;
     if (a.M < 512) return 8;
     const int cls = a.N >= 2048 ? (a.K <= 1536 ? g_gemm_short.load() : g_gemm_wide.load()) : (a.K >= 2048 ? g_gemm_narrow.load() : g_gemm_small.load());
     if (!g_gemm_auto_small.load()) return cls;
@@ -153,6 +158,7 @@ int launch_gemm(const GemmArgs& a, void* stream) {
         case 6: return launch_gemm_stagger<T, EPI, ACT, AMODE, Cfg1, 1>(a, stream);   // the same with the single-tile prologue of rounds 1-2 (A/B)
         case 8: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgS>(a, stream);
         case 9: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgS6>(a, stream);
+        case 10: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgM>(a, stream);
         default: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg0>(a, stream);
     }
 }
@@ -177,7 +183,7 @@ int launch_gemm_fp8(const GemmArgs& a, void* stream) {
             LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE_PLAIN, Cfg1, 0, fp8_t>), dim3(tiles), dim3(Cfg1::NT), Cfg1::SMEM_TOTAL, stream, a);
             return check_launch("lmi_gemm_fp8");
         }
-        case 8: case 9: return launch_gemm_fp8_ring<T, EPI, ACT, CfgS>(a, stream);
+        case 8: case 9: case 10: return launch_gemm_fp8_ring<T, EPI, ACT, CfgS>(a, stream);
         default: return launch_gemm_fp8_ring<T, EPI, ACT, Cfg0>(a, stream);
     }
 }
@@ -459,6 +465,7 @@ int lmi_set_option(const char* key, int value) {
     }
     if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "gemm.auto_small")) { g_gemm_auto_small = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "gemm.mid_m")) { g_gemm_mid_m = value ? 1 : 0; return LMI_OK; }
     {
         struct { const char* key; std::atomic<int>* var; } classes[] = {{"gemm.wide", &g_gemm_wide}, {"gemm.short_k", &g_gemm_short},
                                                           {"gemm.narrow_n", &g_gemm_narrow}, {"gemm.small", &g_gemm_small}};

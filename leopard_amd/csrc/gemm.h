@@ -195,18 +195,21 @@ template <int WTN> struct GemmImage { static constexpr int RS = WTN * 4 + 16; };
 // where the row sits in a packed batch.
 template <typename C>
 struct GemmRowScale {
-    static constexpr int TPR = C::NT / C::BM;                                // threads per row: 2 or 4
+    // geometries whose thread count is 2x or 4x the tile rows share a row between 2 / 4 threads and prefetch; any other geometry (384 x 128:
+    // 512 threads for 384 rows) gives thread r < BM the whole row and reads the partials after the main loop (LATE: one exposed L2 round
+    // trip per tile, on shapes whose tiles run for tens of microseconds)
+    static constexpr bool LATE = !(C::NT % C::BM == 0 && (C::NT / C::BM == 2 || C::NT / C::BM == 4));
+    static constexpr int TPR = LATE ? 1 : C::NT / C::BM;                     // threads per row
     static constexpr int QPT = 4 / TPR;                                      // quarters per thread
-    static_assert(TPR == 2 || TPR == 4, "threads per tile row");
-    f32x4 v[QPT][4];                                                         // fast path: 16 partials per quarter (hidden size 4096)
+    f32x4 v[LATE ? 1 : QPT][4];                                              // fast path: 16 partials per quarter (hidden size 4096)
     const float* part;
     int qlen;
 
     LMI_DEV void load(const GemmArgs& p, int m0, int tid) {
         const int r = tid / TPR, sub = tid % TPR;
-        part = p.rowsq_in + (long)imin(m0 + r, p.M - 1) * p.rowsq_parts + sub * QPT * (p.rowsq_parts >> 2);
+        part = p.rowsq_in + (long)imin(m0 + imin(r, C::BM - 1), p.M - 1) * p.rowsq_parts + sub * QPT * (p.rowsq_parts >> 2);
         qlen = p.rowsq_parts >> 2;                                           // rowsq_parts % 4 == 0 is checked by the launcher
-        if (qlen == 16) {
+        if (!LATE && qlen == 16) {
 #pragma unroll
             for (int i = 0; i < QPT; ++i)
 #pragma unroll
@@ -218,7 +221,7 @@ struct GemmRowScale {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             float acc = 0.f;
-            if (qlen == 16) {
+            if (!LATE && qlen == 16) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
             } else if ((qlen & 3) == 0) {
@@ -232,7 +235,9 @@ struct GemmRowScale {
             q[i] = acc;
         }
         float s;
-        if (TPR == 2) {
+        if (TPR == 1) {
+            s = (q[0] + q[1 % QPT]) + (q[2 % QPT] + q[3 % QPT]);             // the same order as the shared-row forms below
+        } else if (TPR == 2) {
             s = q[0] + q[QPT - 1];                                           // (q0 + q1) resp. (q2 + q3)
             s += shfl_xor(s, 1);
         } else {
@@ -240,7 +245,7 @@ struct GemmRowScale {
             s += shfl_xor(s, 1);                                             // (q0 + q1), (q2 + q3)
             s += shfl_xor(s, 2);
         }
-        if (tid % TPR == 0) rstd_lds[tid / TPR] = 1.0f / sqrtf(s / (float)p.norm_dim + p.norm_eps);
+        if (tid % TPR == 0 && tid / TPR < C::BM) rstd_lds[tid / TPR] = 1.0f / sqrtf(s / (float)p.norm_dim + p.norm_eps);
         lds_write_drain();
     }
 };

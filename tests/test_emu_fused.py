@@ -38,7 +38,7 @@ def test_rope_permute_rows_is_the_documented_order():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 5, 8])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 5, 8, 10])
 def test_gemm_ex_producer_and_consumer(ops, dtype, cfg):
     """x += a.w^T; h = T(x * gamma), rowsq partials; then a consumer GEMM on h with the row scale == the GEMM on rmsnorm(x)."""
     M, N, K = 300, 256, 128
@@ -97,7 +97,7 @@ def rope_ref(x, cos, sin):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 5, 8])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 5, 8, 10])
 @pytest.mark.parametrize("with_norm", [False, True])
 def test_rmsnorm_rope_qkv_projection(ops, dtype, cfg, with_norm):
     S, nq, nkv, D, K = 150, 2, 1, 128, 256
@@ -235,7 +235,7 @@ def test_generate_batch_equals_per_sample_generate():
         assert torch.equal(one, got)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 5])
+@pytest.mark.parametrize("cfg", [-1, 0, 5, 10])
 def test_gemm_ex_consumer_at_hidden_4096(ops, cfg):
     """The row-scale prologue's batched-load path (64 partials per row = hidden size 4096), both threads-per-row geometries."""
     dtype = torch.float16

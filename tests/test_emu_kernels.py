@@ -136,7 +136,7 @@ def test_gemm_pixel_shuffle_gather(ops, dtype):
     assert (out.float() - ref).abs().max() <= tol(dtype) * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_every_tile_geometry(ops, cfg):
     """All GemmCfg geometries (128x128 .. 256x256, 2- and 3-slot LDS rings) on ragged M, an N that is not a multiple
     of the tile width, and enough k-tiles to wrap the ring several times."""

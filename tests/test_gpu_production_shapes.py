@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 DTYPES = [torch.float16, torch.bfloat16]
 # 0-4 ring geometries (128x128/2, 256x256/2, 256x128/3, 256x128/2, 128x256/3), 5-7 staggered 256x256 variants, 8 small-M ring
-ALL_CFGS = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8]
+ALL_CFGS = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 10]
 
 
 @pytest.fixture(scope="module")
@@ -323,7 +323,7 @@ def test_gemm_ex_residual_norm_producer_m7187(ops, dtype, cfg, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [-1, 1, 5, 7])
+@pytest.mark.parametrize("cfg", [-1, 1, 5, 7, 10])
 def test_gemm_ex_swiglu_consumer_m7187(ops, dtype, cfg):
     """gate/up + SwiGLU with the RMSNorm row scale applied to the accumulators (rowsq_in), M = 7187, N = 28672."""
     from leopard_amd.weights import interleave_gate_up
@@ -678,3 +678,30 @@ def test_rope_qkv_fp8_vs_gemm_fp8_then_rope(ops, dtype, M):
     e = rel_err(got[:, :qk], ref[:, :qk].float())
     assert e <= 3 * eps(dtype), e
     assert torch.equal(kc[3:3 + M], got[:, H * hd:qk]) and bool((kc[:3] == 0).all())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_mid_m_complete_tile_m312(ops, dtype):
+    """Idefics2's text side (S = 312): gate/up + SwiGLU with the folded RMSNorm row scale on the M-complete 384 x 128 geometry the chooser
+    picks for 256 < M <= 384 and wide N, vs fp32 and vs the 64 x 128 geometry (gemm.mid_m = 0): same rows, same row scales (bit-identical
+    rstd by construction), results equal within the output rounding."""
+    from leopard_amd.weights import interleave_gate_up
+    M, F, K = 312, 14336, 4096
+    a, w, _, ref = operands(M, 2 * F, K, dtype, 0.02)
+    wi = interleave_gate_up(w[:F], w[F:])
+    g = torch.Generator(device=DEV).manual_seed(93)
+    sq = (torch.rand(M, K // 64, generator=g, device=DEV) + 0.5) * 64
+    rstd = torch.rsqrt(sq.sum(-1, keepdim=True) / K + 1e-5)
+    want = torch.nn.functional.silu(ref[:, :F] * rstd) * (ref[:, F:] * rstd)
+    outs = {}
+    try:
+        for mid in (1, 0):
+            ops.set_option("gemm.mid_m", mid)
+            out = torch.full((M, F), float("nan"), dtype=dtype, device=DEV)
+            ops.gemm_ex(a, wi, out, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq, norm_dim=K, norm_eps=1e-5)
+            outs[mid] = out
+            e = rel_err(out, want)
+            assert e <= 3 * eps(dtype), f"mid_m {mid}: {e:.3e}"
+    finally:
+        ops.set_option("gemm.mid_m", 1)
+    assert rel_err(outs[1], outs[0].float()) <= 2 * eps(dtype)
