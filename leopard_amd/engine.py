@@ -247,7 +247,7 @@ class LeopardEngine:
         att = self._empty(M, D)
         cu = self._vit_cu_cache[n]
         scale = hd ** -0.5
-        fused = self.fp8_fused and self.use_tr and not self.ops.emulated_non_dma()
+        fused = self.fp8_fused and self.use_tr          # (the fp8-output attention lives in the LDS-DMA kernel, the production one)
         for li, (L, Q) in enumerate(zip(W.vit_layers, P.vit)):
             ops.norm_fp8(x, L.ln1_w, L.ln1_b, h8, vc.layer_norm_eps, 2.0 ** Q.act["h1"])
             ops.gemm_fp8(h8, Q.lin["qkv"].w8, qkv, bias=L.qkv_b, scale_exp=Q.out_exp("h1", "qkv"))
@@ -436,7 +436,7 @@ class LeopardEngine:
         qkv = self._empty(S, qw + 2 * kw)
         att = self._empty(S, qw)
         scale = hd ** -0.5
-        fused = self.fp8_fused and self.use_tr and not self.ops.emulated_non_dma()
+        fused = self.fp8_fused and self.use_tr          # (the fp8-output attention lives in the LDS-DMA kernel, the production one)
         for i, (L, Q) in enumerate(zip(W.llm_layers, P.llm)):
             ops.norm_fp8(x, L.in_norm, None, h8, tc.rms_norm_eps, 2.0 ** Q.act["h1"])
             if fused and hd == 128 and "qkv_rope" in Q.lin:

@@ -301,10 +301,6 @@ class Ops:
                                               _DT[qkv.dtype], self._stream(qkv)))
         return qkv
 
-    def emulated_non_dma(self) -> bool:
-        """(engine helper) the fp8-output attention exists in the LDS-DMA kernel only; it is the production kernel everywhere."""
-        return False
-
     def norm_fp8(self, x, w, b, out8, eps, out_scale: float):
         """out8 (uint8 / float8 [M, D]) = fp8(norm(x) * out_scale): LayerNorm when b is given, RMSNorm when b is None."""
         M, D = x.shape
