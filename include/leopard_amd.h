@@ -39,7 +39,8 @@ enum {
     LMI_EPI_RESIDUAL = 1, /* out[f32] += acc + bias            (residual stream update)   */
     LMI_EPI_STORE_F32 = 2,/* out[f32] = acc + bias + addmat[row % add_period]             */
     LMI_EPI_SWIGLU = 3,   /* out[T][:, N/2] = silu(gate) * up, W rows interleaved [32 gate | 32 up] */
-    LMI_EPI_QKV_ROPE = 4  /* q | k | v projection + RoPE + KV-cache append (lmi_rmsnorm_rope only) */
+    LMI_EPI_QKV_ROPE = 4, /* q | k | v projection + RoPE + KV-cache append (lmi_rmsnorm_rope only) */
+    LMI_EPI_SWIGLU_F32 = 5/* LMI_EPI_SWIGLU with an fp32 destination [., N/2] (split-operand precision mode) */
 };
 enum { LMI_ACT_NONE = 0, LMI_ACT_GELU_TANH = 1, LMI_ACT_GELU_ERF = 2 };
 enum { LMI_A_PLAIN = 0, LMI_A_PIXEL_SHUFFLE = 1 };
@@ -207,6 +208,16 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
  * (uint8, row stride ldo8), straight from the fp32 accumulators — the fp8 schedule's o_proj operand without a 16-bit round trip and a
  * conversion launch (BASELINE configs[4]).  LDS-DMA kernel only (head_dim 72 / 96 / 128). */
 int lmi_attn_varlen_fwd_fp8(const void* q, const void* k, const void* v, void* out_fp8, int ldo8, float out_scale, const int* cu_seqlens_q,
+                            const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                            int ldq, int ldk, int ldv, float scale, int causal, int window, int dtype, void* stream);
+
+/* Split-operand precision mode (LeopardEngine.split_operands).  The HIP path's distance from the fp32 reference is one
+ * rounding to the 16-bit type per hand-over of an activation to an MFMA operand.  lmi_split_hi_lo writes an fp32 activation [M, K] as the
+ * 16-bit pair [M, 2K] = [T(x) | T(x - T(x))]; a GEMM over it against the weight laid out twice, [W | W], computes hi.W + lo.W — the
+ * product of the unrounded activation — at twice the K.  The producers hand over fp32: the norms (LMI_F32 outputs), the attention
+ * (lmi_attn_varlen_fwd_f32: normalised output in fp32, LDS-DMA kernel), fc1 (LMI_EPI_STORE_F32 + GELU) and gate/up (LMI_EPI_SWIGLU_F32). */
+int lmi_split_hi_lo(const float* x, void* out, int M, int K, int ldx, int ldo, int dtype, void* stream);
+int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* out_f32, int ldo32, const int* cu_seqlens_q,
                             const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                             int ldq, int ldk, int ldv, float scale, int causal, int window, int dtype, void* stream);
 

@@ -45,6 +45,8 @@ struct AttnArgs {
     int n_splits, split_tiles, part_rows;
     float* part_o;            // [n_splits, part_rows, n_heads, D]
     float* part_ml;           // [n_splits, part_rows, n_heads, 2]  (m, l)
+    float* out_f32;           // LDS-DMA kernel, optional: instead of `out`, the normalised output in fp32 [total_q, ...] (row stride ldo32) — the
+    int ldo32;                // split-operand precision mode hands it to lmi_split_hi_lo instead of rounding it to 16 bits here
     void* out_fp8;            // LDS-DMA kernel, optional: instead of `out`, write e4m3(O * out_fp8_scale) bytes [total_q, ...] (row stride ldo8) —
     float out_fp8_scale;      // the o_proj operand of the fp8 schedule straight from the attention epilogue (no conversion launch)
     int ldo8;
@@ -575,6 +577,18 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         return;
     }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (p.out_f32) {
+        float* o32 = p.out_f32 + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldo32 + head * D;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int d = db * 32 + 8 * qd + 4 * fh;
+                if (my_q < len_q && d < D)
+                    *(f32x4*)(o32 + d) = f32x4{o_acc[db][4 * qd] * inv, o_acc[db][4 * qd + 1] * inv, o_acc[db][4 * qd + 2] * inv, o_acc[db][4 * qd + 3] * inv};
+            }
+        return;
+    }
     if (p.out_fp8) {
         // fp8 operand of the next GEMM: 4 e4m3 bytes per dword; after the half-wave exchange the low lane owns d = db*32 + 16qp + 0..7
         // and the high one + 8..15 — 8 contiguous bytes per lane

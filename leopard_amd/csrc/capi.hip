@@ -225,6 +225,7 @@ int dispatch_gemm(const GemmArgs& a, int epi, int act, int amode, void* stream) 
             break;
         case LMI_EPI_STORE_F32:
             if (act == LMI_ACT_NONE) return launch_gemm<T, EPI_STORE_F32, ACT_NONE, AMODE_PLAIN>(a, stream);
+            if (act == LMI_ACT_GELU_TANH) return launch_gemm<T, EPI_STORE_F32, ACT_GELU_TANH, AMODE_PLAIN>(a, stream);   // split-operand mode: fc1 -> fp32
             break;
         case LMI_EPI_SWIGLU:
             if (act == LMI_ACT_NONE) return launch_gemm<T, EPI_SWIGLU_T, ACT_NONE, AMODE_PLAIN>(a, stream);
@@ -615,6 +616,8 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
         return fail(LMI_EINVAL, "%s: norm_out needs the RESIDUAL epilogue, norm_gamma, rowsq_out, ld_norm %% 8 == 0 and no row_map", who);
     if (M == 0) return LMI_OK;
     GemmArgs a;
+    a.swiglu_f32 = 0;
+    if (epilogue == LMI_EPI_SWIGLU_F32) { epilogue = LMI_EPI_SWIGLU; a.swiglu_f32 = 1; }
     a.A = A; a.W = W; a.out = out; a.bias = bias; a.addmat = addmat; a.add_rows = add_rows; a.row_map = row_map;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.add_period = add_period; a.ps_grid = ps_grid; a.group_m = g_gemm_group_m; a.order = g_gemm_order;
     a.norm_out = x.norm_out; a.norm_gamma = x.norm_gamma; a.rowsq_out = x.rowsq_out; a.ld_norm = x.ld_norm;
@@ -772,10 +775,10 @@ int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int
     LMI_DISPATCH_T(out_dtype, dispatch_gemm_fp8<f16_t>(a, epilogue, act, stream), dispatch_gemm_fp8<bf16_t>(a, epilogue, act, stream));
 }
 
-static int attn_varlen_entry(const char* who, const void* q, const void* k, const void* v, void* out, void* out_fp8, int ldo8, float out_fp8_scale,
+static int attn_varlen_entry(const char* who, const void* q, const void* k, const void* v, void* out, float* out_f32, int ldo32, void* out_fp8, int ldo8, float out_fp8_scale,
                              const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                              int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream) {
-    if (!q || !k || !v || (!out && !out_fp8) || !cu_seqlens_q || !cu_seqlens_k) return fail(LMI_EINVAL, "%s: null pointer", who);
+    if (!q || !k || !v || (!out && !out_fp8 && !out_f32) || !cu_seqlens_q || !cu_seqlens_k) return fail(LMI_EINVAL, "%s: null pointer", who);
     if (n_seq < 0 || max_seqlen_q < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads))
         return fail(LMI_EINVAL, "%s: bad head counts (%d, %d)", who, n_heads, n_kv_heads);
     if (head_dim != 128 && head_dim != 96 && head_dim != 72)
@@ -785,10 +788,12 @@ static int attn_varlen_entry(const char* who, const void* q, const void* k, cons
         return fail(LMI_EINVAL, "%s: alignment", who);
     if (out_fp8 && (!use_tr || !g_attn_dma.load() || (ldo8 & 7) || ((uintptr_t)out_fp8 & 7) || !(out_fp8_scale > 0.f)))
         return fail(LMI_EINVAL, "%s: the fp8 output needs the LDS-DMA kernel (use_tr), ldo8 %% 8 == 0, an 8-byte aligned pointer and a positive scale", who);
+    if (out_f32 && (!use_tr || !g_attn_dma.load() || (ldo32 & 3) || !aligned16(out_f32)))
+        return fail(LMI_EINVAL, "%s: the fp32 output needs the LDS-DMA kernel (use_tr), ldo32 %% 4 == 0 and a 16-byte aligned pointer", who);
     if (n_seq == 0 || max_seqlen_q == 0) return LMI_OK;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = nullptr;
-    a.out_fp8 = out_fp8; a.ldo8 = ldo8; a.out_fp8_scale = out_fp8_scale;
+    a.out_fp8 = out_fp8; a.ldo8 = ldo8; a.out_fp8_scale = out_fp8_scale; a.out_f32 = out_f32; a.ldo32 = ldo32;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
     a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr; a.gqa_pack = 0;
     a.check_k_extent = 1;
@@ -811,7 +816,7 @@ int lmi_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, 
                         const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                         int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream) {
     if (!out) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd: null pointer");
-    return attn_varlen_entry("lmi_attn_varlen_fwd", q, k, v, out, nullptr, 0, 0.f, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads, n_kv_heads,
+    return attn_varlen_entry("lmi_attn_varlen_fwd", q, k, v, out, nullptr, 0, nullptr, 0, 0.f, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads, n_kv_heads,
                              head_dim, ldq, ldk, ldv, ldo, scale, causal, window, use_tr, dtype, stream);
 }
 
@@ -819,8 +824,27 @@ int lmi_attn_varlen_fwd_fp8(const void* q, const void* k, const void* v, void* o
                             const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                             int ldq, int ldk, int ldv, float scale, int causal, int window, int dtype, void* stream) {
     if (!out_fp8) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd_fp8: null pointer");
-    return attn_varlen_entry("lmi_attn_varlen_fwd_fp8", q, k, v, nullptr, out_fp8, ldo8, out_scale, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads,
+    return attn_varlen_entry("lmi_attn_varlen_fwd_fp8", q, k, v, nullptr, nullptr, 0, out_fp8, ldo8, out_scale, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads,
                              n_kv_heads, head_dim, ldq, ldk, ldv, 0, scale, causal, window, 1, dtype, stream);
+}
+
+int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* out_f32, int ldo32, const int* cu_seqlens_q,
+                            const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                            int ldq, int ldk, int ldv, float scale, int causal, int window, int dtype, void* stream) {
+    if (!out_f32) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd_f32: null pointer");
+    return attn_varlen_entry("lmi_attn_varlen_fwd_f32", q, k, v, nullptr, out_f32, ldo32, nullptr, 0, 0.f, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q,
+                             n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, 0, scale, causal, window, 1, dtype, stream);
+}
+
+int lmi_split_hi_lo(const float* x, void* out, int M, int K, int ldx, int ldo, int dtype, void* stream) {
+    if (!x || !out || M < 0 || K <= 0 || (K & 7) || (ldx & 3) || (ldo & 7) || ldo < 2 * K || !aligned16(x) || !aligned16(out))
+        return fail(LMI_EINVAL, "lmi_split_hi_lo: bad argument (M=%d K=%d ldx=%d ldo=%d; K %% 8 == 0, ldo >= 2K)", M, K, ldx, ldo);
+    if (M == 0) return LMI_OK;
+    const int grid = grid_for((long)M * (K >> 3), 256);
+    if (dtype == LMI_F16) LMI_LAUNCH((split_hi_lo_kernel<f16_t>), dim3(grid), dim3(256), 0, stream, x, (f16_t*)out, M, K, ldx, ldo);
+    else if (dtype == LMI_BF16) LMI_LAUNCH((split_hi_lo_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, x, (bf16_t*)out, M, K, ldx, ldo);
+    else return fail(LMI_EINVAL, "lmi_split_hi_lo: dtype must be LMI_F16 or LMI_BF16");
+    return check_launch("lmi_split_hi_lo");
 }
 
 int64_t lmi_attn_decode_workspace_bytes(int q_rows, int n_heads, int head_dim, int max_seqlen_k) {
@@ -847,7 +871,7 @@ static int attn_decode_entry(const char* who, const void* q, const void* k, cons
     if (n_seq == 0 || max_seqlen_q == 0 || q_rows == 0) return LMI_OK;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = k_len;
-    a.out_fp8 = nullptr; a.ldo8 = 0; a.out_fp8_scale = 0.f;
+    a.out_fp8 = nullptr; a.ldo8 = 0; a.out_fp8_scale = 0.f; a.out_f32 = nullptr; a.ldo32 = 0;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
     if (((long)max_seqlen_k * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_k * ldv + head_dim) * 2 >= (1L << 32))
         return fail(LMI_EINVAL, "%s: one sequence's K / V rows span >= 4 GiB (max_seqlen_k %d, ldk %d, ldv %d)", who, max_seqlen_k, ldk, ldv);

@@ -469,6 +469,33 @@ __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void*
 }
 
 // ------------------------------------------------------------------------------------------------
+// lmi_split_hi_lo: fp32 [M, K] -> 16-bit [M, 2K] = [ hi | lo ], hi = T(x), lo = T(x - hi).  The "split operand" precision mode
+// (engine.split_operands): a GEMM over the 2K-wide operand against [W | W] computes hi.W + lo.W, i.e. the product of the UNROUNDED
+// activation (to ~2^-22) on the 16-bit matrix pipe — the hand-over rounding that dominates the distance to the fp32 reference is gone.
+// HBM-bound: 4 B in, 4 B out per element.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) split_hi_lo_kernel(const float* x, T* out, int M, int K, int ldx, int ldo) {
+    typedef typename vec_of<T>::x8 T8;
+    const int cpr = K >> 3;
+    const long total = (long)M * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / cpr), c = (int)(i - (long)m * cpr);
+        const float* src = x + (long)m * ldx + c * 8;
+        const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+        T8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (T)a[e]; hi[4 + e] = (T)b[e];
+            lo[e] = (T)sub_rn(a[e], (float)hi[e]); lo[4 + e] = (T)sub_rn(b[e], (float)hi[4 + e]);
+        }
+        T* o = out + (long)m * ldo + c * 8;
+        *(T8*)o = hi;
+        *(T8*)(o + K) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // lmi_debug_copy: grid-stride 16-byte copy on a caller-chosen number of 256-thread workgroups.  Diagnostics only
 // (tools/overlap_probe.py): a stand-in for a collective's transport kernel — few workgroups, no LDS, few registers — to observe
 // whether such a kernel gets CU time beside a GEMM that holds one 128 KiB-LDS workgroup on every CU.

@@ -76,6 +76,7 @@ struct GemmArgs {
     int ld_cache, cache_pos0, rope_q, rope_k;
     // ---- fp8 operands (lmi_gemm_fp8): the accumulators come out multiplied by 2^(scale_e8m0 - 127) (E8M0 block scale of the MFMA,
     // every byte the same), which undoes the power-of-two scales the operands were quantised with
+    int swiglu_f32;              // EPI_SWIGLU_T with an fp32 destination (split-operand precision mode: the product goes to lmi_split_hi_lo)
     int scale_e8m0;
     float out_scale;             // fp8 OUTPUTS (T = fp8_t: GELU / SwiGLU results handed to the next fp8 GEMM): value * out_scale, then e4m3
 };
@@ -362,7 +363,13 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 }
                 if (m < p.M) {
                     const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
-                    *(T8*)((T*)p.out + orow * p.ldo + (nw0 >> 1) + oc) = o;
+                    if (p.swiglu_f32) {                              // wave-uniform: the unrounded products
+                        float* d32 = (float*)p.out + orow * p.ldo + (nw0 >> 1) + oc;
+                        *(f32x4*)d32 = f32x4{fast_silu(g0[0]) * u0[0], fast_silu(g0[1]) * u0[1], fast_silu(g0[2]) * u0[2], fast_silu(g0[3]) * u0[3]};
+                        *(f32x4*)(d32 + 4) = f32x4{fast_silu(g1[0]) * u1[0], fast_silu(g1[1]) * u1[1], fast_silu(g1[2]) * u1[2], fast_silu(g1[3]) * u1[3]};
+                    } else {
+                        *(T8*)((T*)p.out + orow * p.ldo + (nw0 >> 1) + oc) = o;
+                    }
                 }
             }
             wave_lds_fence();

@@ -116,6 +116,10 @@ class LeopardEngine:
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
+        # Split-operand precision mode: every A operand of every ViT / LLM layer linear is handed over as a hi + lo pair of
+        # 16-bit values (lmi_split_hi_lo) and multiplied against [W | W] — the GEMMs run at 2 K, the hand-over roundings that make up the
+        # distance to the fp32 reference are gone (full-depth logits within north_star's 1e-3; ~1.8x the prefill time).  Prefill only.
+        self.split_operands = False
         self.skinny_packed = True      # batched decode: stream the projections from a copy in the MFMA operand order (coalesced 1-KiB loads)
         self.fp8_fused = True          # fp8 schedule: attention writes the fp8 o_proj operand, q|k|v GEMM does RoPE + KV append (False: separate launches)
         self._fp8 = None               # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
@@ -209,6 +213,8 @@ class LeopardEngine:
             self.trace("vit.embed", x)
         if self.fp8 is not None:
             return self._vit_layers_fp8(x, n)
+        if self.split_operands:
+            return self._vit_layers_split(x, n)
         h = self._empty(M, D)
         qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0]) if W.vit_layers else None
         att = self._empty(M, D)
@@ -267,6 +273,82 @@ class LeopardEngine:
         h = self._empty(M, D)
         ops.layernorm(x, W.post_ln_w, W.post_ln_b, h, vc.layer_norm_eps)
         return h
+
+    # ---- split-operand precision mode -------------------------------------------------------------------------------------------
+    def _split_weights(self):
+        """[W | W] copies of the layer-linear weights (K doubled), built on first use: +0.8 GB (SigLIP) + 14 GB (Llama-3.1-8B)."""
+        sw = getattr(self, "_split_w", None)
+        if sw is None:
+            dup = lambda w: torch.cat([w, w], dim=1).contiguous()
+            W = self.W
+            sw = self._split_w = {
+                "vit": [(dup(L.qkv_w), dup(L.o_w), dup(L.fc1_w), dup(L.fc2_w)) for L in W.vit_layers],
+                "llm": [(dup(L.qkv_w_rope if L.qkv_w_rope is not None else L.qkv_w), dup(L.o_w), dup(L.gu_w), dup(L.down_w)) for L in W.llm_layers]}
+        return sw
+
+    def _vit_layers_split(self, x: torch.Tensor, n: int) -> torch.Tensor:
+        """The SigLIP layers with split (hi + lo) A operands: LayerNorm -> fp32 -> [hi | lo]; attention output and GELU output in fp32 ->
+        [hi | lo]; every linear at 2 K against [W | W].  q / k / v and the attention arithmetic stay 16-bit."""
+        ops, W, vc = self.ops, self.W, self.cfg.vision_config
+        T, D, H, hd = vc.num_patches, vc.hidden_size, vc.num_attention_heads, vc.head_dim
+        M = n * T
+        f32 = torch.float32
+        h32, h2 = self._empty(M, D, dtype=f32), self._empty(M, 2 * D)
+        qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0])
+        ff32, ff2 = self._empty(M, W.vit_ff, dtype=f32), self._empty(M, 2 * W.vit_ff)
+        cu = self._vit_cu_cache[n]
+        scale = hd ** -0.5
+        for li, (L, (qkv_w2, o_w2, fc1_w2, fc2_w2)) in enumerate(zip(W.vit_layers, self._split_weights()["vit"])):
+            ops.layernorm(x, L.ln1_w, L.ln1_b, h32, vc.layer_norm_eps)
+            ops.split_hi_lo(h32, h2)
+            ops.gemm(h2, qkv_w2, qkv, bias=L.qkv_b)
+            ops.attention_f32out(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], h32, cu, cu, T, H, H, hd, scale, False)
+            ops.split_hi_lo(h32, h2)
+            ops.gemm(h2, o_w2, x, bias=L.o_b, epilogue=_lib.EPI_RESIDUAL)
+            ops.layernorm(x, L.ln2_w, L.ln2_b, h32, vc.layer_norm_eps)
+            ops.split_hi_lo(h32, h2)
+            ops.gemm(h2, fc1_w2, ff32, bias=L.fc1_b, act=_lib.ACT_GELU_TANH, epilogue=_lib.EPI_STORE_F32)
+            ops.split_hi_lo(ff32, ff2)
+            ops.gemm(ff2, fc2_w2, x, bias=L.fc2_b, epilogue=_lib.EPI_RESIDUAL)
+            if self.trace:
+                self.trace(f"vit.{li}", x)
+        h = self._empty(M, D)
+        ops.layernorm(x, W.post_ln_w, W.post_ln_b, h, vc.layer_norm_eps)
+        return h
+
+    def _llm_layers_split(self, x, cache, cu, cos, sin, max_len):
+        """The Llama / Mistral layers with split (hi + lo) A operands (see _vit_layers_split); q|k|v + RoPE + KV append stay one launch
+        (lmi_rmsnorm_rope on the 2 K operand), the attention hands over fp32."""
+        ops, W, tc = self.ops, self.W, self.cfg.text_config
+        S, D = x.shape
+        (H, KV), hd = self._llm_heads(), tc.head_dim
+        qw, kw = H * hd, KV * hd
+        f32 = torch.float32
+        h32, h2 = self._empty(S, D, dtype=f32), self._empty(S, 2 * D)
+        a32, a2 = (h32, h2) if qw == D else (self._empty(S, qw, dtype=f32), self._empty(S, 2 * qw))
+        qkv = self._empty(S, qw + 2 * kw)
+        gu32, gu2 = self._empty(S, W.llm_ff, dtype=f32), self._empty(S, 2 * W.llm_ff)
+        scale = hd ** -0.5
+        for i, (L, (qkv_w2, o_w2, gu_w2, down_w2)) in enumerate(zip(W.llm_layers, self._split_weights()["llm"])):
+            ops.rmsnorm(x, L.in_norm, h32, tc.rms_norm_eps)
+            ops.split_hi_lo(h32, h2)
+            if L.qkv_w_rope is not None and hd == 128:
+                ops.rmsnorm_rope(h2, qkv_w2, qkv, None, tc.rms_norm_eps, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None,
+                                 0, H, KV, hd)
+            else:
+                ops.gemm(h2, qkv_w2, qkv)
+                ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
+            ops.attention_f32out(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], a32, cu, cu, max_len, H, KV, hd, scale, True,
+                                 window=tc.sliding_window or 0)
+            ops.split_hi_lo(a32, a2)
+            ops.gemm(a2, o_w2, x, epilogue=_lib.EPI_RESIDUAL)
+            ops.rmsnorm(x, L.post_norm, h32, tc.rms_norm_eps)
+            ops.split_hi_lo(h32, h2)
+            ops.gemm(h2, gu_w2, gu32, epilogue=_lib.EPI_SWIGLU_F32)
+            ops.split_hi_lo(gu32, gu2)
+            ops.gemm(gu2, down_w2, x, epilogue=_lib.EPI_RESIDUAL)
+            if self.trace:
+                self.trace(f"llm.{i}", x)
 
     def enable_fp8(self, calibration_samples, headroom: float = 2.0):
         """Switch the ViT / LLM layer linears to fp8 operands (BASELINE configs[4]): quantise the weights once, take the static
@@ -362,8 +444,11 @@ class LeopardEngine:
         max_len = max(int(l) for l in seq_lens)
         if self.trace:
             self.trace("llm.embed", x)
-        if self.fp8 is not None:
-            self._llm_layers_fp8(x, cache, cu, cos, sin, max_len)
+        if self.fp8 is not None or (self.split_operands and self.tp_size == 1):
+            if self.fp8 is not None:
+                self._llm_layers_fp8(x, cache, cu, cos, sin, max_len)
+            else:
+                self._llm_layers_split(x, cache, cu, cos, sin, max_len)
             if cache is not None:
                 cache.length = S
             return self._lm_head(x, last_rows, all_logits)

@@ -284,6 +284,22 @@ class Ops:
                                           epilogue, act, int(scale_exp), dt, float(out_scale), self._stream(out)))
         return out
 
+    def split_hi_lo(self, x_f32, out):
+        """out [M, 2K] (16-bit) = [T(x) | T(x - T(x))] of the fp32 x [M, K] (lmi_split_hi_lo; split-operand precision mode)."""
+        M, K = x_f32.shape
+        assert x_f32.dtype == torch.float32 and out.shape == (M, 2 * K)
+        self._check(self.lib.lmi_split_hi_lo(_ptr(x_f32), _ptr(out), M, K, x_f32.stride(0), out.stride(0), _DT[out.dtype], self._stream(out)))
+        return out
+
+    def attention_f32out(self, q, k, v, out32, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, scale, causal, window=0):
+        """lmi_attn_varlen_fwd_f32: the normalised attention output in fp32 [total_q, n_heads * head_dim]."""
+        n_seq = cu_q.numel() - 1
+        assert out32.dtype == torch.float32
+        self._check(self.lib.lmi_attn_varlen_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out32), out32.stride(0), _ptr(cu_q), _ptr(cu_k), n_seq,
+                                                     int(max_seqlen_q), n_heads, n_kv_heads, head_dim, q.stride(0), k.stride(0), v.stride(0),
+                                                     float(scale), int(bool(causal)), int(window), _DT[q.dtype], self._stream(out32)))
+        return out32
+
     def attention_fp8out(self, q, k, v, out8, out_scale: float, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, scale, causal, window=0):
         """lmi_attn_varlen_fwd_fp8: the attention output written as e4m3(O * out_scale) bytes (uint8 [total_q, n_heads * head_dim])."""
         n_seq = cu_q.numel() - 1

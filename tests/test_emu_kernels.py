@@ -677,3 +677,44 @@ def test_attention_decode_gqa_pack_is_bit_identical_to_head_per_block(ops):
         ref = (torch.softmax((qs[:, None, :] @ ks.transpose(-1, -2)) * hd ** -0.5, -1) @ vs).reshape(-1)
         assert (outs[0][s].float() - ref).abs().max() <= 3e-3
 
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_split_hi_lo_and_fp32_producers(ops, dtype):
+    """lmi_split_hi_lo: [hi | lo] with hi = T(x), lo = T(x - hi) bit for bit; a GEMM over [hi | lo] against [W | W] equals the fp32
+    product to ~2^-19; the fp32 hand-over forms of the producers: attention (lmi_attn_varlen_fwd_f32), fc1 + GELU -> fp32, gate/up -> fp32."""
+    M, K, N = 70, 128, 128
+    x = rnd((M, K), torch.float32, 51)
+    out = torch.zeros(M, 2 * K, dtype=dtype)
+    ops.split_hi_lo(x, out)
+    hi = x.to(dtype)
+    assert torch.equal(out[:, :K], hi) and torch.equal(out[:, K:], (x - hi.float()).to(dtype))
+    w = rnd((N, K), dtype, 52, 0.1)
+    y = torch.zeros(M, N)
+    ops.gemm(out, torch.cat([w, w], dim=1).contiguous(), y, epilogue=_lib.EPI_STORE_F32)
+    ref = x.double() @ w.double().T
+    plain = torch.zeros(M, N)
+    ops.gemm(hi, w, plain, epilogue=_lib.EPI_STORE_F32)
+    e_split, e_plain = (y.double() - ref).abs().max().item(), (plain.double() - ref).abs().max().item()
+    assert e_split <= 0.02 * e_plain + 1e-6, (e_split, e_plain)
+    # fc1 + GELU with an fp32 destination == the 16-bit destination before its rounding
+    g32 = torch.zeros(M, N)
+    ops.gemm(hi, w, g32, act=_lib.ACT_GELU_TANH, epilogue=_lib.EPI_STORE_F32)
+    g16 = torch.zeros(M, N, dtype=dtype)
+    ops.gemm(hi, w, g16, act=_lib.ACT_GELU_TANH)
+    assert torch.equal(g32.to(dtype), g16)
+    # gate/up + SwiGLU with an fp32 destination
+    s32 = torch.zeros(M, N // 2)
+    ops.gemm(hi, w, s32, epilogue=_lib.EPI_SWIGLU_F32)
+    s16 = torch.zeros(M, N // 2, dtype=dtype)
+    ops.gemm(hi, w, s16, epilogue=_lib.EPI_SWIGLU)
+    assert torch.equal(s32.to(dtype), s16)
+    # attention with an fp32 destination
+    H, hd, S = 2, 128, 70
+    qkv = rnd((S, 3 * H * hd), dtype, 53)
+    cu = torch.tensor([0, 30, S], dtype=torch.int32)
+    o16 = torch.zeros(S, H * hd, dtype=dtype)
+    ops.attention(qkv[:, :H * hd], qkv[:, H * hd:2 * H * hd], qkv[:, 2 * H * hd:], o16, cu, cu, 40, H, H, hd, hd ** -0.5, True, True)
+    o32 = torch.zeros(S, H * hd)
+    ops.attention_f32out(qkv[:, :H * hd], qkv[:, H * hd:2 * H * hd], qkv[:, 2 * H * hd:], o32, cu, cu, 40, H, H, hd, hd ** -0.5, True)
+    assert torch.equal(o32.to(dtype), o16)

@@ -51,11 +51,12 @@ def sample_inputs(cfg, n_images, w, h, seed=0):
     return u8, torch.from_numpy(ids).reshape(1, -1), plan
 
 
-def hip_run(cfg, ops, dtype, ids, u8, dev):
+def hip_run(cfg, ops, dtype, ids, u8, dev, split=False):
     from leopard_amd.engine import LeopardEngine
     from leopard_amd.weights import EngineWeights, SynthSource
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
     eng = LeopardEngine(cfg, W, ops=ops, device=dev)
+    eng.split_operands = split
     trace = []
     eng.trace = lambda name, x: trace.append((name, x.detach().float().cpu().clone()))
     res = eng.prefill(ids.to(dev), torch.from_numpy(u8).to(dev))
@@ -88,6 +89,7 @@ def report(name, n_images, w, h, ops, Wt, dev, out, emu_bf16):
     hb, tr_hb = hip_run(cfg, ops, torch.bfloat16, ids, u8, dev)
     runs["HIP fp16"] = (h16, tr_h16)
     runs["HIP bf16"] = (hb, tr_hb)
+    runs["HIP fp16 split operands"] = hip_run(cfg, ops, torch.float16, ids, u8, dev, split=True)
     S = ids.shape[1] + u8.shape[0] * (cfg.tokens_per_tile - 1)
     print(f"\n=== {name}: {n_images} x ({w}x{h}) -> {u8.shape[0]} ViT inputs, S = {S}; 27 + 32 layers, full width; "
           f"fp32 oracle {t_ref:.1f} s on {torch.get_num_threads()} host threads ===", file=out)
@@ -95,6 +97,8 @@ def report(name, n_images, w, h, ops, Wt, dev, out, emu_bf16):
     print("relative RMS error of the fp32 residual stream vs the fp32 oracle, rms(x - x_ref) / rms(x_ref):", file=out)
     print(f"{'after':>10} " + " ".join(f"{c:>24}" for c in cols) + f" {'HIP fp16 vs emulated':>22}", file=out)
     for key in tr_ref:
+        if any(key not in runs[c][1] for c in cols):
+            continue
         row = []
         for c in cols:
             x = runs[c][1][key]
