@@ -17,6 +17,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from .checkpoint import CheckpointSource, load_config
@@ -64,6 +66,9 @@ class LeopardForConditionalGeneration:
             ops = self._ops if self._ops is not None else Ops()
             W = EngineWeights.build(self.config, self._source_factory(device, self.compute_dtype), self.compute_dtype)
             self._engine = LeopardEngine(self.config, W, ops=ops, device=device)
+            # LEOPARD_AMD_PRECISION=split: the split-operand precision mode for the prefill (full-depth logits within 1e-3 of the fp32
+            # arithmetic the reference script asks for with torch_dtype=torch.float32, at ~1.8x the prefill time); default: the fast schedule
+            self._engine.split_operands = os.environ.get("LEOPARD_AMD_PRECISION", "").lower() == "split"
             self.device = device
         return self
 

@@ -30,7 +30,8 @@ Precision: EVAL:373 asks for ``torch_dtype=torch.float32``; the engine computes 
 accumulation and fp32 residual streams (``LEOPARD_AMD_COMPUTE_DTYPE`` = f16 (default) | bf16).  That narrowing is NOT silent: every
 ``from_pretrained`` emits a ``UserWarning`` when the requested and the compute type differ and records both in
 ``leopard_amd_run_info.json`` in the working directory — next to the shard files ``results_*`` the script writes — so that a result
-row can always be traced to the arithmetic that produced it.
+row can always be traced to the arithmetic that produced it.  ``LEOPARD_AMD_PRECISION=split`` selects the split-operand precision
+mode for the prefill (every layer-linear operand as a hi + lo pair of 16-bit values: full-depth logits within 1e-3 of fp32, ~1.8x the time).
 
 Smoke-run knobs (GPU-less containers / CI only; the product path needs none of them):
     LEOPARD_AMD_LIB             alternative C-ABI library (the CPU kernel-logic emulator build); implies host tensors
@@ -78,7 +79,8 @@ def _record_run_info(model_class: str, checkpoint: str, requested, compute) -> N
         warnings.warn(f"{model_class}.from_pretrained: torch_dtype={req} was requested; leopard_amd computes with {cmp_} MFMA operands "
                       f"(fp32 accumulation, fp32 residual streams) — recorded in leopard_amd_run_info.json", UserWarning, stacklevel=3)
     info = {"model_class": model_class, "checkpoint": str(checkpoint), "requested_torch_dtype": req, "compute_dtype": cmp_,
-            "accumulate_dtype": "float32", "residual_stream_dtype": "float32", "library": os.environ.get("LEOPARD_AMD_LIB") or "libleopard_amd.so",
+            "accumulate_dtype": "float32", "residual_stream_dtype": "float32",
+            "precision_mode": "split operands (hi + lo 16-bit pairs, GEMMs at 2 K)" if os.environ.get("LEOPARD_AMD_PRECISION", "").lower() == "split" else "fast", "library": os.environ.get("LEOPARD_AMD_LIB") or "libleopard_amd.so",
             "fallback_scorers": sorted(_FALLBACK_SCORERS)}
     try:
         with open("leopard_amd_run_info.json", "w") as f:
