@@ -223,6 +223,36 @@ def _fp8_calibration(cfg):
     return [(ids.to(DEV), torch.from_numpy(u8).to(DEV))]
 
 
+def test_configs4_combination_fp8_packed_batch_graph_encode(ops):
+    """BASELINE configs[4] as ONE combination (fp8 linears x several samples packed in one pass x HIP-graph-captured encode), at the mid
+    depth: prefill_batch under an fp8 plan with graph_encode on gives, per sample, exactly the logits of that sample's own fp8 prefill
+    (kernels are row-independent: packing and graph replay change no bit), the encode really is replayed from a graph, and the batch
+    path takes the fused fp8 hand-overs (no conversion / RoPE launches)."""
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    eng.enable_fp8(_fp8_calibration(cfg))
+    samples = []
+    for n, w, h, seed in [(2, 1344, 896, 21), (1, 800, 500, 22), (3, 700, 700, 23)]:
+        u8, ids, _ = sample_inputs(cfg, n, w, h, seed=seed)
+        samples.append((ids, torch.from_numpy(u8).to(DEV)))
+    singles = [eng.prefill(ids, tiles).logits_last.clone() for ids, tiles in samples]
+    calls = []
+    for name in ("quantize_fp8", "rope_qk", "attention_fp8out", "rope_qkv_fp8"):
+        fn = getattr(ops, name)
+        setattr(ops, name, (lambda f, n_: (lambda *a, **k: (calls.append(n_), f(*a, **k))[1]))(fn, name))
+    try:
+        eng.graph_encode = True
+        for rep in range(2):                                        # capture, then replay
+            logits, seq_lens = eng.prefill_batch(samples)
+            for j, one in enumerate(singles):
+                assert torch.equal(logits[j], one), (rep, j)
+        assert len(eng._encode_graphs) == 1 and torch.isfinite(logits).all()
+        assert "rope_qkv_fp8" in calls and "attention_fp8out" in calls and "quantize_fp8" not in calls and "rope_qk" not in calls
+    finally:
+        for name in ("quantize_fp8", "rope_qk", "attention_fp8out", "rope_qkv_fp8"):
+            delattr(ops, name)
+
+
 def test_mid_config_fp8_vs_oracle(ops, mid_oracle):
     """2 + 2 layers at full width with fp8 linears: the logits sit where the oracle that rounds the same operands (activations AND
     weights) to e4m3 says they must — fp8 is a reduced-precision line of its own (never the 1e-3 headline), so what is asserted is
