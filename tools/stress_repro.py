@@ -42,4 +42,21 @@ for r in range(reps):
         if not same:
             print(f"rep {r}: MISMATCH max|d| prefill {float((ref - res.logits_last).abs().max()):.3e}")
 print(f"{'fp8' if fp8 else 'f16'} schedule: {reps} repetitions, {bad} mismatches")
+# batched decode (pooled KV slots, skinny-M projections, one captured step per token for the batch): same tokens and same final logits
+# every time
+if not fp8:
+    samples = []
+    for j, n in enumerate((1, 2, 1, 3)):
+        t, pl = GpuTiler(ops, dev).tile_sample([synth_image_u8(40 + 10 * j + i, 700, 500) for i in range(n)])
+        samples.append((torch.from_numpy(synth_prompt_ids(pl.vit_inputs_per_image, cfg, seed=30 + j)).reshape(1, -1), t))
+    ref_b, ref_l, bad_b = None, None, 0
+    for r in range(max(2, reps // 5)):
+        outs = eng.generate_batch(samples, max_new_tokens=8, eos_token_id=())
+        lg = eng._batch_states[len(samples)].logits.clone()
+        if ref_b is None:
+            ref_b, ref_l = outs, lg
+        elif not (all(torch.equal(a, b) for a, b in zip(ref_b, outs)) and torch.equal(ref_l, lg)):
+            bad_b += 1
+    print(f"batched decode (4 samples x 8 tokens): {max(2, reps // 5)} repetitions, {bad_b} mismatches")
+    bad += bad_b
 sys.exit(1 if bad else 0)
