@@ -283,6 +283,13 @@ int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, 
 int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed, int dtype,
                     void* stream);
 
+/* Batched decode: the q | k | v projection as lmi_gemm_skinny with RoPE and the KV append in its epilogue (W rows in
+ * weights.rope_permute_rows order, optionally packed): row m rotates at position pos_rows_dev[m] and appends K / V to row
+ * m * cache_stride + pos_rows_dev[m] of the pooled caches — lmi_gemm_skinny + lmi_rope_qk_rows in one launch. */
+int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
+                        int ldo, int packed, const float* cos_all, const float* sin_all, void* k_cache, void* v_cache, int ld_cache,
+                        int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream);
+
 /* Same with the RMSNorm of the decode step folded in: x is the fp32 residual row [K], norm_weight fp32 [K], and the row
  * fed to the product is T(norm_weight * (x * rsqrt(mean(x^2) + eps))) — the arithmetic of lmi_rmsnorm, without its launch.
  * K = 4096 (the hidden size of Llama-3.1-8B / Mistral-7B). */

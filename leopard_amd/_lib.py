@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libleopard_amd.so")
+# LEOPARD_AMD_LIB: another build of the same library (A/B of a compile-time kernel variant on one box); default = the in-tree build
+LIB_PATH = os.environ.get("LEOPARD_AMD_LIB") or os.path.join(_HERE, "libleopard_amd.so")
 
 LMI_F16, LMI_BF16, LMI_F32, LMI_FP8 = 0, 1, 2, 3
 EPI_STORE, EPI_RESIDUAL, EPI_STORE_F32, EPI_SWIGLU, EPI_QKV_ROPE, EPI_SWIGLU_F32 = 0, 1, 2, 3, 4, 5
@@ -52,6 +53,7 @@ SIGNATURES = {
     "lmi_rope_qkv_fp8": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_split_hi_lo": [_P, _P, _I, _I, _I, _I, _I, _P],
     "lmi_attn_varlen_fwd_f32": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
+    "lmi_rope_qkv_skinny": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, C.c_int64, _P, _I, _P],
     "lmi_debug_copy": [_P, _P, C.c_int64, _I, _P],
     "lmi_gemm_skinny": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_lm_head_last": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P],

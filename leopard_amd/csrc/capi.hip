@@ -324,6 +324,11 @@ int norm_impl(const float* x, const float* w, const float* b, void* out, int M, 
         !aligned16(x) || !aligned16(w) || !aligned16(out))
         return fail(LMI_EINVAL, "%s: bad argument (M=%d D=%d ldx=%d ldo=%d; D%%8==0, D<=4096)", what, M, D, ldx, ldo);
     if (M == 0) return LMI_OK;
+    if (M <= 32) {                                                  // a handful of rows (decode): one workgroup per row (norm_rows_kernel)
+        if (D <= 2048) LMI_LAUNCH((norm_rows_kernel<T, RMS, 1>), dim3(M), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps, out_scale);
+        else LMI_LAUNCH((norm_rows_kernel<T, RMS, 2>), dim3(M), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps, out_scale);
+        return check_launch(what);
+    }
     const int grid = (M + 3) / 4;
     if (D <= 1536) LMI_LAUNCH((norm_kernel<T, RMS, 3>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps, out_scale);
     else LMI_LAUNCH((norm_kernel<T, RMS, 8>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps, out_scale);
@@ -415,14 +420,18 @@ int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, in
 }
 
 template <typename T, bool PACKED>
-int skinny_impl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, void* stream) {
-    const int units = (epilogue == LMI_SKINNY_SWIGLU) ? N / 32 : N / 16;
+int skinny_impl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, void* stream,
+                const SkinnyRope& rp = SkinnyRope()) {
+    const int units = (epilogue == LMI_SKINNY_SWIGLU || epilogue == 4) ? N / 32 : N / 16;
+#define LMI_SK(E) LMI_LAUNCH((skinny_gemm_kernel<T, E, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo, rp)
     switch (epilogue) {
-        case LMI_SKINNY_STORE: LMI_LAUNCH((skinny_gemm_kernel<T, SK_STORE_T, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
-        case LMI_SKINNY_RESIDUAL: LMI_LAUNCH((skinny_gemm_kernel<T, SK_RESID_F32, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
-        case LMI_SKINNY_SWIGLU: LMI_LAUNCH((skinny_gemm_kernel<T, SK_SWIGLU_T, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
-        default: LMI_LAUNCH((skinny_gemm_kernel<T, SK_STORE_F32, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo); break;
+        case LMI_SKINNY_STORE: LMI_SK(SK_STORE_T); break;
+        case LMI_SKINNY_RESIDUAL: LMI_SK(SK_RESID_F32); break;
+        case LMI_SKINNY_SWIGLU: LMI_SK(SK_SWIGLU_T); break;
+        case 4: LMI_SK(SK_QKV_ROPE_T); break;                        // lmi_rope_qkv_skinny only
+        default: LMI_SK(SK_STORE_F32); break;
     }
+#undef LMI_SK
     return check_launch("lmi_gemm_skinny");
 }
 
@@ -916,6 +925,26 @@ int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K
                        (skinny_impl<bf16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)));
     LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)),
                    (skinny_impl<bf16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)));
+}
+
+int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
+                        int ldo, int packed, const float* cos_all, const float* sin_all, void* k_cache, void* v_cache, int ld_cache,
+                        int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream) {
+    if (!Wqkv_rope || !X || !qkv || !cos_all || !sin_all || !k_cache || !v_cache || !pos_rows_dev) return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: null pointer");
+    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: head_dim %d (only 128)", head_dim);
+    const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
+    if (M < 0 || M > 16 || n_q_heads <= 0 || n_kv_heads <= 0 || K <= 0 || (K % 128) || (ldw & 7) || (ldx & 7) || ldw < K || ldx < K || (packed && ldw != K) ||
+        (ld_cache & 7) || cache_stride <= 0 || ldo < N || !aligned16(Wqkv_rope) || !aligned16(X))
+        return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: bad argument (M <= 16, K %% 128 == 0, 16-byte aligned rows)");
+    if (M == 0) return LMI_OK;
+    SkinnyRope rp;
+    rp.cos_all = cos_all; rp.sin_all = sin_all; rp.pos = pos_rows_dev; rp.k_cache = k_cache; rp.v_cache = v_cache; rp.ld_cache = ld_cache;
+    rp.cache_stride = (long)cache_stride; rp.rope_q = n_q_heads * head_dim; rp.rope_k = n_kv_heads * head_dim;
+    if (packed)
+        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, true>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp)),
+                       (skinny_impl<bf16_t, true>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp)));
+    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp)),
+                   (skinny_impl<bf16_t, false>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp)));
 }
 
 int lmi_rope_qk_rows(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all, const float* sin_all,

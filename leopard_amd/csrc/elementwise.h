@@ -186,6 +186,89 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same norms for a HANDFUL of rows (decode: 1 .. 16 rows): one 256-thread workgroup per row instead of one wave, so that a row's
+// 16 KiB arrive through 4 waves' worth of loads in flight (the one-wave form is latency-bound at ~7.6 us for 8 rows; the batched decode
+// step runs 64 of them).  Statistics: per-lane partial -> wave butterfly -> 4 wave sums added in wave order (deterministic).
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool RMS, int MAXV>     // MAXV = max 8-element chunks per thread (D <= MAXV * 2048)
+__global__ void __launch_bounds__(256) norm_rows_kernel(const float* x, const float* w, const float* b, T* out,
+                                                        int M, int D, int ldx, int ldo, float eps, float out_scale) {
+    typedef typename vec_of<T>::x8 T8;
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    const float* xr = x + (long)row * ldx;
+    const int nvec = D >> 3;
+    f32x4 v[MAXV][2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + tid;
+        if (c < nvec) {
+            v[i][0] = *(const f32x4*)(xr + c * 8);
+            v[i][1] = *(const f32x4*)(xr + c * 8 + 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                s += RMS ? (v[i][h][0] * v[i][h][0] + v[i][h][1] * v[i][h][1] + v[i][h][2] * v[i][h][2] + v[i][h][3] * v[i][h][3])
+                         : (v[i][h][0] + v[i][h][1] + v[i][h][2] + v[i][h][3]);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = 1.0f / sqrtf(s / (float)D + eps);
+    } else {
+        mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = i * 256 + tid;
+            if (c < nvec) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[i][h][e] - mean; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        if (lane == 0) red[1][wave] = q;
+        __syncthreads();
+        q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        rstd = 1.0f / sqrtf(q / (float)D + eps);
+    }
+    T* orow = out + (long)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + tid;
+        if (c < nvec) {
+            T8 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 ww = *(const f32x4*)(w + c * 8 + 4 * h);
+                if (RMS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = ww[e] * (v[i][h][e] * rstd);
+                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);
+                    }
+                } else {
+                    const f32x4 bb = *(const f32x4*)(b + c * 8 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = (v[i][h][e] - mean) * rstd * ww[e] + bb[e];
+                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);
+                    }
+                }
+            }
+            *(T8*)(orow + c * 8) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sequence-parallel residual update (tensor-parallel LLM): x[row] += delta[row] (the reduce-scattered partial
 // products of o_proj / down_proj, 16-bit or fp32), x written back, then out[row] = w * (x * rstd) as norm_kernel<RMS> does.
 // out == nullptr: the add only.  One wave per row, row in registers.
@@ -344,7 +427,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const T* W, const T* x, const
         for (int i = 0; i < KCH; ++i) {
             const int c = i * 64 + lane;
             if (c * 8 < K) {
-                const T8 wv = *(const T8*)(wrow + c * 8);
+                const T8 wv = ld_stream((const T8*)(wrow + c * 8));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc += (float)wv[e] * (float)xv[i][e];
             }
@@ -435,7 +518,7 @@ __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void*
             const int u = imin(ub + r / RW, units - 1);
             const T* wrow = W + (long)row_of(u, r % RW) * ldw;
 #pragma unroll
-            for (int i = 0; i < CPW; ++i) wv[r][i] = *(const T8*)(wrow + ((wave * CPW + i) * 64 + lane) * 8);
+            for (int i = 0; i < CPW; ++i) wv[r][i] = ld_stream((const T8*)(wrow + ((wave * CPW + i) * 64 + lane) * 8));
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -569,7 +652,7 @@ __global__ void __launch_bounds__(256) lm_head_rows_kernel(const T* W, const flo
             const f32x4 x0 = *(const f32x4*)(xs + c), x1 = *(const f32x4*)(xs + c + 4);
             T8 wv[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) wv[r] = *(const T8*)(W + (long)imin(nb + r, N - 1) * ldw + c);
+            for (int r = 0; r < R; ++r) wv[r] = ld_stream((const T8*)(W + (long)imin(nb + r, N - 1) * ldw + c));
 #pragma unroll
             for (int r = 0; r < R; ++r) {
 #pragma unroll

@@ -379,6 +379,19 @@ inline float sub_rn(float a, float b) { return a - b; }
 // ------------------------------------------------------------------------------------------------
 // shared helpers
 // ------------------------------------------------------------------------------------------------
+// One-shot streamed operand (a decode step's weights: every byte is read once by one CU): non-temporal policy, so that the stream
+// does not push the activations / partial slabs the next launches re-read out of L2 / MALL.  LMI_STREAM_NT=0 builds the default policy
+// (A/B only).
+#ifndef LMI_STREAM_NT
+#define LMI_STREAM_NT 1
+#endif
+template <typename V> LMI_DEV V ld_stream(const V* p) {
+#if !defined(LMI_EMU) && LMI_STREAM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 LMI_DEV int imin(int a, int b) { return a < b ? a : b; }
 LMI_DEV int imax(int a, int b) { return a > b ? a : b; }
 template <typename T> LMI_DEV float to_f32(T v) { return (float)v; }

@@ -22,20 +22,37 @@
 
 namespace lmi {
 
-enum { SK_STORE_T = 0, SK_RESID_F32 = 1, SK_SWIGLU_T = 2, SK_STORE_F32 = 3 };
+enum { SK_STORE_T = 0, SK_RESID_F32 = 1, SK_SWIGLU_T = 2, SK_STORE_F32 = 3, SK_QKV_ROPE_T = 4 };
+
+// SK_QKV_ROPE_T: the q | k | v projection of a batched decode step with RoPE and the KV append in the epilogue.  W rows in
+// weights.rope_permute_rows order (q / k heads stored as d = [0..31, 64..95, 32..63, 96..127]), so that the two 16-row blocks a workgroup
+// owns — rows r and r + 32 of a 64-row group, exactly the SwiGLU pairing — hold first-half elements and their rotate-half partners.
+// Row m of the batch rotates at its own position pos[m] (device memory) and appends K / V to row m * cache_stride + pos[m] of the pooled
+// caches; v rows (natural order) are two independent blocks.
+struct SkinnyRope {
+    const float* cos_all;     // [capacity, 64]
+    const float* sin_all;
+    const int* pos;           // [M]
+    void* k_cache;
+    void* v_cache;
+    int ld_cache;
+    long cache_stride;
+    int rope_q, rope_k;       // columns [0, rope_q) are q heads, [rope_q, rope_q + rope_k) k heads, the rest v
+};
 
 template <typename T, int EPI, bool PACKED>
-__global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo) {
+__global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, SkinnyRope rp) {
     typedef typename vec_of<T>::x8 T8;
-    constexpr int NW = (EPI == SK_SWIGLU_T) ? 2 : 1;               // weight row blocks per workgroup (gate, up)
-    constexpr int DEPTH = (EPI == SK_SWIGLU_T) ? 2 : 3;            // k-steps of loads in flight per wave (<= 128 VGPRs: two workgroups per CU)
+    constexpr bool PAIR = (EPI == SK_SWIGLU_T || EPI == SK_QKV_ROPE_T);
+    constexpr int NW = PAIR ? 2 : 1;                               // weight row blocks per workgroup (gate, up / first half, rotate-half partner)
+    constexpr int DEPTH = PAIR ? 2 : 3;                            // k-steps of loads in flight per wave (<= 128 VGPRs: two workgroups per CU)
     __shared__ float part[8][NW][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 15, g = lane >> 4;
     const int unit = blockIdx.x;
     // first weight row of block b: plain = 16 rows per unit; SwiGLU = unit u -> 64-row group u >> 1, half u & 1: gate rows at +16 * half,
     // their up partners 32 rows further
-    const int row0 = (EPI == SK_SWIGLU_T) ? (unit >> 1) * 64 + (unit & 1) * 16 : unit * 16;
+    const int row0 = PAIR ? (unit >> 1) * 64 + (unit & 1) * 16 : unit * 16;
     const int nsteps_all = K >> 7;
     const T* wrow[NW];
 #pragma unroll
@@ -53,7 +70,7 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
         for (int b = 0; b < NW; ++b)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                wv[slot][b][c] = PACKED ? *(const T8*)(wrow[b] + (long)(wave + 8 * s) * 2048 + c * 512) : *(const T8*)(wrow[b] + k0 + 32 * c);
+                wv[slot][b][c] = ld_stream(PACKED ? (const T8*)(wrow[b] + (long)(wave + 8 * s) * 2048 + c * 512) : (const T8*)(wrow[b] + k0 + 32 * c));
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (has_x) xv[slot][c] = *(const T8*)(xrow + k0 + 32 * c);
@@ -98,7 +115,33 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
             v[b] = s;
         }
         if (m < M) {
-            if (EPI == SK_SWIGLU_T) {
+            if (EPI == SK_QKV_ROPE_T) {
+                const int c1 = row0 + n, c2 = c1 + 32;              // the two columns (in W's row order) this thread finishes
+                T* orow = (T*)out + (long)m * ldo;
+                const int p = rp.pos[m];
+                const long crow = (long)m * rp.cache_stride + p;
+                if (c1 >= rp.rope_q + rp.rope_k) {                   // v: natural order, two plain values
+                    const int vc = rp.rope_q + rp.rope_k;
+                    orow[c1] = (T)v[0];
+                    orow[c2] = (T)v[1];
+                    T* vrow = (T*)rp.v_cache + crow * rp.ld_cache - vc;
+                    vrow[c1] = (T)v[0];
+                    vrow[c2] = (T)v[1];
+                } else {                                             // q / k: rotate-half on the fp32 sums, natural order on store
+                    const int hbase = c1 & ~127, j = c1 & 127;       // j in [0, 32) or [64, 96): position in the permuted head
+                    const int d1 = (j >> 6) * 32 + (j & 31);         // first-half element 0..63; partner d1 + 64
+                    const float cs = rp.cos_all[(long)p * 64 + d1], sn = rp.sin_all[(long)p * 64 + d1];
+                    const T o1 = (T)__builtin_fmaf(v[0], cs, -mul_rn(v[1], sn));
+                    const T o2 = (T)__builtin_fmaf(v[1], cs, mul_rn(v[0], sn));
+                    orow[hbase + d1] = o1;
+                    orow[hbase + d1 + 64] = o2;
+                    if (c1 >= rp.rope_q) {
+                        T* krow = (T*)rp.k_cache + crow * rp.ld_cache - rp.rope_q;
+                        krow[hbase + d1] = o1;
+                        krow[hbase + d1 + 64] = o2;
+                    }
+                }
+            } else if (EPI == SK_SWIGLU_T) {
                 const float gt = v[0], up = v[NW - 1];
                 ((T*)out)[(long)m * ldo + (unit >> 1) * 32 + (unit & 1) * 16 + n] = (T)(gt / (1.0f + fexp(-gt)) * up);
             } else if (EPI == SK_STORE_T) {

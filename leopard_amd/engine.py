@@ -992,8 +992,10 @@ class LeopardEngine:
         if pk is None:
             from .weights import skinny_pack
             W = self.W
-            pk = self._skinny_pack = {"layers": [(skinny_pack(L.qkv_w), skinny_pack(L.o_w), skinny_pack(L.gu_w), skinny_pack(L.down_w))
-                                                 for L in W.llm_layers], "head": skinny_pack(W.lm_head)}
+            # q|k|v: the rope-permuted rows when they exist (RoPE + KV append then ride in the projection's epilogue: lmi_rope_qkv_skinny)
+            pk = self._skinny_pack = {"layers": [(skinny_pack(L.qkv_w_rope if L.qkv_w_rope is not None else L.qkv_w), skinny_pack(L.o_w),
+                                                  skinny_pack(L.gu_w), skinny_pack(L.down_w)) for L in W.llm_layers],
+                                      "head": skinny_pack(W.lm_head)}
         return pk
 
     def _batch_decode_body(self, st):
@@ -1004,11 +1006,15 @@ class LeopardEngine:
         ops.embed_merge(st.tok, st.src, W.embed, None, st.x)
         pk = self._skinny_weights() if self.skinny_packed else None
         for i, L in enumerate(W.llm_layers):
-            qkv_w, o_w, gu_w, down_w = pk["layers"][i] if pk else (L.qkv_w, L.o_w, L.gu_w, L.down_w)
+            rope_fused = L.qkv_w_rope is not None and hd == 128
+            qkv_w, o_w, gu_w, down_w = pk["layers"][i] if pk else (L.qkv_w_rope if rope_fused else L.qkv_w, L.o_w, L.gu_w, L.down_w)
             packed = pk is not None
             ops.rmsnorm(st.x, L.in_norm, st.h, eps)
-            ops.gemm_skinny(qkv_w, st.h, st.qkv, 0, packed)
-            ops.rope_qk_rows(st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos)
+            if rope_fused:
+                ops.rope_qkv_skinny(qkv_w, st.h, st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos, packed)
+            else:
+                ops.gemm_skinny(qkv_w, st.h, st.qkv, 0, packed)
+                ops.rope_qk_rows(st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos)
             ops.attention_decode_pool(st.qkv[:, :qw], st.k[i], st.v[i], st.att, st.cu_q, st.k_begin, st.k_len, st.capacity, H, KV, hd,
                                       hd ** -0.5, st.ws, window=tc.sliding_window or 0)
             ops.gemm_skinny(o_w, st.att, st.x, 1, packed)

@@ -177,6 +177,14 @@ class Ops:
                                              int(bool(packed)), _DT[w.dtype], self._stream(out)))
         return out
 
+    def rope_qkv_skinny(self, w_rope, x, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, cache_stride, pos_rows, packed=False):
+        """lmi_rope_qkv_skinny: batched-decode q|k|v projection with RoPE + KV append in the epilogue (w_rope in rope_permute_rows order)."""
+        M, K = x.shape[0], w_rope.shape[1]
+        self._check(self.lib.lmi_rope_qkv_skinny(_ptr(w_rope), _ptr(x), _ptr(qkv), M, n_q_heads, n_kv_heads, head_dim, K, w_rope.stride(0), x.stride(0),
+                                                 qkv.stride(0), int(bool(packed)), _ptr(cos_all), _ptr(sin_all), _ptr(k_cache), _ptr(v_cache),
+                                                 k_cache.stride(0), int(cache_stride), _ptr(pos_rows), _DT[w_rope.dtype], self._stream(qkv)))
+        return qkv
+
     def decode_workspace_elems(self, q_rows, n_heads, head_dim, max_seqlen_k) -> int:
         n = int(self.lib.lmi_attn_decode_workspace_bytes(q_rows, n_heads, head_dim, max_seqlen_k))
         if n < 0:

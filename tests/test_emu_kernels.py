@@ -630,6 +630,65 @@ def test_rope_rows_equals_rope_at_per_row(ops):
         assert torch.equal(kp[s * cap:(s + 1) * cap], kc) and torch.equal(vp[s * cap:(s + 1) * cap], vc)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_rope_qkv_skinny_equals_projection_then_rope_rows(ops, packed):
+    """lmi_rope_qkv_skinny (q|k|v projection with RoPE + KV append in the epilogue, rope-permuted weight rows) vs the fp32 statement
+    of projection -> rotate-half RoPE at each row's own position; the V columns and the pooled caches; within one 16-bit rounding
+    of lmi_gemm_skinny + lmi_rope_qk_rows (which rounds the projection before rotating)."""
+    from leopard_amd.weights import rope_permute_rows, skinny_pack
+    dtype, H, KV, hd, cap, B, K = torch.float16, 2, 1, 128, 12, 3, 384
+    w, x = rnd(((H + 2 * KV) * hd, K), dtype, 7, 0.1), rnd((B, K), dtype, 8)
+    f = torch.arange(cap).float().reshape(-1, 1) * (1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    pos = torch.tensor([4, 0, 11], dtype=torch.int32)
+    w_rope = torch.cat([rope_permute_rows(w[:(H + KV) * hd]), w[(H + KV) * hd:]]).contiguous()
+    kp, vp = torch.zeros(B * cap, KV * hd, dtype=dtype), torch.zeros(B * cap, KV * hd, dtype=dtype)
+    got = torch.full((B + 1, (H + 2 * KV) * hd), 7.0, dtype=dtype)
+    ops.rope_qkv_skinny(skinny_pack(w_rope) if packed else w_rope, x, got[:B], H, KV, hd, cos, sin, kp, vp, cap, pos, packed=packed)
+    assert bool((got[B] == 7.0).all())
+    lin = x.float() @ w.float().T
+    ref = lin.clone()
+    for s in range(B):
+        c, sn = cos[pos[s]], sin[pos[s]]
+        for h in range(H + KV):
+            a, b = lin[s, h * hd:h * hd + 64], lin[s, h * hd + 64:(h + 1) * hd]
+            ref[s, h * hd:h * hd + 64] = a * c - b * sn
+            ref[s, h * hd + 64:(h + 1) * hd] = b * c + a * sn
+    t = tol(dtype) * max(1.0, ref.abs().max().item())
+    assert (got[:B].float() - ref).abs().max() <= t
+    two = torch.zeros(B, (H + 2 * KV) * hd, dtype=dtype)
+    k2, v2 = torch.zeros_like(kp), torch.zeros_like(vp)
+    ops.gemm_skinny(w, x, two, 0)
+    ops.rope_qk_rows(two, H, KV, hd, cos, sin, k2, v2, cap, pos)
+    assert (got[:B].float() - two.float()).abs().max() <= 2 * t
+    assert torch.equal(got[:B, (H + KV) * hd:], two[:, (H + KV) * hd:])                # V: no rotation, the same rounding
+    for s in range(B):
+        r = s * cap + int(pos[s])
+        assert torch.equal(kp[r], got[s, H * hd:(H + KV) * hd]) and torch.equal(vp[r], got[s, (H + KV) * hd:])
+    touched = torch.zeros(B * cap, dtype=torch.bool)
+    touched[[s * cap + int(pos[s]) for s in range(B)]] = True
+    assert not kp[~touched].any() and not vp[~touched].any()
+
+
+@pytest.mark.parametrize("rms", [True, False])
+@pytest.mark.parametrize("M,D", [(1, 1152), (3, 4096), (32, 256), (33, 4096)])
+def test_norm_small_m_rows_kernel(ops, rms, M, D):
+    """RMSNorm / LayerNorm with a handful of rows (M <= 32: one workgroup per row, norm_rows_kernel) and just above (one wave per row)
+    vs fp64; rows >= M untouched."""
+    dtype = torch.float16
+    x, g, b = rnd((M, D), torch.float32, 1, 2.0) + 0.3, rnd((D,), torch.float32, 2) + 1.0, rnd((D,), torch.float32, 3)
+    out = torch.full((M + 1, D), 7.0, dtype=dtype)
+    xd = x.double()
+    if rms:
+        ops.rmsnorm(x, g, out[:M], 1e-5)
+        ref = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-5) * g.double()
+    else:
+        ops.layernorm(x, g, b, out[:M], 1e-6)
+        ref = torch.nn.functional.layer_norm(xd, (D,), g.double(), b.double(), 1e-6)
+    assert (out[:M].double() - ref).abs().max() <= tol(dtype) * max(1.0, ref.abs().max().item())
+    assert bool((out[M] == 7.0).all())
+
+
 def test_attention_decode_pool_equals_per_sequence_decode(ops):
     """lmi_attn_decode_pool (B sequences in slots of one pooled cache, lengths in a device array) == lmi_attn_decode_fwd per sequence."""
     dtype, H, KV, hd, cap = torch.float16, 4, 2, 128, 200

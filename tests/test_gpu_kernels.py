@@ -375,6 +375,59 @@ def test_gemm_skinny_llama_decode_shapes(ops, dtype, M):
         check(outs[0], ref, dtype if epi in (0, 2) else torch.float16, k=4.0, what=f"skinny {name} M={M}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 8, 16])
+def test_rope_qkv_skinny_llama_shape(ops, dtype, M):
+    """lmi_rope_qkv_skinny at the Llama-3.1-8B decode shape (32 + 8 + 8 heads of 128, K = 4096, C3-sized cache slots): vs fp32 on the
+    device, packed == row-major weights bit for bit, K / V rows land in slot m at pos[m] and nowhere else."""
+    from leopard_amd.weights import rope_permute_rows, skinny_pack
+    H, KV, hd, K, cap = 32, 8, 128, 4096, 7424
+    w, x = rnd(((H + 2 * KV) * hd, K), dtype, 31, 0.02), rnd((M, K), dtype, 32)
+    f = torch.arange(cap, device=DEV).float().reshape(-1, 1) * (1.0 / (500000.0 ** (torch.arange(0, hd, 2, device=DEV).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    pos = ((torch.arange(M, dtype=torch.int64) * 977 + 7186) % cap).to(torch.int32).to(DEV)
+    w_rope = torch.cat([rope_permute_rows(w[:(H + KV) * hd]), w[(H + KV) * hd:]]).contiguous()
+    wp = skinny_pack(w_rope)
+    res = []
+    for packed in (False, True):
+        kp, vp = torch.zeros(M * cap, KV * hd, dtype=dtype, device=DEV), torch.zeros(M * cap, KV * hd, dtype=dtype, device=DEV)
+        got = torch.zeros(M, (H + 2 * KV) * hd, dtype=dtype, device=DEV)
+        ops.rope_qkv_skinny(wp if packed else w_rope, x, got, H, KV, hd, cos, sin, kp, vp, cap, pos, packed=packed)
+        res.append((got, kp, vp))
+    torch.cuda.synchronize()
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    got, kp, vp = res[0]
+    lin = (x.float() @ w.float().T).view(M, H + 2 * KV, hd)
+    c, sn = cos[pos.long()].unsqueeze(1), sin[pos.long()].unsqueeze(1)
+    ref = lin.clone()
+    a, b = lin[:, :H + KV, :64], lin[:, :H + KV, 64:]
+    ref[:, :H + KV, :64] = a * c - b * sn
+    ref[:, :H + KV, 64:] = b * c + a * sn
+    check(got, ref.view(M, -1), dtype, k=4.0, what=f"rope_qkv_skinny M={M}")
+    rows = torch.arange(M, device=DEV) * cap + pos.long()
+    assert torch.equal(kp[rows], got[:, H * hd:(H + KV) * hd]) and torch.equal(vp[rows], got[:, (H + KV) * hd:])
+    mask = torch.ones(M * cap, dtype=torch.bool, device=DEV)
+    mask[rows] = False
+    assert not kp[mask].any() and not vp[mask].any()
+
+
+@pytest.mark.parametrize("M", [1, 8, 16, 32])
+def test_norm_small_m(ops, M):
+    """RMSNorm D = 4096 / LayerNorm D = 1152 at decode row counts (one workgroup per row) vs fp64 on the device."""
+    for rms, D in ((True, 4096), (False, 1152)):
+        x, g, b = rnd((M, D), torch.float32, 41, 2.0) + 0.3, rnd((D,), torch.float32, 42) + 1.0, rnd((D,), torch.float32, 43)
+        out = torch.zeros(M, D, dtype=torch.float16, device=DEV)
+        xd = x.double()
+        if rms:
+            ops.rmsnorm(x, g, out, 1e-5)
+            ref = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-5) * g.double()
+        else:
+            ops.layernorm(x, g, b, out, 1e-6)
+            ref = torch.nn.functional.layer_norm(xd, (D,), g.double(), b.double(), 1e-6)
+        check(out, ref.float(), torch.float16, k=2.0, what=f"norm rows M={M} D={D}")
+
+
 def test_rope_rows_and_decode_pool_vs_per_sequence(ops):
     """lmi_rope_qk_rows / lmi_attn_decode_pool (B sequences in slots of one pooled cache) == lmi_rope_qk_at / lmi_attn_decode_fwd
     sequence by sequence, bit for bit, at the Llama head geometry and a C3-sized slot."""
