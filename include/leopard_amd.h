@@ -296,6 +296,14 @@ int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, 
 int lmi_gemv_rmsnorm(const void* W, const float* x, const float* norm_weight, float eps, void* out, int N, int K, int ldw,
                      int epilogue, int dtype, void* stream);
 
+/* The decode step's q | k | v projection in ONE launch: lmi_gemv_rmsnorm (store epilogue) + lmi_rope_qk_at — RMSNorm folded into
+ * the load of the fp32 residual row, RoPE at the device position *pos_dev applied to the fp32 sums, q | k | v written in natural
+ * order, K / V appended to cache row *pos_dev.  Wqkv_rope: the q and k rows in weights.rope_permute_rows order, v rows natural
+ * (the weight of lmi_rmsnorm_rope, modeling_llama.py:254-277 restated for one row).  K = 4096, head_dim = 128. */
+int lmi_gemv_rmsnorm_rope(const void* Wqkv_rope, const float* x, const float* norm_weight, float eps, void* qkv, int n_q_heads, int n_kv_heads,
+                          int head_dim, int K, int ldw, const float* cos_all, const float* sin_all, void* k_cache, void* v_cache, int ld_cache,
+                          const int* pos_dev, int dtype, void* stream);
+
 /* Last-position lm_head (EVAL:333 restricted to the rows generate() consumes; SURVEY.md 8(b) "lmi_lm_head_last"): for each
  * selected row r of the fp32 residual stream x [., ldx] (row index rows[r], int64 on device; null = row r),
  * out[r, 0..N) = W[N,K] . (norm_weight * (x_row * rsqrt(mean(x_row^2) + eps))) with the final RMSNorm

@@ -47,6 +47,7 @@ SIGNATURES = {
     "lmi_embed_merge": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lmi_gemv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lmi_gemv_rmsnorm": [_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
+    "lmi_gemv_rmsnorm_rope": [_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],
     "lmi_attn_decode_pool": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, C.c_int64, _I, _P],
     "lmi_rope_qk_rows": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, C.c_int64, _P, _I, _P],
     "lmi_attn_varlen_fwd_fp8": [_P, _P, _P, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],

@@ -629,39 +629,61 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         }
 }
 
-// Merge of the split-KV partials: out[row, head, :] = sum_s w_s O_s / sum_s w_s l_s with w_s = 2^((m_s - max m) c2).
-// One wave per (row, head); a split that saw no visible key has m = -inf and is skipped.
+// Merge of the split-KV partials: out[row, head, :] = sum_s w_s O_s / sum_s w_s l_s with w_s = 2^((m_s - max m) c2); a split that saw
+// no visible key has m = -inf, weight 0 (its partial is all zeros).  One workgroup per (row, head), n_splits <= 64: wave 0 turns the
+// (m, l) pairs into weights (lane s = split s), then the four waves each take the splits s = wave (mod 4), four partial rows in
+// flight per wave (the loads, not the arithmetic, are this kernel's time), and the four wave sums meet in LDS in wave order — the
+// result does not depend on timing.
 template <typename T, int D>
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* part_o, const float* part_ml, T* out, const int* cu_q,
                                                            int n_seq, int n_heads, int n_splits, int part_rows, int ldo, float scale) {
-    const int lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int total_q = cu_q[n_seq];
-    if (item >= (long)total_q * n_heads) return;
-    const int row = (int)(item / n_heads), head = (int)(item - (long)row * n_heads);
+    static_assert(D == 128, "attn_combine_kernel: one float2 per lane");
+    __shared__ float wl[64], red[4][D + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = (int)blockIdx.x;
+    const int row = item / n_heads, head = item - row * n_heads;
+    if (row >= cu_q[n_seq]) return;                                // whole workgroup
     const float c2 = scale * 1.4426950408889634f;
-    float M = -INFINITY;
-    for (int s = 0; s < n_splits; ++s) M = fmaxf(M, part_ml[(((long)s * part_rows + row) * n_heads + head) * 2]);
-    float l = 0.f, acc[(D + 63) / 64];
-#pragma unroll
-    for (int j = 0; j < (D + 63) / 64; ++j) acc[j] = 0.f;
-    for (int s = 0; s < n_splits; ++s) {
-        const long base = ((long)s * part_rows + row) * n_heads + head;
-        const float m = part_ml[base * 2];
-        if (m == -INFINITY) continue;
-        const float w = fast_exp2((m - M) * c2);
-        l += w * part_ml[base * 2 + 1];
-#pragma unroll
-        for (int j = 0; j < (D + 63) / 64; ++j) {
-            const int d = j * 64 + lane;
-            if (d < D) acc[j] += w * part_o[base * D + d];
+    const long stride = (long)part_rows * n_heads;                 // (row, head) items per split
+    const long base0 = (long)row * n_heads + head;
+    float lw = 0.f;
+    if (wave == 0) {
+        float m = -INFINITY, l = 0.f;
+        if (lane < n_splits) {
+            m = part_ml[(base0 + lane * stride) * 2];
+            l = part_ml[(base0 + lane * stride) * 2 + 1];
         }
+        const float M = wave_max(m);
+        const float w = (m == -INFINITY) ? 0.f : fast_exp2((m - M) * c2);
+        wl[lane] = w;
+        lw = wave_sum(w * l);
+        if (lane == 0) red[0][D] = lw;
     }
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    __syncthreads();
+    f32x2 acc = {0.f, 0.f};
+    for (int s0 = wave; s0 < n_splits; s0 += 16) {
+        f32x2 v[4];
 #pragma unroll
-    for (int j = 0; j < (D + 63) / 64; ++j) {
-        const int d = j * 64 + lane;
-        if (d < D) out[(long)row * ldo + head * D + d] = (T)(acc[j] * inv);
+        for (int u = 0; u < 4; ++u) {
+            const int sp = imin(s0 + 4 * u, n_splits - 1);
+            v[u] = *(const f32x2*)(part_o + (base0 + sp * stride) * D + lane * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s0 + 4 * u < n_splits) {
+                const float w = wl[s0 + 4 * u];
+                acc[0] += w * v[u][0];
+                acc[1] += w * v[u][1];
+            }
+    }
+    red[wave][lane * 2] = acc[0];
+    red[wave][lane * 2 + 1] = acc[1];
+    const float l_tot = red[0][D];
+    __syncthreads();
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        out[(long)row * ldo + head * D + d] = (T)(((red[0][d] + red[1][d]) + (red[2][d] + red[3][d])) * inv);
     }
 }
 

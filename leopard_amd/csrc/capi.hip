@@ -248,6 +248,7 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     return check_launch("lmi_attn_varlen_fwd");
 }
 std::atomic<int> g_attn_lds_pad{0};                      // experiment knob: extra dynamic LDS per workgroup (lowers residency)
+std::atomic<int> g_attn_split_tiles{0};      // decode: 64-key tiles per split-KV workgroup; 0 = decode_splits chooses (A/B knob attn.decode_split_tiles)
 std::atomic<int> g_attn_gqa_pack{1};         // decode: 1 = a workgroup's waves take the query heads of one kv head (A/B knob attn.gqa_pack)
 std::atomic<int> g_attn_dma{1};                          // 1 = LDS-DMA kernel (production), 0 = register-staged kernel (cross-checks)
 
@@ -282,19 +283,21 @@ static int gemv_upb(int units, int per_pass, int max_units) {
 }
 template <typename T, int EPI, bool NORM>
 int launch_gemv(const void* W, const void* x, const float* gamma, float eps, const float* bias, void* out, int N, int K, int ldw,
-                void* stream) {
-    const int rows = (EPI == GEMV_SWIGLU_T) ? N / 2 : N;
-    constexpr int RW = (EPI == GEMV_SWIGLU_T) ? 2 : 1;
+                void* stream, const RopeEpi& rp = RopeEpi()) {
+    constexpr bool PAIR = (EPI == GEMV_SWIGLU_T || EPI == GEMV_QKV_ROPE_T);
+    const int rows = PAIR ? N / 2 : N;
+    constexpr int RW = PAIR ? 2 : 1;
     if (K == 4096) {
         const int upb = gemv_upb(rows, 8 / RW, 128 / RW);
         LMI_LAUNCH((gemv_split_kernel<T, EPI, 2, 8, NORM>), dim3((rows + upb - 1) / upb), dim3(256), 0, stream, (const T*)W, x, gamma, eps,
-                   bias, out, N, K, ldw, upb);
+                   bias, out, N, K, ldw, upb, rp);
         return check_launch("lmi_gemv");
     }
+    if (EPI == GEMV_QKV_ROPE_T) return fail(LMI_EINVAL, "lmi_gemv_rmsnorm_rope: K = %d is not a supported hidden size (4096)", K);
     if (K == 14336 && !NORM) {
         const int upb = gemv_upb(rows, 4 / RW, 128 / RW);
         LMI_LAUNCH((gemv_split_kernel<T, EPI, 7, 4, false>), dim3((rows + upb - 1) / upb), dim3(256), 0, stream, (const T*)W, x, gamma, eps,
-                   bias, out, N, K, ldw, upb);
+                   bias, out, N, K, ldw, upb, rp);
         return check_launch("lmi_gemv");
     }
     if (NORM) return fail(LMI_EINVAL, "lmi_gemv_rmsnorm: K = %d is not a supported hidden size (4096)", K);
@@ -394,14 +397,22 @@ int merge_impl(const int64_t* ids, const int64_t* src, const void* table, const 
     } while (0)
 
 // ---- decode attention: split-KV LDS-DMA kernel + merge ------------------------------------------------------------------
-static int decode_splits(int max_seqlen_k, int* split_tiles) {
+// Key tiles per workgroup: the largest of 8, 4, 2, 1 (512 ... 64 keys) that still gives about one workgroup per CU for ONE sequence
+// (grid_heads workgroups per split: the kv heads when the blocks are GQA-packed, else the query heads), at most 64 splits (the merge
+// kernel gives every split one lane).  A function of the launch shape only — never of device data (graph capture) or of the number
+// of sequences (a pooled launch and its sequences one by one split alike and agree bit for bit).
+static int decode_splits(int max_seqlen_k, int grid_heads, int* split_tiles) {
     const int tiles = (max_seqlen_k + ATT_BKV - 1) / ATT_BKV;
-    int st = 8;                                                  // 512 keys per workgroup ...
-    while ((tiles + st - 1) / st > 64) st *= 2;                  // ... unless that needs more than 64 splits
+    int st = g_attn_split_tiles.load() > 0 ? g_attn_split_tiles.load() : 8;
+    if (g_attn_split_tiles.load() <= 0)
+        while (st > 1 && (long)grid_heads * ((tiles + st - 1) / st) < 256) st >>= 1;
+    while ((tiles + st - 1) / st > 64) st *= 2;
     *split_tiles = st;
     const int n = (tiles + st - 1) / st;
-    return n < 2 ? 2 : n;      // a single chunk also goes through the partial + merge pair: one code path, and the grid
-                               // never depends on device data (graph capture)
+    return n < 2 ? 2 : n;      // a single chunk also goes through the partial + merge pair: one code path
+}
+static int decode_grid_heads(int n_heads, int n_kv_heads, int max_q) {
+    return (g_attn_gqa_pack.load() && n_heads == 4 * n_kv_heads && max_q <= 32) ? n_kv_heads : n_heads;
 }
 
 template <typename T>
@@ -409,19 +420,19 @@ int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, in
     static std::atomic<uint64_t> attr_done{0};
     allow_big_lds(attn_fwd_dma_kernel<T, 128, true>, 160 * 1024, attr_done);
     // GQA-packed blocks when a kv head serves exactly 4 query heads (Llama-3.1-8B, Mistral-7B) and a sequence has at most 32 query rows
-    a.gqa_pack = (g_attn_gqa_pack.load() && a.n_heads == 4 * a.n_kv_heads && max_q <= 32) ? 1 : 0;
+    a.gqa_pack = decode_grid_heads(a.n_heads, a.n_kv_heads, max_q) != a.n_heads ? 1 : 0;
     a.n_qblocks = a.gqa_pack ? (max_q + 31) / 32 : (max_q + ATT_BQ - 1) / ATT_BQ;
     LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true>), dim3(a.n_qblocks * (a.gqa_pack ? a.n_kv_heads : a.n_heads) * n_seq * a.n_splits), dim3(ATT_THREADS),
                AttnDmaGeom<128>::SMEM, stream, a);
     const long items = (long)q_rows * a.n_heads;
-    LMI_LAUNCH((attn_combine_kernel<T, 128>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, (const float*)a.part_o,
+    LMI_LAUNCH((attn_combine_kernel<T, 128>), dim3((unsigned)items), dim3(256), 0, stream, (const float*)a.part_o,
                (const float*)a.part_ml, (T*)out, a.cu_q, n_seq, a.n_heads, a.n_splits, a.part_rows, ldo, a.scale);
     return check_launch("lmi_attn_decode_fwd");
 }
 
 template <typename T, bool PACKED>
 int skinny_impl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, void* stream,
-                const SkinnyRope& rp = SkinnyRope()) {
+                const RopeEpi& rp = RopeEpi()) {
     const int units = (epilogue == LMI_SKINNY_SWIGLU || epilogue == 4) ? N / 32 : N / 16;
 #define LMI_SK(E) LMI_LAUNCH((skinny_gemm_kernel<T, E, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo, rp)
     switch (epilogue) {
@@ -488,6 +499,11 @@ int lmi_set_option(const char* key, int value) {
     }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.gqa_pack")) { g_attn_gqa_pack = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "attn.decode_split_tiles")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(LMI_EINVAL, "lmi_set_option: attn.decode_split_tiles in {0, 1, 2, 4, 8}");
+        g_attn_split_tiles = value;
+        return LMI_OK;
+    }
     if (!strcmp(key, "attn.lds_pad")) { g_attn_lds_pad = value < 0 ? 0 : (value > 90 * 1024 ? 90 * 1024 : value); return LMI_OK; }
     return fail(LMI_EINVAL, "lmi_set_option: unknown key %s", key);
 }
@@ -858,8 +874,8 @@ int lmi_split_hi_lo(const float* x, void* out, int M, int K, int ldx, int ldo, i
 
 int64_t lmi_attn_decode_workspace_bytes(int q_rows, int n_heads, int head_dim, int max_seqlen_k) {
     if (q_rows < 0 || n_heads <= 0 || head_dim <= 0 || max_seqlen_k < 0) return -1;
-    int st;
-    const int n = decode_splits(max_seqlen_k, &st);
+    const int tiles = (max_seqlen_k + ATT_BKV - 1) / ATT_BKV;      // the most splits any launch shape takes: one per tile, at most 64
+    const int n = tiles < 2 ? 2 : (tiles > 64 ? 64 : tiles);
     return (int64_t)n * q_rows * n_heads * (head_dim + 2) * 4;
 }
 
@@ -885,7 +901,7 @@ static int attn_decode_entry(const char* who, const void* q, const void* k, cons
     if (((long)max_seqlen_k * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_k * ldv + head_dim) * 2 >= (1L << 32))
         return fail(LMI_EINVAL, "%s: one sequence's K / V rows span >= 4 GiB (max_seqlen_k %d, ldk %d, ldv %d)", who, max_seqlen_k, ldk, ldv);
     a.check_k_extent = 0;
-    a.n_splits = decode_splits(max_seqlen_k, &a.split_tiles);
+    a.n_splits = decode_splits(max_seqlen_k, decode_grid_heads(n_heads, n_kv_heads, max_seqlen_q), &a.split_tiles);
     a.part_rows = q_rows;
     a.part_o = (float*)workspace;
     a.part_ml = a.part_o + (size_t)a.n_splits * q_rows * n_heads * head_dim;
@@ -937,7 +953,7 @@ int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, 
         (ld_cache & 7) || cache_stride <= 0 || ldo < N || !aligned16(Wqkv_rope) || !aligned16(X))
         return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: bad argument (M <= 16, K %% 128 == 0, 16-byte aligned rows)");
     if (M == 0) return LMI_OK;
-    SkinnyRope rp;
+    RopeEpi rp;
     rp.cos_all = cos_all; rp.sin_all = sin_all; rp.pos = pos_rows_dev; rp.k_cache = k_cache; rp.v_cache = v_cache; rp.ld_cache = ld_cache;
     rp.cache_stride = (long)cache_stride; rp.rope_q = n_q_heads * head_dim; rp.rope_k = n_kv_heads * head_dim;
     if (packed)
@@ -1017,6 +1033,23 @@ int lmi_gemv_rmsnorm(const void* W, const float* x, const float* norm_weight, fl
         return fail(LMI_EINVAL, "lmi_gemv_rmsnorm: bad argument (N=%d K=%d)", N, K);
     LMI_DISPATCH_T(dtype, (dispatch_gemv<f16_t, true>(W, x, norm_weight, eps, nullptr, out, N, K, ldw, epilogue, stream)),
                    (dispatch_gemv<bf16_t, true>(W, x, norm_weight, eps, nullptr, out, N, K, ldw, epilogue, stream)));
+}
+
+int lmi_gemv_rmsnorm_rope(const void* Wqkv_rope, const float* x, const float* norm_weight, float eps, void* qkv, int n_q_heads, int n_kv_heads,
+                          int head_dim, int K, int ldw, const float* cos_all, const float* sin_all, void* k_cache, void* v_cache, int ld_cache,
+                          const int* pos_dev, int dtype, void* stream) {
+    if (!Wqkv_rope || !x || !norm_weight || !qkv || !cos_all || !sin_all || !k_cache || !v_cache || !pos_dev)
+        return fail(LMI_EINVAL, "lmi_gemv_rmsnorm_rope: null pointer");
+    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_gemv_rmsnorm_rope: head_dim %d (only 128)", head_dim);
+    if (n_q_heads <= 0 || n_kv_heads <= 0 || K != 4096 || (ldw & 7) || ldw < K || ld_cache < n_kv_heads * head_dim || !aligned16(x) ||
+        !aligned16(norm_weight) || !aligned16(Wqkv_rope))
+        return fail(LMI_EINVAL, "lmi_gemv_rmsnorm_rope: bad argument (K = %d: only the 4096 hidden size; 16-byte aligned rows)", K);
+    const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
+    RopeEpi rp;
+    rp.cos_all = cos_all; rp.sin_all = sin_all; rp.pos = pos_dev; rp.k_cache = k_cache; rp.v_cache = v_cache; rp.ld_cache = ld_cache;
+    rp.cache_stride = 0; rp.rope_q = n_q_heads * head_dim; rp.rope_k = n_kv_heads * head_dim;
+    LMI_DISPATCH_T(dtype, (launch_gemv<f16_t, GEMV_QKV_ROPE_T, true>(Wqkv_rope, x, norm_weight, eps, nullptr, qkv, N, K, ldw, stream, rp)),
+                   (launch_gemv<bf16_t, GEMV_QKV_ROPE_T, true>(Wqkv_rope, x, norm_weight, eps, nullptr, qkv, N, K, ldw, stream, rp)));
 }
 
 }  // extern "C"

@@ -406,7 +406,22 @@ __global__ void embed_merge_kernel(const long* ids, const long* src, const T* ta
 // weight-streaming GEMV (M = 1): out[n] = W[n,:] . x  — last-token lm_head and the decode step.
 // One wave per output row (per gate/up row pair for SwiGLU); x is held in registers; W streams 16 B / lane.
 // ------------------------------------------------------------------------------------------------
-enum { GEMV_STORE_F32 = 0, GEMV_STORE_T = 1, GEMV_RESID_F32 = 2, GEMV_SWIGLU_T = 3 };
+enum { GEMV_STORE_F32 = 0, GEMV_STORE_T = 1, GEMV_RESID_F32 = 2, GEMV_SWIGLU_T = 3, GEMV_QKV_ROPE_T = 4 };
+
+// RoPE + KV append riding in a decode projection's epilogue (gemv_split_kernel GEMV_QKV_ROPE_T, skinny_gemm_kernel SK_QKV_ROPE_T):
+// the q / k weight rows are in weights.rope_permute_rows order, so rows r and r + 32 of a 64-row group — the SwiGLU pairing — hold
+// a first-half element and its rotate-half partner.
+struct RopeEpi {
+    const float* cos_all;     // [capacity, 64]
+    const float* sin_all;
+    const int* pos;           // [M] (one entry for the batch-1 GEMV)
+    void* k_cache;
+    void* v_cache;
+    int ld_cache;
+    long cache_stride;
+    int rope_q, rope_k;       // columns [0, rope_q) are q heads, [rope_q, rope_q + rope_k) k heads, the rest v
+};
+
 
 template <typename T, int EPI, int KCH>       // KCH = 16-byte chunks per lane (K = KCH*512)
 __global__ void __launch_bounds__(256) gemv_kernel(const T* W, const T* x, const float* bias, void* out,
@@ -466,13 +481,14 @@ __global__ void __launch_bounds__(256) gemv_kernel(const T* W, const T* x, const
 // ------------------------------------------------------------------------------------------------
 template <typename T, int EPI, int CPW, int R, bool NORM>
 __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void* xin, const float* gamma, float eps, const float* bias,
-                                                         void* out, int N, int K, int ldw, int UPB) {
+                                                         void* out, int N, int K, int ldw, int UPB, RopeEpi rp) {
     typedef typename vec_of<T>::x8 T8;
-    constexpr int RW = (EPI == GEMV_SWIGLU_T) ? 2 : 1;            // weight rows per output
+    constexpr bool PAIR = (EPI == GEMV_SWIGLU_T || EPI == GEMV_QKV_ROPE_T);
+    constexpr int RW = PAIR ? 2 : 1;                              // weight rows per unit
     __shared__ float part[4][128];
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int units = (EPI == GEMV_SWIGLU_T) ? N >> 1 : N;
+    const int units = PAIR ? N >> 1 : N;
     const int u0 = blockIdx.x * UPB, u1 = imin(units, u0 + UPB);
     // ---- this wave's slice of x ---------------------------------------------------------------------------------
     T8 xv[CPW];
@@ -508,7 +524,7 @@ __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void*
     }
     // ---- stream the weight rows, R at a time -------------------------------------------------------------------
     auto row_of = [&](int u, int half) -> int {                    // weight row of output u (SwiGLU: gate / up interleaved by 32)
-        if (EPI == GEMV_SWIGLU_T) return ((u >> 5) << 6) + (u & 31) + 32 * half;
+        if (PAIR) return ((u >> 5) << 6) + (u & 31) + 32 * half;
         return u;
     };
     for (int ub = u0; ub < u1; ub += R / RW) {
@@ -541,6 +557,32 @@ __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void*
             const float g = part[0][2 * t] + part[1][2 * t] + part[2][2 * t] + part[3][2 * t];
             const float up = part[0][2 * t + 1] + part[1][2 * t + 1] + part[2][2 * t + 1] + part[3][2 * t + 1];
             ((T*)out)[u] = (T)(g / (1.0f + lmi::fexp(-g)) * up);
+        } else if (EPI == GEMV_QKV_ROPE_T) {
+            // unit u = columns c1 = row_of(u, 0) and c1 + 32 of the permuted q | k | v row: rotate (q, k) from the fp32 sums, restore the
+            // natural order, append K / V to the cache row of this step's position
+            const float a = part[0][2 * t] + part[1][2 * t] + part[2][2 * t] + part[3][2 * t];
+            const float b = part[0][2 * t + 1] + part[1][2 * t + 1] + part[2][2 * t + 1] + part[3][2 * t + 1];
+            const int c1 = ((u >> 5) << 6) + (u & 31), p = *rp.pos;
+            T* o = (T*)out;
+            if (c1 < rp.rope_q + rp.rope_k) {
+                const int hb = c1 & ~127, j = c1 & 127, d1 = ((j >> 6) << 5) + (j & 31);
+                const float cs = rp.cos_all[(long)p * 64 + d1], sn = rp.sin_all[(long)p * 64 + d1];
+                const T o1 = (T)(a * cs - b * sn), o2 = (T)(b * cs + a * sn);
+                o[hb + d1] = o1;
+                o[hb + d1 + 64] = o2;
+                if (hb >= rp.rope_q) {
+                    T* kc = (T*)rp.k_cache + (long)p * rp.ld_cache + (hb - rp.rope_q) + d1;
+                    kc[0] = o1;
+                    kc[64] = o2;
+                }
+            } else {
+                const T va = (T)a, vb = (T)b;
+                o[c1] = va;
+                o[c1 + 32] = vb;
+                T* vc = (T*)rp.v_cache + (long)p * rp.ld_cache + (c1 - rp.rope_q - rp.rope_k);
+                vc[0] = va;
+                vc[32] = vb;
+            }
         } else {
             float v = part[0][t] + part[1][t] + part[2][t] + part[3][t];
             if (bias) v += bias[u];

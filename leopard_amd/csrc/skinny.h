@@ -29,19 +29,9 @@ enum { SK_STORE_T = 0, SK_RESID_F32 = 1, SK_SWIGLU_T = 2, SK_STORE_F32 = 3, SK_Q
 // owns — rows r and r + 32 of a 64-row group, exactly the SwiGLU pairing — hold first-half elements and their rotate-half partners.
 // Row m of the batch rotates at its own position pos[m] (device memory) and appends K / V to row m * cache_stride + pos[m] of the pooled
 // caches; v rows (natural order) are two independent blocks.
-struct SkinnyRope {
-    const float* cos_all;     // [capacity, 64]
-    const float* sin_all;
-    const int* pos;           // [M]
-    void* k_cache;
-    void* v_cache;
-    int ld_cache;
-    long cache_stride;
-    int rope_q, rope_k;       // columns [0, rope_q) are q heads, [rope_q, rope_q + rope_k) k heads, the rest v
-};
 
 template <typename T, int EPI, bool PACKED>
-__global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, SkinnyRope rp) {
+__global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, RopeEpi rp) {
     typedef typename vec_of<T>::x8 T8;
     constexpr bool PAIR = (EPI == SK_SWIGLU_T || EPI == SK_QKV_ROPE_T);
     constexpr int NW = PAIR ? 2 : 1;                               // weight row blocks per workgroup (gate, up / first half, rotate-half partner)

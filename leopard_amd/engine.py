@@ -826,12 +826,16 @@ class LeopardEngine:
         ops.embed_merge(st.tok, st.src0, W.embed, None, st.x)
         fuse = tc.hidden_size == 4096                 # lmi_gemv_rmsnorm: the norm rides in the projection's launch
         for i, L in enumerate(W.llm_layers):
-            if fuse:
-                ops.gemv_rmsnorm(L.qkv_w, st.x[0], L.in_norm, tc.rms_norm_eps, st.qkv[0], epilogue=1)
+            if fuse and hd == 128 and L.qkv_w_rope is not None:   # norm + projection + RoPE + KV append: one launch
+                ops.gemv_rmsnorm_rope(L.qkv_w_rope, st.x[0], L.in_norm, tc.rms_norm_eps, st.qkv[0], H, KV, hd, st.cos, st.sin,
+                                      cache.k[i], cache.v[i], st.pos)
             else:
-                ops.rmsnorm(st.x, L.in_norm, st.h, tc.rms_norm_eps)
-                ops.gemv(L.qkv_w, st.h[0], st.qkv[0], epilogue=1)
-            ops.rope_qk_at(st.qkv, H, KV, hd, st.cos, st.sin, cache.k[i], cache.v[i], st.pos)
+                if fuse:
+                    ops.gemv_rmsnorm(L.qkv_w, st.x[0], L.in_norm, tc.rms_norm_eps, st.qkv[0], epilogue=1)
+                else:
+                    ops.rmsnorm(st.x, L.in_norm, st.h, tc.rms_norm_eps)
+                    ops.gemv(L.qkv_w, st.h[0], st.qkv[0], epilogue=1)
+                ops.rope_qk_at(st.qkv, H, KV, hd, st.cos, st.sin, cache.k[i], cache.v[i], st.pos)
             ops.attention_decode(st.qkv[:, :qw], cache.k[i], cache.v[i], st.att, st.cu_q, st.cu_k, 1, cache.capacity, H, KV, hd,
                                  hd ** -0.5, st.ws, window=tc.sliding_window or 0)
             row_parallel(L.o_w, st.att[0])

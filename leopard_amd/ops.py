@@ -226,6 +226,13 @@ class Ops:
                                               epilogue, _DT[w.dtype], self._stream(out)))
         return out
 
+    def gemv_rmsnorm_rope(self, w_rope, x_f32, norm_weight, eps, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, pos_dev):
+        """lmi_gemv_rmsnorm_rope: the decode step's q|k|v projection with the RMSNorm on its input and RoPE + KV append on its output."""
+        self._check(self.lib.lmi_gemv_rmsnorm_rope(_ptr(w_rope), _ptr(x_f32), _ptr(norm_weight), float(eps), _ptr(qkv), n_q_heads, n_kv_heads,
+                                                   head_dim, w_rope.shape[1], w_rope.stride(0), _ptr(cos_all), _ptr(sin_all), _ptr(k_cache),
+                                                   _ptr(v_cache), k_cache.stride(0), _ptr(pos_dev), _DT[w_rope.dtype], self._stream(qkv)))
+        return qkv
+
     def lm_head_last(self, w, x_f32, rows, norm_weight, eps, out):
         """out[r] = w @ rmsnorm(x_f32[rows[r]]) with the normalised row kept in fp32 (no activation rounding).
         x_f32: fp32 [S, K]; rows: int64 [n] on device or None (rows 0..n-1); out: fp32 [n, >= N]."""

@@ -670,6 +670,42 @@ def test_rope_qkv_skinny_equals_projection_then_rope_rows(ops, packed):
     assert not kp[~touched].any() and not vp[~touched].any()
 
 
+def test_gemv_rmsnorm_rope_equals_norm_projection_rope(ops):
+    """lmi_gemv_rmsnorm_rope (batch-1 decode: RMSNorm + q|k|v projection + RoPE + KV append in one launch) vs the fp32 statement, and
+    within one 16-bit rounding of lmi_gemv_rmsnorm + lmi_rope_qk_at; cache rows other than *pos untouched."""
+    from leopard_amd.weights import rope_permute_rows
+    dtype, H, KV, hd, cap, K = torch.float16, 2, 1, 128, 9, 4096
+    N = (H + 2 * KV) * hd
+    w, x, g = rnd((N, K), dtype, 7, 0.03), rnd((1, K), torch.float32, 8, 2.0), rnd((K,), torch.float32, 9) + 1.0
+    f = torch.arange(cap).float().reshape(-1, 1) * (1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    pos = torch.tensor([6], dtype=torch.int32)
+    w_rope = torch.cat([rope_permute_rows(w[:(H + KV) * hd]), w[(H + KV) * hd:]]).contiguous()
+    kc, vc = torch.zeros(cap, KV * hd, dtype=dtype), torch.zeros(cap, KV * hd, dtype=dtype)
+    got = torch.zeros(1, N, dtype=dtype)
+    ops.gemv_rmsnorm_rope(w_rope, x[0], g, 1e-5, got[0], H, KV, hd, cos, sin, kc, vc, pos)
+    xn = (x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * g).to(dtype).float()
+    lin = xn @ w.float().T
+    ref = lin.clone()
+    c, sn = cos[6], sin[6]
+    for h in range(H + KV):
+        a, b = lin[0, h * hd:h * hd + 64], lin[0, h * hd + 64:(h + 1) * hd]
+        ref[0, h * hd:h * hd + 64] = a * c - b * sn
+        ref[0, h * hd + 64:(h + 1) * hd] = b * c + a * sn
+    t = tol(dtype) * max(1.0, ref.abs().max().item())
+    assert (got.float() - ref).abs().max() <= t
+    two = torch.zeros(1, N, dtype=dtype)
+    k2, v2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    ops.gemv_rmsnorm(w, x[0], g, 1e-5, two[0], epilogue=1)
+    ops.rope_qk_at(two, H, KV, hd, cos, sin, k2, v2, pos)
+    assert (got.float() - two.float()).abs().max() <= 2 * t
+    assert torch.equal(got[0, (H + KV) * hd:], two[0, (H + KV) * hd:]) and torch.equal(vc, v2)
+    assert torch.equal(kc[6], got[0, H * hd:(H + KV) * hd]) and torch.equal(vc[6], got[0, (H + KV) * hd:])
+    kc[6] = 0
+    vc[6] = 0
+    assert not kc.any() and not vc.any()
+
+
 @pytest.mark.parametrize("rms", [True, False])
 @pytest.mark.parametrize("M,D", [(1, 1152), (3, 4096), (32, 256), (33, 4096)])
 def test_norm_small_m_rows_kernel(ops, rms, M, D):

@@ -330,6 +330,31 @@ def test_attention_decode_split_kv_long_cache(ops, dtype):
         assert (out.float() - one.float()).abs().max() <= 3 * eps(dtype)
 
 
+@pytest.mark.parametrize("lk,cap", [(7187, 7424), (228, 512), (1, 64), (4100, 16384)])
+def test_attention_decode_every_split_size(ops, lk, cap):
+    """The split-KV geometry (attn.decode_split_tiles: 64 ... 512 keys per workgroup; 0 = chosen from the launch shape) never changes
+    the answer beyond the summation order: every setting within 3 eps of the fp32 reference, splits past the sequence's end (the
+    capacity fixes the grid, not the length) contributing nothing; repeated launches agree bit for bit."""
+    dtype, H, KV, D = torch.float16, 32, 8, 128
+    k, v = rnd((cap, KV * D), dtype, 71), rnd((cap, KV * D), dtype, 72)
+    q = rnd((1, H * D), dtype, 73)
+    cu_q = torch.tensor([0, 1], dtype=torch.int32, device=DEV)
+    cu_k = torch.tensor([0, lk], dtype=torch.int32, device=DEV)
+    ref = attn_ref(q, k[:lk], v[:lk], [0, 1], [0, lk], H, KV, D, D ** -0.5, True)
+    ws = torch.full((ops.decode_workspace_elems(1, H, D, cap),), float("nan"), dtype=torch.float32, device=DEV)
+    try:
+        for st in (0, 1, 2, 4, 8):
+            ops.set_option("attn.decode_split_tiles", st)
+            outs = [torch.full((1, H * D), float("nan"), dtype=dtype, device=DEV) for _ in range(2)]
+            for o in outs:
+                ops.attention_decode(q, k, v, o, cu_q, cu_k, 1, cap, H, KV, D, D ** -0.5, ws)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[1]), st
+            assert (outs[0].float() - ref).abs().max() <= 3 * eps(dtype), st
+    finally:
+        ops.set_option("attn.decode_split_tiles", 0)
+
+
 def test_gemv_rmsnorm_equals_rmsnorm_then_gemv(ops):
     dtype = torch.float16
     K, N = 4096, 6144
@@ -410,6 +435,48 @@ def test_rope_qkv_skinny_llama_shape(ops, dtype, M):
     mask = torch.ones(M * cap, dtype=torch.bool, device=DEV)
     mask[rows] = False
     assert not kp[mask].any() and not vp[mask].any()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemv_rmsnorm_rope_llama_shape(ops, dtype):
+    """lmi_gemv_rmsnorm_rope at the Llama-3.1-8B decode shape vs fp32 on the device and vs lmi_gemv_rmsnorm + lmi_rope_qk_at (V bit for
+    bit — no rotation; q / k within a rounding: the fused launch rotates the unrounded sums); launches agree bit for bit; only cache row
+    *pos is written."""
+    from leopard_amd.weights import rope_permute_rows
+    H, KV, hd, K, cap = 32, 8, 128, 4096, 7424
+    N = (H + 2 * KV) * hd
+    w, x, g = rnd((N, K), dtype, 51, 0.02), rnd((1, K), torch.float32, 52, 2.0), rnd((K,), torch.float32, 53) + 1.0
+    f = torch.arange(cap, device=DEV).float().reshape(-1, 1) * (1.0 / (500000.0 ** (torch.arange(0, hd, 2, device=DEV).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    P = 7186
+    pos = torch.tensor([P], dtype=torch.int32, device=DEV)
+    w_rope = torch.cat([rope_permute_rows(w[:(H + KV) * hd]), w[(H + KV) * hd:]]).contiguous()
+    outs = []
+    for _ in range(2):
+        kc, vc = torch.zeros(cap, KV * hd, dtype=dtype, device=DEV), torch.zeros(cap, KV * hd, dtype=dtype, device=DEV)
+        got = torch.zeros(1, N, dtype=dtype, device=DEV)
+        ops.gemv_rmsnorm_rope(w_rope, x[0], g, 1e-5, got[0], H, KV, hd, cos, sin, kc, vc, pos)
+        outs.append((got, kc, vc))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    got, kc, vc = outs[0]
+    xn = (x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * g).to(dtype).float()
+    lin = (xn @ w.float().T).view(H + 2 * KV, hd)
+    ref = lin.clone()
+    a, b = lin[:H + KV, :64], lin[:H + KV, 64:]
+    ref[:H + KV, :64] = a * cos[P] - b * sin[P]
+    ref[:H + KV, 64:] = b * cos[P] + a * sin[P]
+    check(got, ref.view(1, -1), dtype, k=4.0, what="gemv_rmsnorm_rope")
+    two = torch.zeros(1, N, dtype=dtype, device=DEV)
+    k2, v2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    ops.gemv_rmsnorm(w, x[0], g, 1e-5, two[0], epilogue=1)
+    ops.rope_qk_at(two, H, KV, hd, cos, sin, k2, v2, pos)
+    assert torch.equal(got[0, (H + KV) * hd:], two[0, (H + KV) * hd:]) and torch.equal(vc, v2)
+    check(got, two, dtype, k=4.0, what="gemv_rmsnorm_rope vs two launches")
+    assert torch.equal(kc[P], got[0, H * hd:(H + KV) * hd]) and torch.equal(vc[P], got[0, (H + KV) * hd:])
+    kc[P] = 0
+    assert not kc.any()
 
 
 @pytest.mark.parametrize("M", [1, 8, 16, 32])
