@@ -248,6 +248,7 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     return check_launch("lmi_attn_varlen_fwd");
 }
 std::atomic<int> g_attn_lds_pad{0};                      // experiment knob: extra dynamic LDS per workgroup (lowers residency)
+std::atomic<int> g_gemv_plan{1};             // decode GEMV grid: 1 = a whole number of equal workgroups per CU when the shape allows (A/B knob gemv.plan)
 std::atomic<int> g_attn_split_tiles{0};      // decode: 64-key tiles per split-KV workgroup; 0 = decode_splits chooses (A/B knob attn.decode_split_tiles)
 std::atomic<int> g_attn_gqa_pack{1};         // decode: 1 = a workgroup's waves take the query heads of one kv head (A/B knob attn.gqa_pack)
 std::atomic<int> g_attn_dma{1};                          // 1 = LDS-DMA kernel (production), 0 = register-staged kernel (cross-checks)
@@ -274,9 +275,15 @@ int dispatch_attn(const AttnArgs& a, int n_seq, int max_q, int causal, int use_t
                   : launch_attn<T, D, false, false>(a, n_seq, max_q, stream);
 }
 
-// units per workgroup of the K-split kernel: a multiple of the R/RW outputs handled per pass, sized for about a thousand
-// workgroups, at most 128 partial slots per wave
+// units per workgroup of the K-split kernel: a multiple of the units of one pass.  Preferred: a grid of exactly 3, 2 or 1 workgroups
+// per CU (768 / 512 / 256) with the same number of passes in every workgroup — the stream then ends everywhere at once instead of in a
+// partial last round; otherwise about a thousand workgroups.  At most 128 partial slots per wave.
 static int gemv_upb(int units, int per_pass, int max_units) {
+    if (g_gemv_plan.load()) {
+        const int chunks = (units + per_pass - 1) / per_pass;
+        for (int g : {768, 512, 256})
+            if (units % per_pass == 0 && chunks % g == 0 && (chunks / g) * per_pass <= max_units) return (chunks / g) * per_pass;
+    }
     int upb = per_pass;
     while ((units + upb - 1) / upb > 1024 && upb * 2 <= max_units) upb *= 2;
     return upb;
@@ -498,6 +505,7 @@ int lmi_set_option(const char* key, int value) {
             }
     }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "gemv.plan")) { g_gemv_plan = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.gqa_pack")) { g_attn_gqa_pack = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.decode_split_tiles")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(LMI_EINVAL, "lmi_set_option: attn.decode_split_tiles in {0, 1, 2, 4, 8}");

@@ -477,7 +477,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const T* W, const T* x, const
 //   * NORM: x arrives as the fp32 residual row and the RMSNorm (same arithmetic as norm_kernel) is applied while it is
 //     loaded, so the decode step needs no separate norm launch;
 //   * per-row partial sums of the 4 waves meet in LDS once per workgroup, then the epilogue runs.
-// Epilogues as gemv_kernel.  `units` = outputs (row pairs for SwiGLU); workgroup b owns units [b*UPB, (b+1)*UPB).
+// Epilogues as gemv_kernel, plus GEMV_QKV_ROPE_T.  `units` = outputs (row pairs for SwiGLU / RoPE); workgroup b owns units
+// [b*UPB, (b+1)*UPB); the launcher sizes the grid to a whole number of equal workgroups per CU when the shape allows.
+// Measured and dropped (round 3, same box): requesting the next pass's rows before reducing the current one (two register buffers)
+// and the first pass's rows before the norm arithmetic: +1.5 % on the decode step — occupancy (3 workgroups per CU) already keeps the
+// memory queues full, the extra registers and the raw-barrier prologue only cost.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int EPI, int CPW, int R, bool NORM>
 __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void* xin, const float* gamma, float eps, const float* bias,

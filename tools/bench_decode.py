@@ -20,6 +20,7 @@ ap.add_argument("--tokens", type=int, default=32)
 ap.add_argument("--tiles", type=int, nargs="*", default=[1, 42])
 ap.add_argument("--batch", type=int, nargs="*", default=[], help="also time the batched decode step for these batch sizes (1 = the batch-1 loop as the base)")
 ap.add_argument("--skip-single", action="store_true")
+ap.add_argument("--eng", action="append", default=[], help="engine attribute name=int, e.g. decode_prefetch_bytes=33554432")
 ap.add_argument("--opt", action="append", default=[], help="library option key=value (lmi_set_option), e.g. attn.decode_split_tiles=8")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -29,6 +30,9 @@ for kv in args.opt:
     ops.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, torch.float16), torch.float16)
 eng = LeopardEngine(cfg, W, ops=ops, device=dev)
+for kv in args.eng:
+    assert hasattr(eng, kv.split("=")[0]), kv
+    setattr(eng, kv.split("=")[0], int(kv.split("=")[1]))
 for n_tiles in ([] if args.skip_single else args.tiles):
     per_image = [n_tiles] if n_tiles <= 8 else [7] * (n_tiles // 7)
     ids = torch.from_numpy(synth_prompt_ids(per_image, cfg, seed=1)).reshape(1, -1)
