@@ -283,12 +283,24 @@ int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, 
 int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed, int dtype,
                     void* stream);
 
+/* lmi_gemm_skinny with the RMSNorms of the batched decode step folded into its projections — the M <= 16 counterpart of lmi_gemm_ex:
+ *   producer (LMI_SKINNY_RESIDUAL, norm_out != null): after out += acc it also writes norm_out[m, n] = T(out[m, n] * norm_gamma[n]) (T [M, ld_norm])
+ *       and rowsq_out[m, n / 16] = the sum of out[m, 16 (n / 16) .. + 15]^2 (fp32 [M, N / 16]; one partial per workgroup: bit-reproducible);
+ *   consumer (any epilogue, rowsq_in != null, fp32 [M, rowsq_parts]): accumulator row m is multiplied by
+ *       rstd[m] = rsqrt(sum_j rowsq_in[m, j] / norm_dim + norm_eps) before SwiGLU / store.
+ * The decode step then needs no norm launch after its first layer's. */
+int lmi_gemm_skinny_ex(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed,
+                       const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, int ld_norm, const float* norm_gamma,
+                       float* rowsq_out, int dtype, void* stream);
+
 /* Batched decode: the q | k | v projection as lmi_gemm_skinny with RoPE and the KV append in its epilogue (W rows in
  * weights.rope_permute_rows order, optionally packed): row m rotates at position pos_rows_dev[m] and appends K / V to row
- * m * cache_stride + pos_rows_dev[m] of the pooled caches — lmi_gemm_skinny + lmi_rope_qk_rows in one launch. */
+ * m * cache_stride + pos_rows_dev[m] of the pooled caches — lmi_gemm_skinny + lmi_rope_qk_rows in one launch.  rowsq_in != null
+ * (fp32 [M, rowsq_parts], written by the lmi_gemm_skinny_ex producer over the K-wide residual row): X is the un-normalised T(x * gamma)
+ * and every row is scaled by rstd before the rotation (consumer side of the folded RMSNorm). */
 int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
-                        int ldo, int packed, const float* cos_all, const float* sin_all, void* k_cache, void* v_cache, int ld_cache,
-                        int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream);
+                        int ldo, int packed, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_all, const float* sin_all,
+                        void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream);
 
 /* Same with the RMSNorm of the decode step folded in: x is the fp32 residual row [K], norm_weight fp32 [K], and the row
  * fed to the product is T(norm_weight * (x * rsqrt(mean(x^2) + eps))) — the arithmetic of lmi_rmsnorm, without its launch.

@@ -309,7 +309,7 @@ LMI_DEV int att_vchunk72(int r4, int pos) {                    // inverse: which
     return (int)((INV[r4] >> (4 * pos)) & 15);
 }
 
-template <typename T, int D, bool CAUSAL>
+template <typename T, int D, bool CAUSAL, bool STREAM = false>      // STREAM: non-temporal K / V loads (decode: each tile is read once)
 __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p) {
     constexpr int NW = ATT_THREADS / 64, BQ = ATT_BQ, PPW = AttnDmaGeom<D>::PPW;
     typedef AttnDmaGeom<D> G;
@@ -393,8 +393,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
         const int i = j < PPW ? j : j - PPW;
         if ((G::PIECES % NW) != 0 && wave + NW * i >= G::PIECES) return;      // wave-uniform; only ragged piece counts (d = 72) branch
         char* dst = smem + slot * 2 * G::TILE_BYTES + (j < PPW ? 0 : G::TILE_BYTES) + (wave + NW * i) * 1024;
-        if (j < PPW) glds16_buf(k_buf, p_ko[i], (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldk, dst);
-        else glds16_buf(v_buf, p_vo[i], (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldv, dst);
+        if (j < PPW) glds16_buf<STREAM ? 2 : 0>(k_buf, p_ko[i], (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldk, dst);
+        else glds16_buf<STREAM ? 2 : 0>(v_buf, p_vo[i], (unsigned)t * (unsigned)(ATT_BKV * 2) * (unsigned)p.ldv, dst);
     };
     auto issue_tile = [&](int t, int slot) {
 #pragma unroll

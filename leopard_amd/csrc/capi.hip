@@ -248,6 +248,7 @@ int launch_attn(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     return check_launch("lmi_attn_varlen_fwd");
 }
 std::atomic<int> g_attn_lds_pad{0};                      // experiment knob: extra dynamic LDS per workgroup (lowers residency)
+std::atomic<int> g_attn_stream_kv{1};        // decode, GQA-packed: non-temporal K / V tile loads (A/B knob attn.stream_kv)
 std::atomic<int> g_gemv_plan{1};             // decode GEMV grid: 1 = a whole number of equal workgroups per CU when the shape allows (A/B knob gemv.plan)
 std::atomic<int> g_attn_split_tiles{0};      // decode: 64-key tiles per split-KV workgroup; 0 = decode_splits chooses (A/B knob attn.decode_split_tiles)
 std::atomic<int> g_attn_gqa_pack{1};         // decode: 1 = a workgroup's waves take the query heads of one kv head (A/B knob attn.gqa_pack)
@@ -425,12 +426,16 @@ static int decode_grid_heads(int n_heads, int n_kv_heads, int max_q) {
 template <typename T>
 int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, int ldo, void* stream) {
     static std::atomic<uint64_t> attr_done{0};
+    static std::atomic<uint64_t> attr_done_s{0};
     allow_big_lds(attn_fwd_dma_kernel<T, 128, true>, 160 * 1024, attr_done);
+    allow_big_lds(attn_fwd_dma_kernel<T, 128, true, true>, 160 * 1024, attr_done_s);
     // GQA-packed blocks when a kv head serves exactly 4 query heads (Llama-3.1-8B, Mistral-7B) and a sequence has at most 32 query rows
     a.gqa_pack = decode_grid_heads(a.n_heads, a.n_kv_heads, max_q) != a.n_heads ? 1 : 0;
     a.n_qblocks = a.gqa_pack ? (max_q + 31) / 32 : (max_q + ATT_BQ - 1) / ATT_BQ;
-    LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true>), dim3(a.n_qblocks * (a.gqa_pack ? a.n_kv_heads : a.n_heads) * n_seq * a.n_splits), dim3(ATT_THREADS),
-               AttnDmaGeom<128>::SMEM, stream, a);
+    const dim3 grid(a.n_qblocks * (a.gqa_pack ? a.n_kv_heads : a.n_heads) * n_seq * a.n_splits);
+    // GQA-packed blocks read every K / V tile exactly once: non-temporal loads; head-per-block launches re-read them from L2 (4 query heads)
+    if (a.gqa_pack && g_attn_stream_kv.load()) LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true, true>), grid, dim3(ATT_THREADS), AttnDmaGeom<128>::SMEM, stream, a);
+    else LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true>), grid, dim3(ATT_THREADS), AttnDmaGeom<128>::SMEM, stream, a);
     const long items = (long)q_rows * a.n_heads;
     LMI_LAUNCH((attn_combine_kernel<T, 128>), dim3((unsigned)items), dim3(256), 0, stream, (const float*)a.part_o,
                (const float*)a.part_ml, (T*)out, a.cu_q, n_seq, a.n_heads, a.n_splits, a.part_rows, ldo, a.scale);
@@ -439,9 +444,9 @@ int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, in
 
 template <typename T, bool PACKED>
 int skinny_impl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, void* stream,
-                const RopeEpi& rp = RopeEpi()) {
+                const RopeEpi& rp = RopeEpi(), const SkinnyNorm& nm = SkinnyNorm()) {
     const int units = (epilogue == LMI_SKINNY_SWIGLU || epilogue == 4) ? N / 32 : N / 16;
-#define LMI_SK(E) LMI_LAUNCH((skinny_gemm_kernel<T, E, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo, rp)
+#define LMI_SK(E) LMI_LAUNCH((skinny_gemm_kernel<T, E, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo, rp, nm)
     switch (epilogue) {
         case LMI_SKINNY_STORE: LMI_SK(SK_STORE_T); break;
         case LMI_SKINNY_RESIDUAL: LMI_SK(SK_RESID_F32); break;
@@ -451,6 +456,23 @@ int skinny_impl(const void* W, const void* X, void* out, int M, int N, int K, in
     }
 #undef LMI_SK
     return check_launch("lmi_gemm_skinny");
+}
+
+// the folded-norm arguments of lmi_gemm_skinny_ex / lmi_rope_qkv_skinny, checked
+int skinny_norm_args(const char* who, SkinnyNorm& nm, int M, int N, int epilogue, const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps,
+                     void* norm_out, int ld_norm, const float* norm_gamma, float* rowsq_out) {
+    nm = SkinnyNorm();
+    if (rowsq_in) {
+        if (rowsq_parts <= 0 || norm_dim <= 0) return fail(LMI_EINVAL, "%s: rowsq_in needs rowsq_parts > 0 and norm_dim > 0", who);
+        nm.rowsq_in = rowsq_in; nm.parts_in = rowsq_parts; nm.inv_dim = 1.0f / (float)norm_dim; nm.eps = norm_eps;
+    }
+    if (norm_out || rowsq_out || norm_gamma) {
+        if (epilogue != LMI_SKINNY_RESIDUAL || !norm_out || !rowsq_out || !norm_gamma || ld_norm < N)
+            return fail(LMI_EINVAL, "%s: norm_out / norm_gamma / rowsq_out go together, with the residual epilogue (ld_norm >= N)", who);
+        nm.norm_out = norm_out; nm.ld_norm = ld_norm; nm.gamma = norm_gamma; nm.rowsq_out = rowsq_out;
+    }
+    (void)M;
+    return LMI_OK;
 }
 
 template <typename T>
@@ -505,6 +527,7 @@ int lmi_set_option(const char* key, int value) {
             }
     }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "attn.stream_kv")) { g_attn_stream_kv = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "gemv.plan")) { g_gemv_plan = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.gqa_pack")) { g_attn_gqa_pack = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.decode_split_tiles")) {
@@ -934,8 +957,9 @@ int lmi_attn_decode_pool(const void* q, const void* k, const void* v, void* out,
                              n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, window, workspace, workspace_bytes, dtype, stream);
 }
 
-int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed, int dtype,
-                    void* stream) {
+int lmi_gemm_skinny_ex(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed,
+                       const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, int ld_norm, const float* norm_gamma,
+                       float* rowsq_out, int dtype, void* stream) {
     if (!W || !X || !out) return fail(LMI_EINVAL, "lmi_gemm_skinny: null pointer");
     if (M < 0 || M > 16 || N <= 0 || K <= 0 || (K % 128) || epilogue < LMI_SKINNY_STORE || epilogue > LMI_SKINNY_STORE_F32 ||
         (N % (epilogue == LMI_SKINNY_SWIGLU ? 64 : 16)))
@@ -943,32 +967,42 @@ int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K
     if ((ldw & 7) || (ldx & 7) || ldw < K || ldx < K || (packed && ldw != K) || !aligned16(W) || !aligned16(X) ||
         ((epilogue == LMI_SKINNY_RESIDUAL || epilogue == LMI_SKINNY_STORE_F32) ? !aligned16(out) && ((uintptr_t)out & 3) : ((uintptr_t)out & 1)))
         return fail(LMI_EINVAL, "lmi_gemm_skinny: rows must be 16-byte aligned (ldw, ldx multiples of 8 and >= K)");
+    SkinnyNorm nm;
+    if (int rc = skinny_norm_args("lmi_gemm_skinny_ex", nm, M, N, epilogue, rowsq_in, rowsq_parts, norm_dim, norm_eps, norm_out, ld_norm, norm_gamma, rowsq_out))
+        return rc;
     if (M == 0) return LMI_OK;
     if (packed)
-        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)),
-                       (skinny_impl<bf16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)));
-    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)),
-                   (skinny_impl<bf16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream)));
+        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)),
+                       (skinny_impl<bf16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)));
+    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)),
+                   (skinny_impl<bf16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)));
+}
+
+int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed, int dtype,
+                    void* stream) {
+    return lmi_gemm_skinny_ex(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, packed, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, nullptr, dtype, stream);
 }
 
 int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
-                        int ldo, int packed, const float* cos_all, const float* sin_all, void* k_cache, void* v_cache, int ld_cache,
-                        int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream) {
+                        int ldo, int packed, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_all, const float* sin_all,
+                        void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream) {
     if (!Wqkv_rope || !X || !qkv || !cos_all || !sin_all || !k_cache || !v_cache || !pos_rows_dev) return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: null pointer");
     if (head_dim != 128) return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: head_dim %d (only 128)", head_dim);
     const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
     if (M < 0 || M > 16 || n_q_heads <= 0 || n_kv_heads <= 0 || K <= 0 || (K % 128) || (ldw & 7) || (ldx & 7) || ldw < K || ldx < K || (packed && ldw != K) ||
         (ld_cache & 7) || cache_stride <= 0 || ldo < N || !aligned16(Wqkv_rope) || !aligned16(X))
         return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: bad argument (M <= 16, K %% 128 == 0, 16-byte aligned rows)");
+    SkinnyNorm nm;
+    if (int rc = skinny_norm_args("lmi_rope_qkv_skinny", nm, M, N, 4, rowsq_in, rowsq_parts, K, norm_eps, nullptr, 0, nullptr, nullptr)) return rc;
     if (M == 0) return LMI_OK;
     RopeEpi rp;
     rp.cos_all = cos_all; rp.sin_all = sin_all; rp.pos = pos_rows_dev; rp.k_cache = k_cache; rp.v_cache = v_cache; rp.ld_cache = ld_cache;
     rp.cache_stride = (long)cache_stride; rp.rope_q = n_q_heads * head_dim; rp.rope_k = n_kv_heads * head_dim;
     if (packed)
-        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, true>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp)),
-                       (skinny_impl<bf16_t, true>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp)));
-    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp)),
-                   (skinny_impl<bf16_t, false>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp)));
+        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, true>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)),
+                       (skinny_impl<bf16_t, true>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
+    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)),
+                   (skinny_impl<bf16_t, false>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
 }
 
 int lmi_rope_qk_rows(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all, const float* sin_all,

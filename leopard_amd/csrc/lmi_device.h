@@ -79,9 +79,11 @@ struct BufRsrc {
 LMI_DEV BufRsrc make_buf(const void* base, unsigned num_records) {
     return BufRsrc{__builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)num_records, 0x00020000)};
 }
+// AUX = 2: non-temporal (a stream every byte of which is read once — the K / V cache of a decode step).
+template <int AUX = 0>
 LMI_DEV void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset,
-                                             (int)soffset, 0, 0);
+                                             (int)soffset, 0, AUX);
 }
 
 // D[32x32] += A[32x64] * B[64x32] on fp8 e4m3 operands at twice the 16-bit MFMA rate (v_mfma_scale_f32_32x32x64_f8f6f4; the
@@ -298,6 +300,7 @@ struct BufRsrc {
     unsigned num_records;
 };
 inline BufRsrc make_buf(const void* base, unsigned num_records) { return BufRsrc{(const char*)base, num_records}; }
+template <int AUX = 0>
 inline void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
     char* dst = (char*)lds_wave_base + lane_id() * 16;
     const unsigned long off = (unsigned long)voffset + soffset;

@@ -30,16 +30,39 @@ enum { SK_STORE_T = 0, SK_RESID_F32 = 1, SK_SWIGLU_T = 2, SK_STORE_F32 = 3, SK_Q
 // Row m of the batch rotates at its own position pos[m] (device memory) and appends K / V to row m * cache_stride + pos[m] of the pooled
 // caches; v rows (natural order) are two independent blocks.
 
+// The RMSNorms of the batched decode step folded into its projections, as lmi_gemm_ex does for the prefill (gemm.h GemmRowScale):
+//   producer (SK_RESID_F32, norm_out != null): after x += acc it also writes norm_out[m, n] = T(x[m, n] * gamma[n]) — the next norm's
+//       gain applied, its row scale still missing — and rowsq_out[m, unit] = the sum of x[m, n]^2 over the unit's 16 columns (one
+//       partial per workgroup and row, written once: no atomics, bit-reproducible);
+//   consumer (any epilogue, rowsq_in != null): accumulator row m is multiplied by rstd[m] = rsqrt(sum_j rowsq_in[m, j] / norm_dim + eps)
+//       before RoPE / SwiGLU / store; the partials are summed in a fixed order (32 lanes per row: strided partial sums, then a butterfly).
+struct SkinnyNorm {
+    const float* rowsq_in;    // [M, parts_in] or null
+    int parts_in;
+    float inv_dim, eps;
+    void* norm_out;           // T [M, ld_norm] or null (SK_RESID_F32 only)
+    int ld_norm;
+    const float* gamma;       // [N]
+    float* rowsq_out;         // [M, N / 16]
+};
+
 template <typename T, int EPI, bool PACKED>
-__global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, RopeEpi rp) {
+__global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, RopeEpi rp,
+                                                          SkinnyNorm nm) {
     typedef typename vec_of<T>::x8 T8;
     constexpr bool PAIR = (EPI == SK_SWIGLU_T || EPI == SK_QKV_ROPE_T);
     constexpr int NW = PAIR ? 2 : 1;                               // weight row blocks per workgroup (gate, up / first half, rotate-half partner)
     constexpr int DEPTH = PAIR ? 2 : 3;                            // k-steps of loads in flight per wave (<= 128 VGPRs: two workgroups per CU)
     __shared__ float part[8][NW][64][4];
+    __shared__ float rstd_s[16], sq_s[16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int i = lane & 15, g = lane >> 4;
     const int unit = blockIdx.x;
+    // consumer: this thread's share of the row-sum-of-squares partials (row tid >> 5, partials (tid & 31), + 32, ...): requested first,
+    // reduced after the main loop
+    float ssq = 0.f;
+    if (nm.rowsq_in && (tid >> 5) < M)
+        for (int q = tid & 31; q < nm.parts_in; q += 32) ssq += nm.rowsq_in[(long)(tid >> 5) * nm.parts_in + q];
     // first weight row of block b: plain = 16 rows per unit; SwiGLU = unit u -> 64-row group u >> 1, half u & 1: gate rows at +16 * half,
     // their up partners 32 rows further
     const int row0 = PAIR ? (unit >> 1) * 64 + (unit & 1) * 16 : unit * 16;
@@ -91,6 +114,11 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
     }
 #pragma unroll
     for (int b = 0; b < NW; ++b) *(f32x4*)part[wave][b][lane] = acc[b];
+    if (nm.rowsq_in) {
+#pragma unroll
+        for (int msk = 16; msk >= 1; msk >>= 1) ssq += shfl_xor(ssq, msk);      // the 32 lanes of one row (a half wave)
+        if ((tid & 31) == 0) rstd_s[tid >> 5] = 1.0f / sqrtf(ssq * nm.inv_dim + nm.eps);
+    }
     __syncthreads();
     // D[n][m]: lane l, register r -> n = 4 (l >> 4) + r, m = l & 15.  Thread t < 256 finishes element (l = t & 63, r = t >> 6).
     if (tid < 256) {
@@ -102,7 +130,7 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
             float s = part[0][b][l][r];
 #pragma unroll
             for (int w = 1; w < 8; ++w) s += part[w][b][l][r];     // fixed order: results do not depend on timing
-            v[b] = s;
+            v[b] = nm.rowsq_in ? s * rstd_s[m] : s;
         }
         if (m < M) {
             if (EPI == SK_QKV_ROPE_T) {
@@ -139,8 +167,23 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
             } else if (EPI == SK_STORE_F32) {
                 ((float*)out)[(long)m * ldo + row0 + n] = v[0];
             } else {
-                ((float*)out)[(long)m * ldo + row0 + n] += v[0];
+                float* xo = (float*)out + (long)m * ldo + row0 + n;
+                const float xn = *xo + v[0];
+                *xo = xn;
+                if (nm.norm_out) {
+                    ((T*)nm.norm_out)[(long)m * nm.ld_norm + row0 + n] = (T)(xn * nm.gamma[row0 + n]);
+                    sq_s[n][m] = xn * xn;
+                }
             }
+        }
+    }
+    if (EPI == SK_RESID_F32 && nm.norm_out) {
+        __syncthreads();
+        if (tid < M) {
+            float q = 0.f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) q += sq_s[n][tid];
+            nm.rowsq_out[(long)tid * (N >> 4) + unit] = q;
         }
     }
 }

@@ -120,6 +120,7 @@ class LeopardEngine:
         # 16-bit values (lmi_split_hi_lo) and multiplied against [W | W] — the GEMMs run at 2 K, the hand-over roundings that make up the
         # distance to the fp32 reference are gone (full-depth logits within north_star's 1e-3; ~1.8x the prefill time).  Prefill only.
         self.split_operands = False
+        self.skinny_fold_norm = True   # batched decode: RMSNorms folded into the projections (lmi_gemm_skinny_ex producer / consumer); False: norm launches
         self.skinny_packed = True      # batched decode: stream the projections from a copy in the MFMA operand order (coalesced 1-KiB loads)
         self.fp8_fused = True          # fp8 schedule: attention writes the fp8 o_proj operand, q|k|v GEMM does RoPE + KV append (False: separate launches)
         self._fp8 = None               # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
@@ -982,6 +983,7 @@ class LeopardEngine:
         st.x = self._empty(B, D, dtype=torch.float32)
         st.h, st.qkv, st.att = self._empty(B, D), self._empty(B, (H + 2 * KV) * hd), self._empty(B, H * hd)
         st.gu = self._empty(B, W.llm_ff)
+        st.sq_a, st.sq_b = self._empty(B, D // 16, dtype=torch.float32), self._empty(B, D // 16, dtype=torch.float32)   # folded-norm partials
         st.logits = self._empty(B, W.lm_head.shape[0], dtype=torch.float32)
         st.cos, st.sin = self.rope_tables(torch.arange(cap))
         st.ws = torch.empty(self.ops.decode_workspace_elems(B, H, hd, cap), dtype=torch.float32, device=dev)
@@ -1009,22 +1011,37 @@ class LeopardEngine:
         qw, eps = H * hd, tc.rms_norm_eps
         ops.embed_merge(st.tok, st.src, W.embed, None, st.x)
         pk = self._skinny_weights() if self.skinny_packed else None
+        packed = pk is not None
+        D, n_layers = tc.hidden_size, len(W.llm_layers)
+        # folded RMSNorms (as the prefill's fused schedule): every residual projection (o_proj, down_proj) also emits T(x * gamma_next) and
+        # per-row partial sums of squares, the projection that consumes them scales its accumulator rows by rstd — only the first
+        # layer's norm and the final one stay launches of their own
+        fold = self.skinny_fold_norm and D % 16 == 0 and all(L.qkv_w_rope is not None for L in W.llm_layers) and hd == 128
         for i, L in enumerate(W.llm_layers):
             rope_fused = L.qkv_w_rope is not None and hd == 128
             qkv_w, o_w, gu_w, down_w = pk["layers"][i] if pk else (L.qkv_w_rope if rope_fused else L.qkv_w, L.o_w, L.gu_w, L.down_w)
-            packed = pk is not None
-            ops.rmsnorm(st.x, L.in_norm, st.h, eps)
+            if not fold or i == 0:
+                ops.rmsnorm(st.x, L.in_norm, st.h, eps)
             if rope_fused:
-                ops.rope_qkv_skinny(qkv_w, st.h, st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos, packed)
+                ops.rope_qkv_skinny(qkv_w, st.h, st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos, packed,
+                                    rowsq_in=st.sq_b if fold and i > 0 else None, norm_eps=eps)
             else:
                 ops.gemm_skinny(qkv_w, st.h, st.qkv, 0, packed)
                 ops.rope_qk_rows(st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos)
             ops.attention_decode_pool(st.qkv[:, :qw], st.k[i], st.v[i], st.att, st.cu_q, st.k_begin, st.k_len, st.capacity, H, KV, hd,
                                       hd ** -0.5, st.ws, window=tc.sliding_window or 0)
-            ops.gemm_skinny(o_w, st.att, st.x, 1, packed)
-            ops.rmsnorm(st.x, L.post_norm, st.h, eps)
-            ops.gemm_skinny(gu_w, st.h, st.gu, 2, packed)
-            ops.gemm_skinny(down_w, st.gu, st.x, 1, packed)
+            if fold:
+                ops.gemm_skinny(o_w, st.att, st.x, 1, packed, norm_out=st.h, norm_gamma=L.post_norm, rowsq_out=st.sq_a)
+                ops.gemm_skinny(gu_w, st.h, st.gu, 2, packed, rowsq_in=st.sq_a, norm_dim=D, norm_eps=eps)
+                if i + 1 < n_layers:
+                    ops.gemm_skinny(down_w, st.gu, st.x, 1, packed, norm_out=st.h, norm_gamma=W.llm_layers[i + 1].in_norm, rowsq_out=st.sq_b)
+                else:
+                    ops.gemm_skinny(down_w, st.gu, st.x, 1, packed)
+            else:
+                ops.gemm_skinny(o_w, st.att, st.x, 1, packed)
+                ops.rmsnorm(st.x, L.post_norm, st.h, eps)
+                ops.gemm_skinny(gu_w, st.h, st.gu, 2, packed)
+                ops.gemm_skinny(down_w, st.gu, st.x, 1, packed)
         # head: one pass over lm_head for all B rows (lmi_lm_head_last streams the 1 GB head once PER row)
         ops.rmsnorm(st.x, W.final_norm, st.h, eps)
         ops.gemm_skinny(pk["head"] if pk else W.lm_head, st.h, st.logits, 3, pk is not None)

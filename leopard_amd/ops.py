@@ -168,20 +168,30 @@ class Ops:
                                               _ptr(pos_rows), _DT[qkv.dtype], self._stream(qkv)))
         return qkv
 
-    def gemm_skinny(self, w, x, out, epilogue=0, packed=False):
+    def gemm_skinny(self, w, x, out, epilogue=0, packed=False, rowsq_in=None, norm_dim=0, norm_eps=0.0, norm_out=None, norm_gamma=None, rowsq_out=None):
         """out[M <= 16, .] = epilogue(x @ w.T): the projections of a batched decode step.  epilogue: 0 store T, 1 fp32 +=,
-        2 SwiGLU (w rows interleaved [32 gate | 32 up], out [M, N/2]), 3 store fp32.  packed: w is weights.skinny_pack(w) (same shape)."""
+        2 SwiGLU (w rows interleaved [32 gate | 32 up], out [M, N/2]), 3 store fp32.  packed: w is weights.skinny_pack(w) (same shape).
+        rowsq_in / norm_out + norm_gamma + rowsq_out: the folded RMSNorm of lmi_gemm_skinny_ex (consumer / producer side)."""
         N, K = w.shape
         M = x.shape[0]
-        self._check(self.lib.lmi_gemm_skinny(_ptr(w), _ptr(x), _ptr(out), M, N, K, w.stride(0), x.stride(0), out.stride(0), int(epilogue),
-                                             int(bool(packed)), _DT[w.dtype], self._stream(out)))
+        if rowsq_in is None and norm_out is None:
+            self._check(self.lib.lmi_gemm_skinny(_ptr(w), _ptr(x), _ptr(out), M, N, K, w.stride(0), x.stride(0), out.stride(0), int(epilogue),
+                                                 int(bool(packed)), _DT[w.dtype], self._stream(out)))
+            return out
+        self._check(self.lib.lmi_gemm_skinny_ex(_ptr(w), _ptr(x), _ptr(out), M, N, K, w.stride(0), x.stride(0), out.stride(0), int(epilogue),
+                                                int(bool(packed)), _ptr(rowsq_in), 0 if rowsq_in is None else rowsq_in.shape[1], int(norm_dim),
+                                                float(norm_eps), _ptr(norm_out), 0 if norm_out is None else norm_out.stride(0), _ptr(norm_gamma),
+                                                _ptr(rowsq_out), _DT[w.dtype], self._stream(out)))
         return out
 
-    def rope_qkv_skinny(self, w_rope, x, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, cache_stride, pos_rows, packed=False):
-        """lmi_rope_qkv_skinny: batched-decode q|k|v projection with RoPE + KV append in the epilogue (w_rope in rope_permute_rows order)."""
+    def rope_qkv_skinny(self, w_rope, x, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, cache_stride, pos_rows, packed=False,
+                        rowsq_in=None, norm_eps=0.0):
+        """lmi_rope_qkv_skinny: batched-decode q|k|v projection with RoPE + KV append in the epilogue (w_rope in rope_permute_rows order);
+        rowsq_in: consumer side of the folded RMSNorm."""
         M, K = x.shape[0], w_rope.shape[1]
         self._check(self.lib.lmi_rope_qkv_skinny(_ptr(w_rope), _ptr(x), _ptr(qkv), M, n_q_heads, n_kv_heads, head_dim, K, w_rope.stride(0), x.stride(0),
-                                                 qkv.stride(0), int(bool(packed)), _ptr(cos_all), _ptr(sin_all), _ptr(k_cache), _ptr(v_cache),
+                                                 qkv.stride(0), int(bool(packed)), _ptr(rowsq_in), 0 if rowsq_in is None else rowsq_in.shape[1],
+                                                 float(norm_eps), _ptr(cos_all), _ptr(sin_all), _ptr(k_cache), _ptr(v_cache),
                                                  k_cache.stride(0), int(cache_stride), _ptr(pos_rows), _DT[w_rope.dtype], self._stream(qkv)))
         return qkv
 

@@ -131,6 +131,24 @@ def test_generate_batch_decodes_the_batch_together_and_equals_per_sample_generat
     st = eng._batch_states[3]
     again = eng.generate_batch(samples, max_new_tokens=5, eos_token_id=eos)      # state (pool, buffers) reused, same result
     assert eng._batch_states[3] is st and all(torch.equal(a, b) for a, b in zip(batch, again))
+    # the RMSNorms folded into the projections (default) vs as launches of their own: the same tokens, and only 2 norm launches per step
+    norms = []
+    rms = ops.rmsnorm
+    ops.rmsnorm = lambda *a, **k: (norms.append(1), rms(*a, **k))[1]
+    try:
+        calls.clear(); norms.clear()
+        eng.generate_batch(samples, max_new_tokens=5, eos_token_id=eos)
+        folded = len(norms) / len(calls)
+        eng.skinny_fold_norm = False
+        calls.clear(); norms.clear()
+        plain = eng.generate_batch(samples, max_new_tokens=5, eos_token_id=eos)
+        unfolded = len(norms) / len(calls)
+    finally:
+        ops.rmsnorm = rms
+        eng.skinny_fold_norm = True
+    assert all(torch.equal(a, b) for a, b in zip(batch, plain))
+    n_layers = len(W.llm_layers)
+    assert unfolded - folded == 2 * n_layers - 1, (folded, unfolded)
 
 
 def test_split_operand_mode_removes_the_hand_over_roundings(setup):

@@ -670,6 +670,69 @@ def test_rope_qkv_skinny_equals_projection_then_rope_rows(ops, packed):
     assert not kp[~touched].any() and not vp[~touched].any()
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemm_skinny_folded_rmsnorm_producer_and_consumers(ops, packed):
+    """lmi_gemm_skinny_ex: the residual projection also emits T(x * gamma) and per-16-column sums of squares (producer); the SwiGLU
+    projection and lmi_rope_qkv_skinny scale their accumulator rows by rstd from those partials (consumers) — against the norm launch
+    followed by the plain projections, and against fp32."""
+    from leopard_amd.weights import rope_permute_rows, skinny_pack
+    dtype, M, D, K0, eps = torch.float16, 5, 256, 384, 1e-5
+    pk = skinny_pack if packed else (lambda w: w)
+    a, w_o = rnd((M, K0), dtype, 1), rnd((D, K0), dtype, 2, 0.1)
+    x0, gamma = rnd((M, D), torch.float32, 3, 2.0), rnd((D,), torch.float32, 4) + 1.0
+    # producer
+    x = x0.clone()
+    h = torch.full((M + 1, D), 7.0, dtype=dtype)
+    sq = torch.full((M + 1, D // 16), 7.0)
+    ops.gemm_skinny(pk(w_o), a, x, 1, packed, norm_out=h[:M], norm_gamma=gamma, rowsq_out=sq[:M])
+    x_ref = x0.clone()
+    ops.gemm_skinny(pk(w_o), a, x_ref, 1, packed)
+    assert torch.equal(x, x_ref)                                     # the residual itself is untouched by the extra outputs
+    assert torch.equal(h[:M], (x * gamma).to(dtype)) and bool((h[M] == 7.0).all()) and bool((sq[M] == 7.0).all())
+    want_sq = (x.double() ** 2).view(M, D // 16, 16).sum(-1)
+    assert (sq[:M].double() - want_sq).abs().max() <= 1e-5 * want_sq.abs().max()
+    rstd = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + eps)
+    # consumer, SwiGLU
+    F = 128
+    w_gu = rnd((2 * F, D), dtype, 5, 0.1)
+    gu = torch.zeros(M, F, dtype=dtype)
+    ops.gemm_skinny(pk(w_gu), h[:M], gu, 2, packed, rowsq_in=sq[:M], norm_dim=D, norm_eps=eps)
+    lin = (h[:M].double() @ w_gu.double().T) * rstd
+    lv = lin.view(M, 2 * F // 64, 2, 32)
+    want = (torch.nn.functional.silu(lv[:, :, 0]) * lv[:, :, 1]).reshape(M, F)
+    assert (gu.double() - want).abs().max() <= tol(dtype) * max(1.0, want.abs().max().item())
+    hn = torch.zeros(M, D, dtype=dtype)                               # the unfused schedule: norm launch, plain projection
+    ops.rmsnorm(x, gamma, hn, eps)
+    gu2 = torch.zeros(M, F, dtype=dtype)
+    ops.gemm_skinny(pk(w_gu), hn, gu2, 2, packed)
+    assert (gu.float() - gu2.float()).abs().max() <= 2 * tol(dtype) * max(1.0, want.abs().max().item())
+    # consumer, q|k|v + RoPE
+    H, KV, hd, cap = 2, 1, 128, 12
+    w = rnd(((H + 2 * KV) * hd, D), dtype, 6, 0.1)
+    w_rope = torch.cat([rope_permute_rows(w[:(H + KV) * hd]), w[(H + KV) * hd:]]).contiguous()
+    f = torch.arange(cap).float().reshape(-1, 1) * (1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    pos = torch.tensor([4, 0, 11, 3, 7], dtype=torch.int32)
+    outs = []
+    for xin, rs in ((h[:M], sq[:M]), (hn, None)):
+        kp, vp = torch.zeros(M * cap, KV * hd, dtype=dtype), torch.zeros(M * cap, KV * hd, dtype=dtype)
+        got = torch.zeros(M, (H + 2 * KV) * hd, dtype=dtype)
+        ops.rope_qkv_skinny(pk(w_rope), xin, got, H, KV, hd, cos, sin, kp, vp, cap, pos, packed=packed, rowsq_in=rs, norm_eps=eps)
+        outs.append((got, kp, vp))
+    scale = max(1.0, outs[1][0].float().abs().max().item())
+    for g, u in zip(outs[0], outs[1]):
+        assert (g.float() - u.float()).abs().max() <= 2 * tol(dtype) * scale
+    lin = ((h[:M].double() @ w.double().T) * rstd).float()
+    ref = lin.clone()
+    for s_ in range(M):
+        c, sn = cos[pos[s_]], sin[pos[s_]]
+        for hh in range(H + KV):
+            a_, b_ = lin[s_, hh * hd:hh * hd + 64], lin[s_, hh * hd + 64:(hh + 1) * hd]
+            ref[s_, hh * hd:hh * hd + 64] = a_ * c - b_ * sn
+            ref[s_, hh * hd + 64:(hh + 1) * hd] = b_ * c + a_ * sn
+    assert (outs[0][0].float() - ref).abs().max() <= tol(dtype) * scale
+
+
 def test_gemv_rmsnorm_rope_equals_norm_projection_rope(ops):
     """lmi_gemv_rmsnorm_rope (batch-1 decode: RMSNorm + q|k|v projection + RoPE + KV append in one launch) vs the fp32 statement, and
     within one 16-bit rounding of lmi_gemv_rmsnorm + lmi_rope_qk_at; cache rows other than *pos untouched."""

@@ -438,6 +438,64 @@ def test_rope_qkv_skinny_llama_shape(ops, dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 8, 16])
+def test_gemm_skinny_folded_rmsnorm_llama_shapes(ops, dtype, M):
+    """lmi_gemm_skinny_ex at the Llama-3.1-8B decode shapes: the o_proj producer (residual + T(x gamma) + 256 row-square partials per row)
+    feeding the gate/up SwiGLU consumer and the q|k|v + RoPE consumer, against the norm launch + plain projections and fp32 on the
+    device; launches agree bit for bit."""
+    from leopard_amd.weights import rope_permute_rows, skinny_pack
+    D, FF, H, KV, hd, cap, eps_n = 4096, 14336, 32, 8, 128, 512, 1e-5
+    a, w_o = rnd((M, D), dtype, 81), skinny_pack(rnd((D, D), dtype, 82, 0.02))
+    x0, gamma = rnd((M, D), torch.float32, 83, 2.0), rnd((D,), torch.float32, 84) + 1.0
+    runs = []
+    for _ in range(2):
+        x = x0.clone()
+        h, sq = torch.zeros(M, D, dtype=dtype, device=DEV), torch.zeros(M, D // 16, device=DEV)
+        ops.gemm_skinny(w_o, a, x, 1, True, norm_out=h, norm_gamma=gamma, rowsq_out=sq)
+        runs.append((x, h, sq))
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(runs[0], runs[1]))
+    x, h, sq = runs[0]
+    check(h, x * gamma, dtype, k=1.0, what="producer norm_out")    # one rounding of x * gamma (the device may round the product once, torch twice)
+    want_sq = (x.double() ** 2).view(M, D // 16, 16).sum(-1)
+    assert (sq.double() - want_sq).abs().max() <= 1e-5 * want_sq.abs().max()
+    rstd = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + eps_n)
+    hn = torch.zeros(M, D, dtype=dtype, device=DEV)
+    ops.rmsnorm(x, gamma, hn, eps_n)
+    # gate / up
+    w_gu = rnd((2 * FF, D), dtype, 85, 0.02)
+    wp = skinny_pack(w_gu)
+    gu, gu2 = torch.zeros(M, FF, dtype=dtype, device=DEV), torch.zeros(M, FF, dtype=dtype, device=DEV)
+    ops.gemm_skinny(wp, h, gu, 2, True, rowsq_in=sq, norm_dim=D, norm_eps=eps_n)
+    ops.gemm_skinny(wp, hn, gu2, 2, True)
+    lv = ((h.double() @ w_gu.double().T) * rstd).view(M, 2 * FF // 64, 2, 32)
+    want = (torch.nn.functional.silu(lv[:, :, 0]) * lv[:, :, 1]).reshape(M, FF).float()
+    check(gu, want, dtype, k=4.0, what="folded gate/up")
+    check(gu, gu2, dtype, k=6.0, what="folded vs norm launch, gate/up")
+    # q | k | v + RoPE
+    w = rnd(((H + 2 * KV) * hd, D), dtype, 86, 0.02)
+    w_rope = skinny_pack(torch.cat([rope_permute_rows(w[:(H + KV) * hd]), w[(H + KV) * hd:]]).contiguous())
+    f = torch.arange(cap, device=DEV).float().reshape(-1, 1) * (1.0 / (500000.0 ** (torch.arange(0, hd, 2, device=DEV).float() / hd))).reshape(1, -1)
+    cos, sin = f.cos().contiguous(), f.sin().contiguous()
+    pos = ((torch.arange(M, dtype=torch.int64) * 97 + 300) % cap).to(torch.int32).to(DEV)
+    outs = []
+    for xin, rs in ((h, sq), (hn, None)):
+        kp, vp = torch.zeros(M * cap, KV * hd, dtype=dtype, device=DEV), torch.zeros(M * cap, KV * hd, dtype=dtype, device=DEV)
+        got = torch.zeros(M, (H + 2 * KV) * hd, dtype=dtype, device=DEV)
+        ops.rope_qkv_skinny(w_rope, xin, got, H, KV, hd, cos, sin, kp, vp, cap, pos, packed=True, rowsq_in=rs, norm_eps=eps_n)
+        outs.append((got, kp, vp))
+    for g, u in zip(outs[0], outs[1]):
+        check(g, u, dtype, k=6.0, what="folded vs norm launch, q|k|v")
+    lin = ((h.double() @ w.double().T) * rstd).float().view(M, H + 2 * KV, hd)
+    c, sn = cos[pos.long()].unsqueeze(1), sin[pos.long()].unsqueeze(1)
+    ref = lin.clone()
+    a_, b_ = lin[:, :H + KV, :64], lin[:, :H + KV, 64:]
+    ref[:, :H + KV, :64] = a_ * c - b_ * sn
+    ref[:, :H + KV, 64:] = b_ * c + a_ * sn
+    check(outs[0][0], ref.view(M, -1), dtype, k=4.0, what="folded q|k|v")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemv_rmsnorm_rope_llama_shape(ops, dtype):
     """lmi_gemv_rmsnorm_rope at the Llama-3.1-8B decode shape vs fp32 on the device and vs lmi_gemv_rmsnorm + lmi_rope_qk_at (V bit for
     bit — no rotation; q / k within a rounding: the fused launch rotates the unrounded sums); launches agree bit for bit; only cache row
