@@ -19,6 +19,12 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_f16 -o f16 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/final/prof_f16_bench.json 2> $R/gpurun_out/final/prof_f16.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_fp8 -o fp8 -- python $R/bench.py --dtype fp8 --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/final/prof_fp8_bench.json 2> $R/gpurun_out/final/prof_fp8.err
 cd $R
+# decode, batch 1 (short context) and batch 8: per-kernel durations
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_dec1 -o dec1 -- python $R/tools/bench_decode.py --tiles 1 --tokens 64 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_dec8 -o dec8 -- python $R/tools/bench_decode.py --skip-single --tiles 1 --batch 8 --tokens 64 > /dev/null 2>&1
+cd $R
+for d in prof_dec1 prof_dec8; do f=$(find gpurun_out/final/$d -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/final/${d}_kernel_stats.csv; rm -rf gpurun_out/final/$d; done
 for d in prof_f16 prof_fp8; do f=$(find gpurun_out/final/$d -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/final/${d}_kernel_stats.csv; rm -rf gpurun_out/final/$d; done
 for f in gpurun_out/final/bench_*.json; do echo "$f: $(cut -c1-260 $f)"; done
 head -12 gpurun_out/final/prof_fp8_kernel_stats.csv | cut -c1-200
