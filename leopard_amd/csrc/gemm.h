@@ -368,7 +368,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                         *(f32x4*)d32 = f32x4{fast_silu(g0[0]) * u0[0], fast_silu(g0[1]) * u0[1], fast_silu(g0[2]) * u0[2], fast_silu(g0[3]) * u0[3]};
                         *(f32x4*)(d32 + 4) = f32x4{fast_silu(g1[0]) * u1[0], fast_silu(g1[1]) * u1[1], fast_silu(g1[2]) * u1[2], fast_silu(g1[3]) * u1[3]};
                     } else {
-                        *(T8*)((T*)p.out + orow * p.ldo + (nw0 >> 1) + oc) = o;
+                        st_epi<2>((T8*)((T*)p.out + orow * p.ldo + (nw0 >> 1) + oc), o);
                     }
                 }
             }
@@ -398,8 +398,8 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
             }
             if (EPI == EPI_RESID_F32) {
                 const float* drow = (const float*)p.out + orow[it] * p.ldo + nw0 + oc;
-                old0[it] = *(const f32x4*)drow;
-                old1[it] = *(const f32x4*)(drow + 4);
+                old0[it] = ld_epi<1>((const f32x4*)drow);
+                old1[it] = ld_epi<1>((const f32x4*)(drow + 4));
             }
         }
         wave_lds_fence();
@@ -426,11 +426,11 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 const float os = (sizeof(T) == 1) ? p.out_scale : 1.0f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o[e] = OutCvt<T>::cvt(v0[it][e] * os); o[4 + e] = OutCvt<T>::cvt(v1[it][e] * os); }
-                *(T8*)((T*)p.out + orow[it] * p.ldo + nw0 + oc) = o;
+                st_epi<2>((T8*)((T*)p.out + orow[it] * p.ldo + nw0 + oc), o);
             } else {
                 float* drow = (float*)p.out + orow[it] * p.ldo + nw0 + oc;
-                *(f32x4*)drow = v0[it];
-                *(f32x4*)(drow + 4) = v1[it];
+                st_epi<1>((f32x4*)drow, v0[it]);
+                st_epi<1>((f32x4*)(drow + 4), v1[it]);
                 if (EPI == EPI_RESID_F32 && p.norm_out) {
                     // the next RMSNorm, started here: gain applied and rounded; its row scale is finished by the consumer GEMM
                     T8 hn;

@@ -395,6 +395,27 @@ template <typename V> LMI_DEV V ld_stream(const V* p) {
     return *p;
 #endif
 }
+// GEMM epilogue traffic with a non-temporal hint, by class (LMI_EPI_NT bits; compile-time, so that an A/B is two builds of the library
+// on one box — LEOPARD_AMD_LIB): bit 1 = the fp32 residual read-modify-write, bit 2 = the 16-bit / fp8 outputs of the store / GELU /
+// SwiGLU epilogues (hundreds of MB per launch, written once: without the hint they are write-allocated in L2 over the operand tiles
+// the other workgroups are re-reading).  Measured on the C3 step, two boxes, two rounds each: bit 1 +-0.0 %, bit 2 -0.3 ... -0.6 %
+// (production), the same hint on the q | k | v rows / the attention output +0.4 % (the next launch wants them cached), on the prefill's
+// KV-cache append +-0.0 %.
+#ifndef LMI_EPI_NT
+#define LMI_EPI_NT 2
+#endif
+template <int BIT, typename V> LMI_DEV void st_epi(V* p, V v) {
+#if !defined(LMI_EMU)
+    if (LMI_EPI_NT & BIT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
+}
+template <int BIT, typename V> LMI_DEV V ld_epi(const V* p) {
+#if !defined(LMI_EMU)
+    if (LMI_EPI_NT & BIT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
 LMI_DEV int imin(int a, int b) { return a < b ? a : b; }
 LMI_DEV int imax(int a, int b) { return a > b ? a : b; }
 template <typename T> LMI_DEV float to_f32(T v) { return (float)v; }
