@@ -670,13 +670,13 @@ def test_rope_qkv_skinny_equals_projection_then_rope_rows(ops, packed):
     assert not kp[~touched].any() and not vp[~touched].any()
 
 
-@pytest.mark.parametrize("packed", [False, True])
-def test_gemm_skinny_folded_rmsnorm_producer_and_consumers(ops, packed):
+@pytest.mark.parametrize("packed,M,D", [(False, 5, 256), (True, 5, 256), (True, 16, 640), (False, 1, 384)])
+def test_gemm_skinny_folded_rmsnorm_producer_and_consumers(ops, packed, M, D):
     """lmi_gemm_skinny_ex: the residual projection also emits T(x * gamma) and per-16-column sums of squares (producer); the SwiGLU
     projection and lmi_rope_qkv_skinny scale their accumulator rows by rstd from those partials (consumers) — against the norm launch
     followed by the plain projections, and against fp32."""
     from leopard_amd.weights import rope_permute_rows, skinny_pack
-    dtype, M, D, K0, eps = torch.float16, 5, 256, 384, 1e-5
+    dtype, K0, eps = torch.float16, 384, 1e-5                        # D / 16 partials per row: fewer than, equal to and more than the 32 lanes that sum them
     pk = skinny_pack if packed else (lambda w: w)
     a, w_o = rnd((M, K0), dtype, 1), rnd((D, K0), dtype, 2, 0.1)
     x0, gamma = rnd((M, D), torch.float32, 3, 2.0), rnd((D,), torch.float32, 4) + 1.0
@@ -712,7 +712,7 @@ def test_gemm_skinny_folded_rmsnorm_producer_and_consumers(ops, packed):
     w_rope = torch.cat([rope_permute_rows(w[:(H + KV) * hd]), w[(H + KV) * hd:]]).contiguous()
     f = torch.arange(cap).float().reshape(-1, 1) * (1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))).reshape(1, -1)
     cos, sin = f.cos().contiguous(), f.sin().contiguous()
-    pos = torch.tensor([4, 0, 11, 3, 7], dtype=torch.int32)
+    pos = torch.tensor([4, 0, 11, 3, 7, 1, 2, 5, 6, 8, 9, 10, 0, 11, 4, 3][:M], dtype=torch.int32)
     outs = []
     for xin, rs in ((h[:M], sq[:M]), (hn, None)):
         kp, vp = torch.zeros(M * cap, KV * hd, dtype=dtype), torch.zeros(M * cap, KV * hd, dtype=dtype)
