@@ -57,6 +57,11 @@ int lmi_abi_version(void);
  *   "gemm.order"    0 = each XCD owns a contiguous slab of the tile order (default), 1 = round-robin 32-tile patches
  *   "attn.dma"      1 = LDS-DMA attention kernel (default), 0 = register-staged cross-check kernel
  *   "attn.lds_pad"  extra dynamic LDS per attention workgroup in bytes (lowers residency; default 0)
+ *   "attn.gqa_pack" 1 = decode blocks take the 4 query heads of one kv head (default), 0 = one block per query head
+ *   "attn.decode_split_tiles"  64-key tiles per split-KV decode workgroup: 0 = chosen from the launch shape (default), 1 / 2 / 4 / 8
+ *   "attn.stream_kv"  1 = non-temporal K / V tile loads in GQA-packed decode blocks (default), 0 = default cache policy
+ *   "gemv.plan"     1 = decode GEMV grid of a whole number of equal workgroups per CU when the shape allows (default), 0 = ~1000 workgroups
+ *   "gemm.mid_m" / "gemm.auto_small"  M-complete 384 x 128 tiles for 256 < M <= 384 / small-shape geometries (default 1)
  * Unknown keys and out-of-range values return LMI_EINVAL. */
 int lmi_set_option(const char* key, int value);
 
