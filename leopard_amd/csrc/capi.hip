@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "attention.h"
+#include "attention64.h"
 #include "elementwise.h"
 #include "patch_embed.h"
 #include "gemm.h"
@@ -266,8 +267,41 @@ int launch_attn_dma(const AttnArgs& a, int n_seq, int max_q, void* stream) {
     return check_launch("lmi_attn_varlen_fwd");
 }
 
+// Software-pipelined attention (attention64.h): long self-attention prefills at head_dim 128 writing the plain 16-bit output.  OPT-IN
+// (attn.rows64; 0 = attention.h's kernel, the default): measured on the Llama shape (S = 7187, f16; profiles/r04_attention64_study.txt)
+// 1 = two 32-row blocks per wave, one wave per SIMD: 0.572 ms; 2 = one block per wave, two waves per SIMD: 0.505 ms; attention.h 0.442 ms
+// — a single hand-interleaved instruction stream per wave loses to two independent workgroups per CU on this part (the issue port, not
+// the matrix pipe, is what the softmax competes for).  attn.rows64_min: shortest max_seqlen_q that takes the opt-in kernel.
+std::atomic<int> g_attn_rows64{0};
+std::atomic<int> g_attn_rows64_min{1024};
+template <typename T, bool CAUSAL, int NBLK>
+int launch_attn_r64(const AttnArgs& a, int n_seq, int max_q, void* stream) {
+    typedef Attn64Geom<NBLK> G;
+    const int qblocks = (max_q + G::BQ - 1) / G::BQ;
+    static std::atomic<uint64_t> attr_done{0};
+    allow_big_lds(attn_fwd_r64_kernel<T, CAUSAL, NBLK>, G::SMEM, attr_done);
+    AttnArgs b = a;
+    b.n_qblocks = qblocks;
+    LMI_LAUNCH((attn_fwd_r64_kernel<T, CAUSAL, NBLK>), dim3(qblocks * a.n_heads * n_seq), dim3(G::NT), G::SMEM, stream, b);
+    return check_launch("lmi_attn_varlen_fwd");
+}
+template <typename T, int D>
+bool attn_r64_applies(const AttnArgs& a, int max_q, int use_tr) {
+    if (D != 128 || !use_tr || !g_attn_dma.load() || !g_attn_rows64.load() || max_q < g_attn_rows64_min.load()) return false;
+    if (!a.out || a.out_fp8 || a.out_f32 || a.n_splits > 1 || a.k_len || a.gqa_pack || a.check_k_extent) return false;   // self-attention, 16-bit output only
+    // the ring requests tiles up to two past the end (range-checked to zeros): their 32-bit offsets must not wrap
+    return ((long)(max_q + 4 * ATT_BKV) * a.ldk + D) * 2 < (1L << 32) && ((long)(max_q + 4 * ATT_BKV) * a.ldv + D) * 2 < (1L << 32);
+}
+
 template <typename T, int D>
 int dispatch_attn(const AttnArgs& a, int n_seq, int max_q, int causal, int use_tr, void* stream) {
+    if constexpr (D == 128) {
+        if (attn_r64_applies<T, D>(a, max_q, use_tr)) {
+            if (g_attn_rows64.load() == 1)
+                return causal ? launch_attn_r64<T, true, 2>(a, n_seq, max_q, stream) : launch_attn_r64<T, false, 2>(a, n_seq, max_q, stream);
+            return causal ? launch_attn_r64<T, true, 1>(a, n_seq, max_q, stream) : launch_attn_r64<T, false, 1>(a, n_seq, max_q, stream);
+        }
+    }
     if (use_tr && g_attn_dma)
         return causal ? launch_attn_dma<T, D, true>(a, n_seq, max_q, stream) : launch_attn_dma<T, D, false>(a, n_seq, max_q, stream);
     if (causal) return use_tr ? launch_attn<T, D, true, true>(a, n_seq, max_q, stream)
@@ -464,11 +498,15 @@ int skinny_norm_args(const char* who, SkinnyNorm& nm, int M, int N, int epilogue
     nm = SkinnyNorm();
     if (rowsq_in) {
         if (rowsq_parts <= 0 || norm_dim <= 0) return fail(LMI_EINVAL, "%s: rowsq_in needs rowsq_parts > 0 and norm_dim > 0", who);
+        // the producer (a residual lmi_gemm_skinny_ex over the norm_dim-wide stream) writes one partial per 16-column workgroup and row
+        if (rowsq_parts != norm_dim / 16 || (norm_dim % 16) || ((uintptr_t)rowsq_in & 3))
+            return fail(LMI_EINVAL, "%s: rowsq_parts %d must be norm_dim / 16 = %d (4-byte aligned partials)", who, rowsq_parts, norm_dim / 16);
         nm.rowsq_in = rowsq_in; nm.parts_in = rowsq_parts; nm.inv_dim = 1.0f / (float)norm_dim; nm.eps = norm_eps;
     }
     if (norm_out || rowsq_out || norm_gamma) {
-        if (epilogue != LMI_SKINNY_RESIDUAL || !norm_out || !rowsq_out || !norm_gamma || ld_norm < N)
-            return fail(LMI_EINVAL, "%s: norm_out / norm_gamma / rowsq_out go together, with the residual epilogue (ld_norm >= N)", who);
+        if (epilogue != LMI_SKINNY_RESIDUAL || !norm_out || !rowsq_out || !norm_gamma || ld_norm < N || ((uintptr_t)rowsq_out & 3) || ((uintptr_t)norm_out & 1) ||
+            ((uintptr_t)norm_gamma & 3))
+            return fail(LMI_EINVAL, "%s: norm_out / norm_gamma / rowsq_out go together, with the residual epilogue (ld_norm >= N, aligned pointers)", who);
         nm.norm_out = norm_out; nm.ld_norm = ld_norm; nm.gamma = norm_gamma; nm.rowsq_out = rowsq_out;
     }
     (void)M;
@@ -527,6 +565,12 @@ int lmi_set_option(const char* key, int value) {
             }
     }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "attn.rows64")) {
+        if (value < 0 || value > 2) return fail(LMI_EINVAL, "lmi_set_option: attn.rows64 in {0, 1, 2}");
+        g_attn_rows64 = value;
+        return LMI_OK;
+    }
+    if (!strcmp(key, "attn.rows64_min")) { g_attn_rows64_min = value < 0 ? 0 : value; return LMI_OK; }
     if (!strcmp(key, "attn.stream_kv")) { g_attn_stream_kv = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "gemv.plan")) { g_gemv_plan = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.gqa_pack")) { g_attn_gqa_pack = value ? 1 : 0; return LMI_OK; }
@@ -967,6 +1011,9 @@ int lmi_gemm_skinny_ex(const void* W, const void* X, void* out, int M, int N, in
     if ((ldw & 7) || (ldx & 7) || ldw < K || ldx < K || (packed && ldw != K) || !aligned16(W) || !aligned16(X) ||
         ((epilogue == LMI_SKINNY_RESIDUAL || epilogue == LMI_SKINNY_STORE_F32) ? !aligned16(out) && ((uintptr_t)out & 3) : ((uintptr_t)out & 1)))
         return fail(LMI_EINVAL, "lmi_gemm_skinny: rows must be 16-byte aligned (ldw, ldx multiples of 8 and >= K)");
+    // the output row holds N columns (SwiGLU: N / 2 products): a smaller ldo would let the residual read-modify-write run into the next row
+    if (ldo < (epilogue == LMI_SKINNY_SWIGLU ? N / 2 : N))
+        return fail(LMI_EINVAL, "lmi_gemm_skinny: ldo %d < output row width %d", ldo, epilogue == LMI_SKINNY_SWIGLU ? N / 2 : N);
     SkinnyNorm nm;
     if (int rc = skinny_norm_args("lmi_gemm_skinny_ex", nm, M, N, epilogue, rowsq_in, rowsq_parts, norm_dim, norm_eps, norm_out, ld_norm, norm_gamma, rowsq_out))
         return rc;

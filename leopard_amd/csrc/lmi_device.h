@@ -59,6 +59,7 @@ LMI_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x 
 // Wait until at most N of this wave's VMEM operations (LDS-DMA pieces) are outstanding, then workgroup barrier.
 // Raw s_barrier on purpose: __syncthreads() would drain vmcnt to 0 while LDS-DMA is in flight.
 template <int N> LMI_DEV void wait_vmcnt_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+template <int N> LMI_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // D[32x32] += A[32x16] * B[16x32].  Lane l supplies A[l&31][8*(l>>5)+j] and B[8*(l>>5)+j][l&31], j=0..7;
 // receives D[(r&3)+8*(r>>2)+4*(l>>5)][l&31], r=0..15.
@@ -214,6 +215,7 @@ LMI_DEV float sub_rn(float a, float b) { float r = a - b; asm volatile("" : "+v"
 inline int lane_id() { return threadIdx.x & 63; }
 inline int wave_id() { return (int)(threadIdx.x >> 6); }
 template <int N> inline void wait_vmcnt_barrier() { __syncthreads(); }
+template <int N> inline void wait_vmcnt() {}
 inline float emu_fp8_decode(uint8_t v) {
     const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
     float f;

@@ -323,10 +323,11 @@ def encode_images_sharded(engine, tiles: torch.Tensor) -> torch.Tensor:
     tpt = engine.cfg.tokens_per_tile
     D = engine.cfg.text_config.hidden_size
     max_rows = max(b - a for a, b in slices) * tpt
-    # exchange dtype: the 16-bit compute type by default (SURVEY.md 8e budgets 58 MB for C3; the merged rows are rounded to that
-    # type at their first hand-over to a GEMM operand anyway, one layer later), fp32 when `engine.tp_vision_gather_dtype` asks
-    # for the bit-identical-to-one-rank result (parity runs)
-    gdt = getattr(engine, "tp_vision_gather_dtype", None) or engine.dtype
+    # exchange dtype: fp32 by default — the gathered rows are merged into the fp32 residual stream, which carries them UNROUNDED through
+    # every layer, so a 16-bit exchange is one rounding the single-rank path does not have (2^-11 relative in fp16, 2^-8 in bf16) and the
+    # tensor-parallel result would no longer equal the one-rank result.  116 MB at C3 over 7 links is ~0.1 ms.  `engine.tp_vision_gather_dtype
+    # = engine.dtype` opts into the 16-bit exchange (58 MB, the figure SURVEY.md 8e budgets) as a bandwidth mode with that stated rounding.
+    gdt = getattr(engine, "tp_vision_gather_dtype", None) or torch.float32
     mine = torch.zeros(max_rows, D, dtype=gdt, device=tiles.device)
     if hi > lo:
         mine[:(hi - lo) * tpt] = engine.encode_images(tiles[lo:hi].contiguous())

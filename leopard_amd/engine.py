@@ -18,6 +18,7 @@ between kernels are the 16-bit compute type; weights are converted once at load 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -108,8 +109,12 @@ class LeopardEngine:
                 raise RuntimeError(f"tensor-parallel weights (tp_size {weights.tp_size}) need an initialised process group of that size")
         self.tp_chunks = 2             # row chunks per layer under TP: chunk c's collectives overlap chunk c+1's GEMMs
         self.tp_comm_dtype = None      # dtype of the reduce-scattered partial products: None = the compute type, torch.float32 = exact sums
-        self.tp_decode_graph = True    # TP decode: capture the step (with its RCCL all-reduces) in a HIP graph when the communicator is RcclComm
-        self.tp_vision_gather_dtype = None   # all-gather of the projected visual tokens: None = the compute type (58 MB at C3), torch.float32 = bit-identical to one rank
+        # TP decode: capture the step (with its RCCL all-reduces) in a HIP graph when the communicator is RcclComm.  OFF by default: capture and
+        # replay of a multi-rank RCCL step has only ever run on a one-rank communicator (tests/test_gpu_dist.py) — LMI_TP_DECODE_GRAPH=1 /
+        # this flag opt in, and a failed capture falls back to the eager step (``_decode_run``)
+        self.tp_decode_graph = os.environ.get("LMI_TP_DECODE_GRAPH", "0") == "1"
+        # all-gather of the projected visual tokens: None = fp32 (bit-identical to one rank: the rows are merged into the fp32 residual stream,
+        # which carries them unrounded through every layer); the 16-bit compute type halves the bytes (58 MB at C3) at one extra rounding
         self._comm_stream = None
         self.graph_encode = False      # capture the vision encode per ViT-input count in a HIP graph (BASELINE config 5)
         self._encode_graphs: Dict[tuple, tuple] = {}   # (ViT-input count, stream) -> (graph, static in, static out)
@@ -859,8 +864,9 @@ class LeopardEngine:
         # HIP graph capture records like any kernel (RCCL supports capture; tests/test_gpu_dist.py captures and replays
         # lmi_allreduce on the device), so the step stays ONE graph replay per token; over a torch.distributed group (gloo in the
         # CPU tests, host-staged) it cannot be captured and runs eagerly.
-        tp_capturable = self.tp_size == 1 or (type(self.comm).__name__ == "RcclComm" and self.tp_decode_graph)
-        if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs or not tp_capturable:
+        from .dist import RcclComm
+        tp_capturable = self.tp_size == 1 or (isinstance(self.comm, RcclComm) and self.tp_decode_graph)
+        if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs or not tp_capturable or getattr(st, "graph_failed", False):
             self._decode_body(st, cache)
             return
         if st.graph is None:
@@ -872,12 +878,29 @@ class LeopardEngine:
                 self._decode_body(st, cache)
             torch.cuda.current_stream(self.device).wait_stream(side)
             st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.cu_k.copy_(keep[2])
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            sent0 = self.comm.sent_bytes if self.comm is not None else 0
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._decode_body(st, cache)
+            except Exception as exc:                   # a communicator that cannot be captured: run the step eagerly from now on
+                if self.tp_size == 1:
+                    raise
+                import warnings
+                warnings.warn(f"tensor-parallel decode step could not be captured in a HIP graph ({exc}); running it eagerly")
+                st.graph_failed = True
+                torch.cuda.synchronize(self.device)
+                st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.cu_k.copy_(keep[2])
                 self._decode_body(st, cache)
+                return
+            st.graph_comm_bytes = (self.comm.sent_bytes - sent0) if self.comm is not None else 0    # what one replay puts on the links
+            if self.comm is not None:
+                self.comm.sent_bytes = sent0           # capture records, it does not send
             st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.cu_k.copy_(keep[2])      # capture does not execute
             st.graph = g
         st.graph.replay()
+        if self.comm is not None:
+            self.comm.sent_bytes += getattr(st, "graph_comm_bytes", 0)
 
     def _decode_seed(self, st, cache: KVCache, token_id: int):
         if cache.length >= cache.capacity:

@@ -37,9 +37,10 @@ def _worker(rank, world, port, out):
     eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
     tiles = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (3, 28, 28, 3), dtype=np.uint8))
     full = eng.encode_images(tiles)
-    vis16 = D.encode_images_sharded(eng, tiles)             # default: exchanged in the 16-bit compute type (half the bytes)
-    eng.tp_vision_gather_dtype = torch.float32              # parity runs: exchanged as fp32 -> bit-identical to one rank
-    vis = D.encode_images_sharded(eng, tiles)
+    vis = D.encode_images_sharded(eng, tiles)               # default: exchanged as fp32 -> bit-identical to one rank
+    eng.tp_vision_gather_dtype = torch.float16              # bandwidth mode: the 16-bit compute type, one stated extra rounding
+    vis16 = D.encode_images_sharded(eng, tiles)
+    eng.tp_vision_gather_dtype = None
     ok = bool(torch.equal(vis, full)) and bool(torch.equal(vis16, full.to(torch.float16).float()))
     out.put((rank, mine, tmax, ok, tuple(vis.shape)))
     D.barrier()

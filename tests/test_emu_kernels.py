@@ -876,3 +876,69 @@ def test_split_hi_lo_and_fp32_producers(ops, dtype):
     o32 = torch.zeros(S, H * hd)
     ops.attention_f32out(qkv[:, :H * hd], qkv[:, H * hd:2 * H * hd], qkv[:, 2 * H * hd:], o32, cu, cu, 40, H, H, hd, hd ** -0.5, True)
     assert torch.equal(o32.to(dtype), o16)
+
+
+# ---- attention64.h: 64 query rows per wave, 32-key software-pipelined steps (the long-prefill kernel at head_dim 128) -----------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_rows64_vs_fp32(ops, dtype, causal, variant):
+    """attn_fwd_r64_kernel against fp32 on ragged shapes: several 256-row workgroups with a tail block (waves with no rows, waves with
+    fewer tiles than the workgroup), a sequence shorter than one wave, one of exactly one tile, GQA 2:1; every output row is written."""
+    H, KV, D = 2, 1, 128
+    lens = [600, 40, 64, 257]
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    T = cu[-1]
+    qkv = rnd((T, (H + 2 * KV) * D), dtype, 160)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    cu_t = torch.tensor(cu, dtype=torch.int32)
+    ref = attn_ref(q, k, v, cu, cu, H, KV, D, D ** -0.5, causal)
+    ops.set_option("attn.rows64_min", 0)
+    try:
+        ops.set_option("attn.rows64", variant)                     # 1: two 32-row blocks per wave; 2: one block per wave, 8 waves
+        out = torch.full((T, H * D), float("nan"), dtype=dtype)
+        ops.attention(q, k, v, out, cu_t, cu_t, max(lens), H, KV, D, D ** -0.5, causal, True)
+        ops.set_option("attn.rows64", 0)
+        base = torch.full((T, H * D), float("nan"), dtype=dtype)
+        ops.attention(q, k, v, base, cu_t, cu_t, max(lens), H, KV, D, D ** -0.5, causal, True)
+    finally:
+        ops.set_option("attn.rows64", 0)
+        ops.set_option("attn.rows64_min", 1024)
+    assert torch.isfinite(out.float()).all()
+    err, err_base = (out.float() - ref).abs().max(), (base.float() - ref).abs().max()
+    assert err <= tol(dtype) * 2, (err, err_base)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_rows64_sliding_window_and_reference_moves(ops, variant):
+    """The deferred softmax reference under the pipelined schedule: scores that grow by far more than 2^8 along the keys (the reference
+    must move several times, each time flushing the pending probabilities first), and the Mistral sliding window (leading tiles fully
+    masked for late rows: the reference stays -inf there)."""
+    H, KV, D, S, Wn = 2, 1, 128, 700, 300
+    dtype = torch.float16
+    qkv = rnd((S, (H + 2 * KV) * D), dtype, 161)
+    q, k, v = qkv[:, :H * D].clone(), qkv[:, H * D:(H + KV) * D].clone(), qkv[:, (H + KV) * D:].clone()
+    k *= torch.linspace(0.2, 6.0, S).reshape(S, 1).to(dtype)       # later keys score higher and higher: frequent reference moves
+    cu = torch.tensor([0, S], dtype=torch.int32)
+    qs = q.float().view(S, H, D).transpose(0, 1)
+    ks = k.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H, 0)
+    vs = v.float().view(S, KV, D).transpose(0, 1).repeat_interleave(H, 0)
+    i, j = torch.arange(S)[:, None], torch.arange(S)[None, :]
+    ops.set_option("attn.rows64_min", 0)
+    ops.set_option("attn.rows64", variant)
+    try:
+        for window in (0, Wn):
+            out = torch.full((S, H * D), float("nan"), dtype=dtype)
+            ops.attention(q, k, v, out, cu, cu, S, H, KV, D, D ** -0.5, True, True, window=window)
+            vis = (j <= i) & ((i - j < window) if window else torch.ones_like(j <= i))
+            sc = (qs @ ks.transpose(-1, -2) * D ** -0.5).masked_fill(~vis, float("-inf"))
+            ref = (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(S, H * D)
+            assert torch.isfinite(out.float()).all()
+            assert (out.float() - ref).abs().max() <= 6e-3, (window, (out.float() - ref).abs().max())
+            if variant == 2 and window == 0:                       # masks before the maxima: a row that sees one key returns its V row exactly
+                assert torch.equal(out[0].view(H, D), v[0].view(KV, D).repeat_interleave(H // KV, 0))
+    finally:
+        ops.set_option("attn.rows64", 0)
+        ops.set_option("attn.rows64_min", 1024)

@@ -38,8 +38,7 @@ def _worker(rank, world, port, out):
     ids = torch.from_numpy(synth_prompt_ids([2, 3], cfg, seed=4)).reshape(1, -1)
     S = ids.shape[1] + 5 * (cfg.tokens_per_tile - 1)
     cache = KVCache(cfg, eng.tp_padded_len(S) + 8, dtype, dev, tp_size=world)
-    eng.tp_vision_gather_dtype = torch.float32              # bit-identical visual tokens (the default exchanges them in 16 bits)
-    vis = D.encode_images_sharded(eng, tiles)
+    vis = D.encode_images_sharded(eng, tiles)               # default exchange dtype (fp32): bit-identical visual tokens, asserted below
     res = eng.prefill(ids, None, cache=cache, visual_tokens=vis)
     assert res.seq_len == S and type(eng.comm).__name__ == "TorchComm" and eng.comm.sent_bytes > 0
     step = eng.decode_step(int(res.logits_last.argmax()), cache).clone()

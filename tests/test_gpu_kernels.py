@@ -278,6 +278,42 @@ def test_attention_siglip_noncausal_d72(ops, dtype, use_tr):
     assert err <= 3 * eps(dtype), f"use_tr={use_tr}: {err}"
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_pipelined_variants_on_device(ops, dtype, variant):
+    """attention64.h (opt-in, attn.rows64 = 1 | 2): the software-pipelined kernels on the device — ragged causal GQA sequences spanning several
+    256-row workgroups against fp32, three launches bit-identical (the ring, the counted waits and, for variant 1, the inline-asm MFMA hazard
+    contract are what the CPU emulator cannot check), and for variant 2 the exactness property of a row that sees a single key."""
+    H, KV, D = 8, 2, 128
+    lens = [1500, 40, 700]
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    T = cu[-1]
+    qkv = rnd((T, (H + 2 * KV) * D), dtype, 66)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    ref = attn_ref(q, k, v, cu, cu, H, KV, D, D ** -0.5, True)
+    ops.set_option("attn.rows64", variant)
+    ops.set_option("attn.rows64_min", 0)
+    try:
+        outs = []
+        for _ in range(3):
+            out = torch.full((T, H * D), float("nan"), dtype=dtype, device=DEV)
+            ops.attention(q, k, v, out, cu_t, cu_t, max(lens), H, KV, D, D ** -0.5, True, True)
+            outs.append(out)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("attn.rows64", 0)
+        ops.set_option("attn.rows64_min", 1024)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    err = (outs[0].float() - ref).abs().max().item()
+    assert err <= 3 * eps(dtype), err
+    if variant == 2:
+        for b in cu[:-1]:
+            assert torch.equal(outs[0][b].view(H, D), v[b].view(KV, D).repeat_interleave(H // KV, 0))
+
+
 def test_attention_decode_and_chunk_shapes(ops):
     H, KV, D = 32, 8, 128
     dtype = torch.float16

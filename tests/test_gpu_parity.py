@@ -17,6 +17,8 @@ The bounds below are the MEASURED errors x 1.2 (profiles/r02_error_growth.txt ho
 budget from the rounding-emulating oracle, which the measurements match); fp16 meets the 1e-3 at the depths the reference's
 C1 / C2 cases have where stated, and where it does not the table shows the same excess for the emulated oracle: it is the
 price of 16-bit operands at that depth, not of the kernels.  Integer / index work is bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -31,7 +33,8 @@ DEV = "cuda:0"
 # predicted budget in profiles/r02_error_growth.txt
 LOGIT_TOL = {torch.float16: 1.25e-3, torch.bfloat16: 1.03e-2}     # mid configuration, 2 + 2 layers: all-position logits 9.9e-4 / 8.2e-3 (last position 5.0e-4 / 4.0e-3)
 FULL_TOL = {("c1", torch.float16): 2.12e-3, ("c1", torch.bfloat16): 1.65e-2,      # full depth, 27 + 32 layers: 1.69e-3 / 1.32e-2
-            ("c2", torch.float16): 1.46e-3, ("c2", torch.bfloat16): 1.43e-2}      #                             1.14e-3 / 1.14e-2
+            ("c2", torch.float16): 1.46e-3, ("c2", torch.bfloat16): 1.43e-2,      #                             1.14e-3 / 1.14e-2
+            ("c3", torch.float16): 1.46e-3, ("c3", torch.bfloat16): 1.40e-2}      # C3 = the benchmarked sample:  1.17e-3 (predicted 1.02e-3) / bf16 measured below
 # C3 sequence length, 2 + 2 layers: residual stream max over 29 M elements / rel-rms, ViT features, last-position logits
 C3LEN_TOL = {torch.float16: (1.13e-3, 9.2e-4, 7.3e-4, 7.1e-4),                    # measured 9.0e-4, 7.4e-4, 5.8e-4, 5.7e-4
              torch.bfloat16: (8.4e-3, 7.3e-3, 5.1e-3, 5.0e-3)}                    # measured 6.8e-3, 5.8e-3, 4.1e-3, 4.0e-3
@@ -115,73 +118,115 @@ def test_merge_mismatch_raises_before_launch(ops, mid_oracle):
         eng.prefill(ids.to(DEV), torch.from_numpy(u8[:2]).to(DEV))
 
 
+# ---- FULL depth (27 + 32 layers) vs committed oracle fixtures ------------------------------------------------------------------------
+# tests/golden/{c1,c2,c3}_full_depth.npz are written by tools/gen_fulldepth_fixtures.py: the fp32 oracle and the oracle with the kernels'
+# 16-bit hand-over roundings emulated, run ONCE on host cores (C3 = the benchmarked configuration: 140 TFLOP per run).  The tests regenerate
+# the inputs from their seeds (checked against the fixture's SHA-256) and compare the HIP path with the stored last-position logits and with
+# the stored fp32 residual stream on a few probe rows after every one of the 59 layers.
+FULL_CASES = {"c1": (1, 336, 336, 1, 228), "c2": (1, 1344, 896, 7, 1242), "c3": (6, 1344, 896, 42, 7187)}      # images, W, H -> ViT inputs, S
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def probe_rows(name, shape):
+    """The rows tools/gen_fulldepth_fixtures.py keeps per layer (ViT stream [N, 676, D] / LLM stream [1, S, D])."""
+    if name.startswith("vit"):
+        return [(t, r) for t in sorted({0, shape[0] - 1}) for r in (0, 337, 675)]
+    S = shape[1]
+    return [(0, r) for r in sorted({S // 3, S // 2, max(S - 2, 0), S - 1})]
+
+
+class FullDepthFixture:
+    def __init__(self, case):
+        import hashlib
+        cfg = full_config()
+        n, w, h, n_vit, S = FULL_CASES[case]
+        z = np.load(os.path.join(GOLDEN, f"{case}_full_depth.npz"))
+        self.u8, self.ids, _ = sample_inputs(cfg, n, w, h)
+        assert list(z["meta"]) == [n, w, h, n_vit, S] and self.u8.shape[0] == n_vit
+        assert np.array_equal(z["ids"], self.ids.numpy()), "prompt synthesiser drifted from the fixture"
+        assert hashlib.sha256(np.ascontiguousarray(self.u8).tobytes()).digest() == z["tiles_sha256"].tobytes(), "tiler output drifted from the fixture"
+        self.S, self.n_vit = S, n_vit
+        self.ref = torch.from_numpy(z["logits_fp32"])
+        self.emu = {k[len("logits_emu_"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("logits_emu_")}
+        self.names = [str(x) for x in z["trace_names"]]
+        off, wid = z["probe_offsets"], z["probe_width"]
+        self.probe = {nm: torch.from_numpy(z["probe_fp32"][off[i]:off[i + 1]]).view(-1, int(wid[i])) for i, nm in enumerate(self.names)}
+        self.pred = {k[len("trace_relrms_emu_"):]: dict(zip(self.names, z[k].tolist())) for k in z.files if k.startswith("trace_relrms_emu_")}
+        self.oracle_seconds = float(z["oracle_seconds"][0])
+
+    def probe_of(self, name, x):
+        """Probe rows of the HIP path's stream `x` ([N * 676, D] or [S, D]) in the fixture's layout."""
+        if name.startswith("vit"):
+            x = x.view(self.n_vit, -1, x.shape[-1])
+            return torch.stack([x[t, r] for t, r in probe_rows(name, x.shape)])
+        return torch.stack([x[r] for _, r in probe_rows(name, (1, x.shape[0]))])
+
+
 @pytest.fixture(scope="module")
-def full_host_weights(ops):
-    """fp32 host copy of the full-size synthetic parameters (generated on the GPU by lmi_fill_synthetic — bit-identical to the
-    numpy generator, see test_fill_synthetic_bit_exact).  The synthetic values are exactly representable in fp16 AND bf16, so
-    one copy serves both compute types."""
-    import psutil
-    from leopard_amd.weights import SynthSource
-    if psutil.virtual_memory().available < 56 * 2 ** 30:
-        pytest.skip("full-depth fp32 oracle needs ~40 GB of host RAM")
-    cfg = full_config()
-    src = SynthSource(cfg, ops, torch.device(DEV), torch.float16)
-    return {name: src.get(name).float().cpu() for name in src.specs}
-
-
-FULL_CASES = {"c1": (1, 336, 336, 1, 228), "c2": (1, 1344, 896, 7, 1242)}      # images, W, H -> ViT inputs, S
-
-
-@pytest.fixture(scope="module")
-def full_depth_oracle(full_host_weights):
-    """fp32 oracle logits of C1 and C2 at full depth (C2: ~22 TFLOP on the host cores), plus the rounding-emulating oracles on C1
-    (fp16, bf16, and fp16 with e4m3 linear operands); each case is computed on first use, once for all compute types."""
-    from leopard_amd.tiler import siglip_normalize
-    from oracle import leopard_oracle as O
-    cfg = full_config()
+def full_depth_oracle():
     done = {}
 
     class Cases:
         def __getitem__(self, name):
             if name not in done:
-                n, w, h, n_vit, S = FULL_CASES[name]
-                u8, ids, plan = sample_inputs(cfg, n, w, h)
-                assert u8.shape[0] == n_vit
-                pix = torch.from_numpy(siglip_normalize(u8))
-                ref = O.prefill_logits(ids, pix, full_host_weights, cfg, last_only=True)[0, 0]
-                emu = {}
-                if name == "c1":
-                    for dt in (torch.float16, torch.bfloat16):
-                        with O.emulate_rounding(dt):
-                            emu[dt] = O.prefill_logits(ids, pix, full_host_weights, cfg, last_only=True)[0, 0]
-                    with O.emulate_rounding(torch.float16, operand_dtype=torch.float8_e4m3fn):
-                        emu["fp8"] = O.prefill_logits(ids, pix, full_host_weights, cfg, last_only=True)[0, 0]
-                done[name] = (u8, ids, S, ref, emu)
+                done[name] = FullDepthFixture(name)
             return done[name]
     return Cases()
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("case", ["c1", "c2"])
-def test_full_depth_vs_oracle(ops, full_depth_oracle, case, dtype):
-    """BASELINE configs C1 and C2 at FULL depth and width: 27 SigLIP + 32 Llama-3.1-8B layers, last-position logits."""
+def rel_rms(a, b):
+    return ((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt()).item()
+
+
+def run_full_depth(ops, fx, dtype, split=False):
     from leopard_amd.engine import LeopardEngine
     from leopard_amd.weights import EngineWeights, SynthSource
     cfg = full_config()
-    u8, ids, S, ref, emu = full_depth_oracle[case]
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, torch.device(DEV), dtype), dtype)
     eng = LeopardEngine(cfg, W, ops=ops, device=torch.device(DEV))
-    res = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV))
-    got = res.logits_last.cpu()
-    assert res.seq_len == S
-    a, n, r = err_stats(got, ref)
-    print(f"[{case} full depth {dtype}] vs fp32 oracle: max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}  "
-          f"max|logit| {ref.abs().max():.3f}  argmax equal = {int(got.argmax()) == int(ref.argmax())}")
+    eng.split_operands = split
+    probes = {}
+    eng.trace = lambda name, x: probes.__setitem__(name, fx.probe_of(name, x.detach()).float().cpu())
+    res = eng.prefill(fx.ids.to(DEV), torch.from_numpy(fx.u8).to(DEV))
+    got = res.logits_last.float().cpu()
+    assert res.seq_len == fx.S
+    del eng, W
+    torch.cuda.empty_cache()
+    return got, probes
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["c1", "c2", "c3"])
+def test_full_depth_vs_oracle(ops, full_depth_oracle, case, dtype):
+    """BASELINE configs C1, C2 and C3 (the benchmarked 6 x 1344x896 sample, 42 ViT inputs, S = 7187) at FULL depth and width: 27 SigLIP + 32
+    Llama-3.1-8B layers, last-position logits and the fp32 residual stream after every layer (probe rows) vs the fp32 oracle
+    (EVAL:248-333 semantics), with the figure stated against north_star's 1e-3."""
+    fx = full_depth_oracle[case]
+    got, probes = run_full_depth(ops, fx, dtype)
+    a, n, r = err_stats(got, fx.ref)
+    print(f"[{case} full depth {dtype}] vs fp32 oracle ({fx.oracle_seconds:.0f} s of host time, committed): max-abs {a:.3e}  normalised-max {n:.3e} "
+          f"(north_star 1e-3: {'met' if n <= 1e-3 else 'x%.2f' % (n / 1e-3)})  rel-rms {r:.3e}  max|logit| {fx.ref.abs().max():.3f}  "
+          f"argmax equal = {int(got.argmax()) == int(fx.ref.argmax())}")
     assert n <= FULL_TOL[(case, dtype)]
-    assert int(got.argmax()) == int(ref.argmax())
-    if dtype in emu:
-        a2, n2, r2 = err_stats(got, emu[dtype])
-        ap, np_, rp = err_stats(emu[dtype], ref)
+    assert int(got.argmax()) == int(fx.ref.argmax())
+    tag = {torch.float16: "fp16", torch.bfloat16: "bf16"}[dtype]
+    # layer by layer on the probe rows: measured error of the fp32 residual stream, and (where the fixture holds the emulating oracle for
+    # this type) the predicted budget beside it
+    worst = 0.0
+    for name in fx.names:
+        if name not in probes:
+            continue
+        m = rel_rms(probes[name], fx.probe[name])
+        pr = fx.pred.get(tag, {}).get(name)
+        if pr is not None and pr > 0 and name not in ("vit.embed", "llm.embed"):
+            worst = max(worst, m / pr)
+            assert m <= 2.0 * pr + 1e-6, f"{name}: measured rel-rms {m:.3e} vs predicted {pr:.3e} on the probe rows"
+    last = fx.names[-1]
+    print(f"[{case} full depth {dtype}] residual stream after {last} (probe rows): measured rel-rms {rel_rms(probes[last], fx.probe[last]):.3e}"
+          + (f", predicted {fx.pred[tag][last]:.3e}; worst measured / predicted over the 59 layers {worst:.2f}" if tag in fx.pred else ""))
+    if tag in fx.emu:
+        a2, n2, r2 = err_stats(got, fx.emu[tag])
+        ap, np_, rp = err_stats(fx.emu[tag], fx.ref)
         print(f"[{case} full depth {dtype}] vs rounding-emulating oracle: normalised-max {n2:.3e} rel-rms {r2:.3e};  "
               f"predicted budget (emulated vs fp32 oracle): normalised-max {np_:.3e} rel-rms {rp:.3e}")
         # The emulating oracle is a statistical twin, not a bit-twin: roundings are amplified chaotically through 59 layers, so
@@ -190,31 +235,19 @@ def test_full_depth_vs_oracle(ops, full_depth_oracle, case, dtype):
         # layer), and the two 16-bit runs are no further apart than two independent draws of that noise.
         assert 0.7 * rp <= r <= 1.4 * rp, f"measured rel-rms {r:.3e} vs predicted budget {rp:.3e}"
         assert r2 <= 1.8 * rp
-    del eng, W
-    torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("case", ["c1", "c2"])
+@pytest.mark.parametrize("case", ["c1", "c2", "c3"])
 def test_full_depth_split_operands_meets_1e_3(ops, full_depth_oracle, case):
     """north_star's figure, literally: with engine.split_operands (every A operand of every layer linear handed over as a hi + lo pair of
-    fp16 values, the GEMMs at 2 K) the last-position logits of C1 and C2 at FULL depth are within 1e-3 of the fp32 reference, normalised by
-    the logit scale (predicted by the oracle with those hand-overs exact: 5.1e-4 / 2.0e-4, profiles/r03_split_operand_study_c*.txt).
-    The mode costs ~1.8x the prefill time (bench.py --split-operands); the production schedule's budget tests are above."""
-    from leopard_amd.engine import LeopardEngine
-    from leopard_amd.weights import EngineWeights, SynthSource
-    cfg = full_config()
-    dtype = torch.float16
-    u8, ids, S, ref, emu = full_depth_oracle[case]
-    W = EngineWeights.build(cfg, SynthSource(cfg, ops, torch.device(DEV), dtype), dtype)
-    eng = LeopardEngine(cfg, W, ops=ops, device=torch.device(DEV))
-    eng.split_operands = True
-    res = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV))
-    got = res.logits_last.cpu()
-    a, n, r = err_stats(got, ref)
+    fp16 values, the GEMMs at 2 K) the last-position logits of C1, C2 and C3 at FULL depth are within 1e-3 of the fp32 reference, normalised
+    by the logit scale (predicted by the oracle with those hand-overs exact: 5.1e-4 / 2.0e-4, profiles/r03_split_operand_study_c*.txt).
+    The mode costs ~1.9x the prefill time (bench.py --split-operands); the production schedule's budget tests are above."""
+    fx = full_depth_oracle[case]
+    got, _ = run_full_depth(ops, fx, torch.float16, split=True)
+    a, n, r = err_stats(got, fx.ref)
     print(f"[{case} full depth fp16, split operands] vs fp32 oracle: max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}")
-    assert res.seq_len == S and n <= 1.0e-3 and int(got.argmax()) == int(ref.argmax())
-    del eng, W
-    torch.cuda.empty_cache()
+    assert n <= 1.0e-3 and int(got.argmax()) == int(fx.ref.argmax())
 
 
 # ---- fp8 linears (BASELINE configs[4]; leopard_amd.fp8): the error budget of e4m3 operands, predicted and measured --------------------
@@ -292,7 +325,8 @@ def test_mid_config_fp8_vs_oracle(ops, mid_oracle):
 def test_full_depth_fp8_c1_vs_oracle(ops, full_depth_oracle):
     """C1 at full depth (27 + 32 layers) with fp8 linears: measured error == the predicted e4m3 budget."""
     cfg = full_config()
-    u8, ids, S, ref, emu = full_depth_oracle["c1"]
+    fx = full_depth_oracle["c1"]
+    u8, ids, ref, emu = fx.u8, fx.ids, fx.ref, fx.emu
     eng = build_engine(cfg, ops, torch.float16)
     eng.enable_fp8(_fp8_calibration(cfg))
     got = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV)).logits_last.cpu()

@@ -115,9 +115,17 @@ def bench_attn(args):
     out = torch.empty(S, H * D, dtype=dtype, device=DEV)
     cu = torch.tensor([0, S], dtype=torch.int32, device=DEV)
     fn = lambda: ops.attention(qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:], out, cu, cu, S, H, KV, D, D ** -0.5, True, True)
-    time_fn(fn, 2)
-    ms = time_fn(fn, args.iters)
-    print(f"llama causal S={S}: {ms:.3f} ms  {2 * H * D * S * (S + 1) / ms / 1e9:.0f} TF/s (causal-counted)")
+    res = {}
+    for rows64 in (0, 1, 2, 0, 1, 2):                            # attention.h / attention64.h with 2 blocks per wave / with 1 block per wave
+        ops.set_option("attn.rows64", rows64)
+        time_fn(fn, 2)
+        ms = time_fn(fn, args.iters)
+        res[rows64] = out.float().clone()
+        print(f"llama causal S={S} rows64={rows64}: {ms:.3f} ms  {2 * H * D * S * (S + 1) / ms / 1e9:.0f} TF/s (causal-counted)", flush=True)
+    for v in (1, 2):
+        d = (res[0] - res[v]).abs().max().item()
+        print(f"  max |attention.h kernel - pipelined variant {v}| = {d:.3e} (outputs of magnitude {res[0].abs().max().item():.2f})")
+    ops.set_option("attn.rows64", 0)
     n, T, Hv, Dv = 42, 676, 16, 72
     qkv2 = torch.randn(n * T, 3 * Hv * Dv, generator=g).to(dtype).to(DEV)
     out2 = torch.empty(n * T, Hv * Dv, dtype=dtype, device=DEV)
