@@ -132,6 +132,16 @@ class LeopardForConditionalGeneration:
         return self.engine.generate_batch(samples, max_new_tokens=max_new_tokens, eos_token_id=eos)
 
 
+    @torch.no_grad()
+    def generate_stream(self, requests: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], batch_size: int = 8, eos_token_id=None,
+                        max_new_tokens: int = 128, stats: Optional[dict] = None, **unused) -> List[torch.Tensor]:
+        """Continuous batching over a list of requests: ``batch_size`` decode slots kept busy (LeopardEngine.generate_stream); the outputs
+        come back in request order, each what ``generate`` returns for that request."""
+        eos = eos_token_id if isinstance(eos_token_id, (list, tuple)) else ([] if eos_token_id is None else [eos_token_id])
+        samples = [(ids.to(self.device), self._as_tiles(pix)) for ids, pix in requests]
+        return self.engine.generate_stream(samples, batch_size=batch_size, max_new_tokens=max_new_tokens, eos_token_id=eos, stats=stats)
+
+
 def from_pretrained(path: str, torch_dtype=torch.float32, **kw) -> LeopardForConditionalGeneration:
     """Drop-in for ``myLlavaForConditionalGeneration.from_pretrained``."""
     return LeopardForConditionalGeneration.from_pretrained(path, torch_dtype=torch_dtype, **kw)

@@ -969,6 +969,8 @@ class LeopardEngine:
     # key counts live in device memory, and the whole step is ONE captured HIP graph per (B, capacity).
     # ------------------------------------------------------------------------------------------------
     MAX_DECODE_BATCH = 16              # rows of one lmi_gemm_skinny launch (one 16x16x32 MFMA column block)
+    HIST = 8                           # continuous batching: decode steps between two host looks at the produced tokens
+    MAX_EOS = 4                        # eos ids held on the device
 
     def _batch_decode_supported(self) -> bool:
         """lmi_gemm_skinny needs K % 128 == 0 and N % 16 == 0 (gate/up: % 64); the pooled decode attention head_dim 128."""
@@ -1010,7 +1012,18 @@ class LeopardEngine:
         st.logits = self._empty(B, W.lm_head.shape[0], dtype=torch.float32)
         st.cos, st.sin = self.rope_tables(torch.arange(cap))
         st.ws = torch.empty(self.ops.decode_workspace_elems(B, H, hd, cap), dtype=torch.float32, device=dev)
+        # continuous batching (generate_stream): which slots hold a running sequence, how many more tokens each may produce, the eos ids,
+        # and a ring of the last HIST steps' tokens — all in device memory, so that slots are admitted / retired between replays of ONE
+        # captured step and the host looks at the tokens only every HIST steps
+        st.live = torch.ones(B, dtype=torch.int32, device=dev)
+        st.budget = torch.full((B,), 1 << 30, dtype=torch.int32, device=dev)
+        st.eos = torch.full((self.MAX_EOS,), -1, dtype=torch.int64, device=dev)
+        st.hist = torch.zeros(self.HIST, B, dtype=torch.int64, device=dev)
+        st.hist_idx = torch.zeros(1, dtype=torch.int64, device=dev)
         st.graph = None
+        # bounded: a serving process that sees many batch sizes keeps the pools of the two most recent ones (each is B x capacity KV rows)
+        while len(states) >= 2:
+            states.pop(next(iter(states)))
         states[B] = st
         return st
 
@@ -1071,25 +1084,35 @@ class LeopardEngine:
         if self.suppress_tokens is not None:
             st.logits.index_fill_(1, self.suppress_tokens, float("-inf"))
         torch.argmax(st.logits[:, :tc.vocab_size], dim=1, out=st.tok)
-        st.pos.add_(1)
-        st.k_len.add_(1)
+        # the step's tokens into the history ring; a slot stops advancing (its position / key count freeze, what it produces afterwards is
+        # ignored) once it produced an eos id or used up its token budget — device arithmetic only, no host value
+        st.hist.index_copy_(0, st.hist_idx, st.tok.unsqueeze(0))
+        st.hist_idx.add_(1).remainder_(self.HIST)
+        st.budget.sub_(st.live)
+        stop = (st.tok.unsqueeze(1) == st.eos.unsqueeze(0)).any(dim=1) | (st.budget <= 0)
+        st.live.mul_((~stop).to(torch.int32))
+        st.pos.add_(st.live)
+        st.k_len.add_(st.live)
 
     def _batch_decode_run(self, st):
         if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs:
             self._batch_decode_body(st)
             return
         if st.graph is None:
-            keep = (st.tok.clone(), st.pos.clone(), st.k_len.clone())
+            names = ("tok", "pos", "k_len", "live", "budget", "hist", "hist_idx")
+            keep = [getattr(st, n).clone() for n in names]
             side = torch.cuda.Stream(device=self.device)               # warm-up outside capture (function attributes, allocator)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 self._batch_decode_body(st)
             torch.cuda.current_stream(self.device).wait_stream(side)
-            st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.k_len.copy_(keep[2])
+            for n, v in zip(names, keep):
+                getattr(st, n).copy_(v)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._batch_decode_body(st)
-            st.tok.copy_(keep[0]); st.pos.copy_(keep[1]); st.k_len.copy_(keep[2])      # capture does not execute
+            for n, v in zip(names, keep):                              # capture does not execute
+                getattr(st, n).copy_(v)
             st.graph = g
         st.graph.replay()
 
@@ -1103,6 +1126,7 @@ class LeopardEngine:
         st.tok.copy_(torch.tensor(nxt, dtype=torch.int64))
         st.pos.copy_(torch.tensor(seq_lens, dtype=torch.int32))
         st.k_len.copy_(torch.tensor([s + 1 for s in seq_lens], dtype=torch.int32))
+        st.live.fill_(1); st.budget.fill_(1 << 30); st.eos.fill_(-1); st.hist_idx.zero_()      # the host applies the stop rule here
         for step in range(max_new_tokens):
             for j in range(B):
                 if not done[j]:
@@ -1114,6 +1138,107 @@ class LeopardEngine:
             self._batch_decode_run(st)
             nxt = [int(t) for t in st.tok.tolist()]
         return outs
+
+    def release_batch_state(self) -> None:
+        """Free the pooled KV caches / captured graphs of the batched decode and the second copy of the LLM weights in the skinny-M
+        operand order (15 GB for Llama-3.1-8B; rebuilt on the next batched call).  Why there are two layouts: the prefill GEMM stages
+        weight ROWS by LDS-DMA (128 contiguous bytes per 8 lanes), the M <= 16 kernel feeds fragments from memory straight into
+        v_mfma_f32_16x16x32 (adjacent lanes = adjacent rows) — from the row-major copy its loads are 64 scattered 16-byte pieces (B = 8
+        step 4.75 ms vs 4.06 ms, profiles/README.md round 3)."""
+        self._batch_states = {}
+        self._skinny_pack = None
+        if self.device.type == "cuda":
+            torch.cuda.empty_cache()
+
+    @torch.no_grad()
+    def generate_stream(self, samples: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], batch_size: int = 8, max_new_tokens: int = 128,
+                        eos_token_id: Sequence[int] = (128001, 128009), stats: Optional[dict] = None) -> List[torch.Tensor]:
+        """CONTINUOUS batching (the reference loop EVAL:381-452 is one generate() per record): ``batch_size`` decode slots,
+        ONE captured step per token for all of them, and a slot that finishes (eos / max_new_tokens) is handed to the next pending sample
+        — prefill of the newcomer, its K / V rows copied into the slot of the pooled cache, five small device writes — without
+        re-capturing anything: positions, key counts, the live mask, the token budget and the eos ids all live in device memory, and the
+        stop rule runs on the device.  The host reads the produced tokens every HIST steps (one copy of a [HIST, B] table) instead of
+        one blocking read per token; a slot that stopped inside the window idles until the window ends (its state is frozen).
+        Returns the outputs in input order, each exactly what ``generate`` returns for that sample (same rule; the batched projections sum
+        in a different order than the batch-1 GEMVs, so a token can differ only on a near tie of the top two logits).
+        ``stats`` (optional dict) receives steps / slot-steps / live slot-steps for occupancy accounting."""
+        assert self.tp_size == 1, "batched generation is a single-rank feature (replicas scale it out)"
+        B = max(1, min(int(batch_size), self.MAX_DECODE_BATCH, len(samples)))
+        eos = [int(e) for e in eos_token_id]
+        if B == 1 or not self._batch_decode_supported() or len(eos) > self.MAX_EOS:
+            return [self.generate(ids, t, max_new_tokens, eos) for ids, t in samples]
+        tpt = self.cfg.tokens_per_tile
+        def merged_len(ids):
+            return ids.shape[-1] + int((ids == self.cfg.image_token_index).sum()) * (tpt - 1)
+        need = max(merged_len(ids) for ids, _ in samples) + max_new_tokens
+        st = self._batch_state(B, need)
+        st.eos.fill_(-1)
+        if eos:
+            st.eos[:len(eos)].copy_(torch.tensor(eos, dtype=torch.int64))
+        st.live.zero_(); st.budget.zero_(); st.pos.zero_(); st.k_len.fill_(1); st.tok.zero_(); st.hist_idx.zero_()
+        eos_set = set(eos)
+        outs: List[Optional[List[int]]] = [None] * len(samples)
+        slot_sample = [-1] * B                                       # which sample a slot runs (-1: free)
+        h_budget = [0] * B                                           # host mirror of the device stop rule
+        pending = list(range(len(samples)))
+        n_steps = slot_steps = live_steps = 0
+        scratch = getattr(self, "_stream_cache", None)
+
+        def admit(j: int) -> bool:
+            """Next pending sample into slot j; False when nothing is pending.  Samples that end with their first token never take a slot."""
+            nonlocal scratch
+            while pending:
+                i = pending.pop(0)
+                ids, tiles = samples[i]
+                S = merged_len(ids)
+                if scratch is None or scratch.capacity < S:
+                    scratch = self._stream_cache = KVCache(self.cfg, (S + 1023) // 1024 * 1024, self.dtype, self.device)
+                scratch.length = 0
+                res = self.prefill(ids.reshape(1, -1), tiles, cache=scratch)
+                first = self.first_token(res.logits_last)
+                out = [int(t) for t in ids.reshape(-1).tolist()] + [first]
+                outs[i] = out
+                if first in eos_set or max_new_tokens <= 1:
+                    continue                                          # finished by the prefill alone
+                for li in range(len(scratch.k)):
+                    self.ops.kv_append(scratch.k[li][:S], scratch.v[li][:S], st.k[li], st.v[li], j * st.capacity)
+                dev = self.device
+                st.tok[j:j + 1].copy_(torch.tensor([first], dtype=torch.int64, device=dev))
+                st.pos[j:j + 1].copy_(torch.tensor([S], dtype=torch.int32, device=dev))
+                st.k_len[j:j + 1].copy_(torch.tensor([S + 1], dtype=torch.int32, device=dev))
+                st.budget[j:j + 1].copy_(torch.tensor([max_new_tokens - 1], dtype=torch.int32, device=dev))
+                st.live[j:j + 1].fill_(1)
+                slot_sample[j], h_budget[j] = i, max_new_tokens - 1
+                return True
+            return False
+
+        for j in range(B):
+            admit(j)
+        while any(i >= 0 for i in slot_sample):
+            window = self.HIST
+            st.hist_idx.zero_()
+            for _ in range(window):
+                self._batch_decode_run(st)
+            toks = st.hist.tolist()                                   # ONE host read per window: [HIST][B]
+            n_steps += window
+            for w in range(window):
+                for j in range(B):
+                    i = slot_sample[j]
+                    slot_steps += 1
+                    if i < 0:
+                        continue
+                    live_steps += 1
+                    t = int(toks[w][j])
+                    outs[i].append(t)
+                    h_budget[j] -= 1
+                    if t in eos_set or h_budget[j] <= 0:
+                        slot_sample[j] = -1                           # retired: the device froze it at this very step
+            for j in range(B):
+                if slot_sample[j] < 0:
+                    admit(j)
+        if stats is not None:
+            stats.update(steps=n_steps, slot_steps=slot_steps, live_slot_steps=live_steps, batch_size=B)
+        return [torch.tensor([o], dtype=torch.long, device=samples[i][0].device) for i, o in enumerate(outs)]
 
     @torch.no_grad()
     def generate_batch(self, samples: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], max_new_tokens: int = 128,

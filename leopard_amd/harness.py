@@ -144,12 +144,13 @@ def shard_result_path(checkpoint: str, shard: int, setting: str, dataset: str) -
 
 
 def run_inference(records: List[dict], model, tokenizer, setting: str = "direct", scorer: Optional[Callable] = None,
-                  device=None, gpu_tiler=None, batch_size: int = 1) -> List[dict]:
+                  device=None, gpu_tiler=None, batch_size: int = 1, stats: Optional[dict] = None) -> List[dict]:
     """The hot loop (EVAL:381-487) over already-sharded records, greedy.  ``gpu_tiler`` (a leopard_amd.gpu_tiler.GpuTiler):
     resize / pad / crop run on the device and the u8 tile stack goes straight to the model (same pixels as the PIL path, bit
-    for bit); without it the reference's host pipeline is used.  ``batch_size`` > 1: that many records share
-    ONE packed prefill (``model.generate_batch``: per-sample cu_seqlens keep them apart) instead of the reference's one
-    ``generate`` per record; the rows are the same."""
+    for bit); without it the reference's host pipeline is used.  ``batch_size`` > 1: that many decode SLOTS are kept busy over all
+    records (``model.generate_stream``: continuous batching — one captured decode step per token for all slots, a finished record's slot
+    goes to the next record at once) instead of the reference's one ``generate`` per record; the rows are the same, in record order.
+    ``stats`` (dict) receives the slot occupancy.  A model without ``generate_stream`` falls back to fixed groups (``generate_batch``)."""
     import numpy as np
     import torch
     from .tiler import siglip_preprocess
@@ -169,6 +170,17 @@ def run_inference(records: List[dict], model, tokenizer, setting: str = "direct"
         enc = tokenizer([s.prompt], return_tensors="pt", truncation=True, max_length=MAX_PROMPT_TOKENS)["input_ids"]
         return s, pixel_values, n_vit, enc
 
+    if batch_size > 1 and hasattr(model, "generate_stream"):
+        # continuous batching: batch_size decode slots over ALL records — a slot freed by a finished record takes the next one at once
+        # (no record waits for the slowest member of a fixed group); the rows are the same and in record order
+        prepared = [prepare(rec) for rec in records]
+        kw = generate_kwargs(tokenizer.pad_token_id)
+        outs = model.generate_stream([(enc.to(dev), pixel_values) for _, pixel_values, _, enc in prepared], batch_size=batch_size,
+                                     eos_token_id=kw["eos_token_id"], max_new_tokens=kw["max_new_tokens"], stats=stats)
+        for rec, (s, _, n_vit, enc), out in zip(records, prepared, outs):
+            response = tokenizer.batch_decode(out[:, enc.shape[1]:], skip_special_tokens=True)[0]
+            rows.append(result_row(rec, s.question, response, n_vit, scorer))
+        return rows
     for b0 in range(0, len(records), max(1, batch_size)):
         group = records[b0:b0 + max(1, batch_size)]
         prepared = [prepare(rec) for rec in group]

@@ -151,6 +151,44 @@ def test_generate_batch_decodes_the_batch_together_and_equals_per_sample_generat
     assert unfolded - folded == 2 * n_layers - 1, (folded, unfolded)
 
 
+def test_generate_stream_continuous_batching_keeps_slots_busy_and_equals_generate(setup):
+    """f4 continuous batching (LeopardEngine.generate_stream): 7 samples of mixed lengths through 3 decode slots — a slot whose sequence
+    ends (its own eos, or max_new_tokens) takes the next pending sample without re-creating the state; the stop rule runs on the device
+    (live mask, token budget, eos ids), the host reads the tokens once per HIST steps; a sample whose FIRST token is an eos never takes a
+    slot.  Every output equals the per-sample generate(), and the slot occupancy beats fixed groups of 3."""
+    ops, cfg, _ = setup
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    eng.HIST = 2                                                     # short windows: admissions happen inside the test's few steps
+    rng = np.random.default_rng(16)
+    def img(n):
+        return torch.from_numpy(rng.integers(0, 256, (n, 28, 28, 3), dtype=np.uint8))
+    samples = [(torch.tensor([[5, 250, 9, 250, 17]]), img(2)), (torch.tensor([[7, 8, 9]]), None), (torch.tensor([[250, 3]]), img(1)),
+               (torch.tensor([[11, 12, 13, 14, 15, 16]]), None), (torch.tensor([[9, 250]]), img(1)), (torch.tensor([[33]]), None),
+               (torch.tensor([[4, 5, 250, 6]]), img(1))]
+    T = 6
+    free = [eng.generate(ids, tiles, max_new_tokens=T, eos_token_id=()) for ids, tiles in samples]
+    # eos ids: sample 1's second new token (stops early) and sample 5's FIRST new token (finished by its prefill)
+    eos = (int(free[1][0, samples[1][0].shape[1] + 1]), int(free[5][0, samples[5][0].shape[1]]))
+    singles = [eng.generate(ids, tiles, max_new_tokens=T, eos_token_id=eos) for ids, tiles in samples]
+    assert singles[5].shape[1] == samples[5][0].shape[1] + 1 and singles[1].shape[1] < samples[1][0].shape[1] + T
+    states_before = dict(getattr(eng, "_batch_states", {}))
+    stats = {}
+    got = eng.generate_stream(samples, batch_size=3, max_new_tokens=T, eos_token_id=eos, stats=stats)
+    for one, out in zip(singles, got):
+        assert torch.equal(one, out), (one.tolist(), out.tolist())
+    st = eng._batch_states[3]
+    assert 3 not in states_before
+    # occupancy: live slot-steps / slot-steps; fixed groups [0-2], [3-5], [6] would run max-length steps for every member
+    assert stats["batch_size"] == 3 and stats["live_slot_steps"] == sum(o.shape[1] - s[0].shape[1] - 1 for o, s in zip(singles, samples))
+    assert stats["live_slot_steps"] / stats["slot_steps"] > 0.55
+    # state reused by a second stream (nothing re-created), same outputs; release drops the pools and the packed weight copy
+    again = eng.generate_stream(list(reversed(samples)), batch_size=3, max_new_tokens=T, eos_token_id=eos)
+    assert eng._batch_states[3] is st and all(torch.equal(a, b) for a, b in zip(reversed(singles), again))
+    eng.release_batch_state()
+    assert not eng._batch_states and eng._skinny_pack is None
+
+
 def test_split_operand_mode_removes_the_hand_over_roundings(setup):
     """engine.split_operands: every A operand of every layer linear handed over as hi + lo (lmi_split_hi_lo, GEMMs at 2 K against [W | W],
     fp32 hand-overs from the norms / attention / GELU / SwiGLU).  The logits must sit where the oracle that treats exactly those sites as

@@ -42,6 +42,14 @@ def _worker(rank, world, port, out):
     res = eng.prefill(ids, None, cache=cache, visual_tokens=vis)
     assert res.seq_len == S and type(eng.comm).__name__ == "TorchComm" and eng.comm.sent_bytes > 0
     step = eng.decode_step(int(res.logits_last.argmax()), cache).clone()
+    # the chunk pipeline and both exchange dtypes: row chunks per layer 1 / 2 / 4 (chunk c's collectives under chunk
+    # c + 1's GEMMs), partial products reduce-scattered in the compute type or as exact fp32 sums, the visual tokens gathered in 16 bits
+    variants = {}
+    for chunks, cdt, vdt in [(1, None, None), (4, None, None), (2, torch.float32, None), (4, torch.float32, dtype), (1, torch.float32, dtype)]:
+        eng.tp_chunks, eng.tp_comm_dtype, eng.tp_vision_gather_dtype = chunks, cdt, vdt
+        v = D.encode_images_sharded(eng, tiles)
+        variants[(chunks, str(cdt), str(vdt))] = eng.prefill(ids, None, visual_tokens=v).logits_last.float().cpu()
+    eng.tp_chunks, eng.tp_comm_dtype, eng.tp_vision_gather_dtype = 2, None, None
     ref = None
     if rank == 0:
         one = LeopardEngine(cfg, EngineWeights.build(cfg, src, dtype), ops=ops, device=dev)
@@ -50,9 +58,10 @@ def _worker(rank, world, port, out):
         s1 = one.decode_step(int(r1.logits_last.argmax()), c1)
         scale = float(r1.logits_last.abs().max())
         ref = (bool(torch.equal(vis, one.encode_images(tiles))), float((res.logits_last - r1.logits_last).abs().max()) / scale,
-               float((step - s1).abs().max()) / scale, int(res.logits_last.argmax()) == int(r1.logits_last.argmax()))
+               float((step - s1).abs().max()) / scale, int(res.logits_last.argmax()) == int(r1.logits_last.argmax()),
+               {k: float((v - r1.logits_last.float().cpu()).abs().max()) / scale for k, v in variants.items()})
     torch.cuda.synchronize()
-    out.put((rank, res.logits_last.cpu().tolist(), ref))
+    out.put((rank, res.logits_last.cpu().tolist(), ref, {k: v.tolist() for k, v in variants.items()}))
     D.barrier()
 
 
@@ -68,11 +77,13 @@ def test_tensor_parallel_and_tile_sharding_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, l0, ref), (_, l1, _) = res
-    assert l0 == l1
-    vis_equal, d_prefill, d_decode, same_argmax = ref
-    assert vis_equal                                   # tile-sharded encode + all-gather: bit-identical
+    (_, l0, ref, v0), (_, l1, _, v1) = res
+    assert l0 == l1 and v0 == v1                       # every rank holds the same logits, under every variant
+    vis_equal, d_prefill, d_decode, same_argmax, d_variants = ref
+    assert vis_equal                                   # tile-sharded encode + all-gather (default fp32 exchange): bit-identical
     assert d_prefill <= 2.5e-3 and d_decode <= 2.5e-3 and same_argmax
+    print("[tp variants] (chunks, exchange dtype, visual gather dtype) -> max|logit diff| / max|logit| vs one rank:", d_variants)
+    assert len(d_variants) == 5 and all(d <= 2.5e-3 for d in d_variants.values())
 
 
 def _rccl_worker(out):

@@ -34,7 +34,7 @@ DEV = "cuda:0"
 LOGIT_TOL = {torch.float16: 1.25e-3, torch.bfloat16: 1.03e-2}     # mid configuration, 2 + 2 layers: all-position logits 9.9e-4 / 8.2e-3 (last position 5.0e-4 / 4.0e-3)
 FULL_TOL = {("c1", torch.float16): 2.12e-3, ("c1", torch.bfloat16): 1.65e-2,      # full depth, 27 + 32 layers: 1.69e-3 / 1.32e-2
             ("c2", torch.float16): 1.46e-3, ("c2", torch.bfloat16): 1.43e-2,      #                             1.14e-3 / 1.14e-2
-            ("c3", torch.float16): 1.46e-3, ("c3", torch.bfloat16): 1.40e-2}      # C3 = the benchmarked sample:  1.17e-3 (predicted 1.02e-3) / bf16 measured below
+            ("c3", torch.float16): 1.32e-3, ("c3", torch.bfloat16): 1.16e-2}      # C3 = the benchmarked sample:  1.05e-3 (predicted 1.02e-3) / 9.25e-3
 # C3 sequence length, 2 + 2 layers: residual stream max over 29 M elements / rel-rms, ViT features, last-position logits
 C3LEN_TOL = {torch.float16: (1.13e-3, 9.2e-4, 7.3e-4, 7.1e-4),                    # measured 9.0e-4, 7.4e-4, 5.8e-4, 5.7e-4
              torch.bfloat16: (8.4e-3, 7.3e-3, 5.1e-3, 5.0e-3)}                    # measured 6.8e-3, 5.8e-3, 4.1e-3, 4.0e-3
@@ -478,6 +478,62 @@ def test_generate_batch_decodes_together_and_equals_per_sample_generate(ops):
             assert float(top2[0] - top2[1]) <= 2e-3 * float(lg.abs().max()), (j, top2)
     again = eng.generate_batch(samples, max_new_tokens=T, eos_token_id=())
     assert all(torch.equal(a, b) for a, b in zip(batch, again)) and eng._batch_states[4] is st
+
+
+@pytest.mark.gpu
+def test_generate_stream_continuous_batching_on_device(ops):
+    """f4 continuous batching on the device (LeopardEngine.generate_stream; mid configuration = full width, 2 + 2 layers): 14 samples of
+    mixed image counts / sizes through 4 decode slots with ONE captured step — slots are retired by the device-side stop rule (eos ids,
+    token budget) and re-admitted between replays; outputs == per-sample generate() (a token may differ only on a near tie of the batch-1
+    logits, as for generate_batch), no step is run by the Python body after the capture, and the live-slot occupancy is reported."""
+    from leopard_amd.engine import KVCache
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    shapes = [(1, 800, 500), (2, 1344, 896), (1, 336, 336), (1, 364, 364), (0, 0, 0), (1, 700, 420), (3, 500, 500), (1, 336, 336),
+              (0, 0, 0), (2, 800, 500), (1, 1344, 896), (1, 364, 364), (0, 0, 0), (1, 500, 800)]
+    samples = []
+    for i, (n, w, h) in enumerate(shapes):
+        if n == 0:
+            ids = torch.from_numpy(np.random.default_rng(200 + i).integers(3, 7000, (1, 9 + 5 * i)))
+            samples.append((ids, None))
+        else:
+            u8, ids, _ = sample_inputs(cfg, n, w, h, seed=100 + i)
+            samples.append((ids, torch.from_numpy(u8).to(DEV)))
+    T = 12
+    free = [eng.generate(ids, tiles, max_new_tokens=T, eos_token_id=()) for ids, tiles in samples]
+    # eos ids that make some samples stop early: sample 2's 4th new token, sample 7's 2nd, sample 9's FIRST (finished by its prefill)
+    eos = tuple({int(free[2][0, samples[2][0].shape[1] + 3]), int(free[7][0, samples[7][0].shape[1] + 1]), int(free[9][0, samples[9][0].shape[1]])})
+    singles = [eng.generate(ids, tiles, max_new_tokens=T, eos_token_id=eos) for ids, tiles in samples]
+    assert min(o.shape[1] - s[0].shape[1] for o, s in zip(singles, samples)) == 1
+    bodies = []
+    body = eng._batch_decode_body
+    eng._batch_decode_body = lambda st: (bodies.append(st.B), body(st))[1]
+    stats = {}
+    got = eng.generate_stream(samples, batch_size=4, max_new_tokens=T, eos_token_id=eos, stats=stats)
+    eng._batch_decode_body = body
+    assert len(bodies) == 2 and eng._batch_states[4].graph is not None            # warm-up + capture; every step afterwards is a replay
+    n_diff = 0
+    for (ids, tiles), one, out in zip(samples, singles, got):
+        S_in = ids.shape[1]
+        if torch.equal(one, out):
+            continue
+        n_diff += 1                                                    # allowed only as a near tie of the batch-1 logits at the first difference
+        j = int((one[0, :min(one.shape[1], out.shape[1])] != out[0, :min(one.shape[1], out.shape[1])]).nonzero()[0])
+        cache = KVCache(cfg, one.shape[1] + 2048, torch.float16, DEV)
+        eng.prefill(ids, tiles, cache=cache)
+        lg, nxt = None, int(one[0, S_in])
+        for t in range(S_in + 1, j + 1):
+            lg = eng.decode_step(nxt, cache).clone()
+            nxt = int(one[0, t])
+        top2 = lg.topk(2).values
+        assert float(top2[0] - top2[1]) <= 2e-3 * float(lg.abs().max()), (j, top2)
+    occ = stats["live_slot_steps"] / stats["slot_steps"]
+    print(f"[generate_stream] 14 samples, 4 slots, T = {T}: {stats['steps']} steps, live-slot occupancy {occ:.2f}, "
+          f"{n_diff} sample(s) differ from generate() on a near tie")
+    assert n_diff <= 2 and occ > 0.5
+    again = eng.generate_stream(samples, batch_size=4, max_new_tokens=T, eos_token_id=eos)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    eng.release_batch_state()
 
 
 @pytest.mark.gpu
