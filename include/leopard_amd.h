@@ -226,6 +226,17 @@ int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* 
                             const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                             int ldq, int ldk, int ldv, float scale, int causal, int window, int dtype, void* stream);
 
+/* Caller-owned scratch of a prefill pass (SURVEY.md 8b "workspace: size from lmi_*_workspace_bytes"; the library allocates nothing).
+ * One contiguous, 256-byte aligned workspace per stage holds every activation buffer that lives between the launches of one pass — the
+ * Llama / Mistral layer stack over `rows` packed sequence rows (reference: LlamaForCausalLM.forward, EVAL:322-333), the SigLIP layer
+ * stack over `rows` = n_vit_inputs x tokens (EVAL:268-273).  Returns the total bytes (-1: bad argument, lmi_last_error); `offsets`
+ * (nullable) receives the byte offset of buffer LMI_WS_* inside the workspace.  The fp32 residual streams, the KV cache and the logits
+ * are results, not scratch: they stay separate caller buffers. */
+enum { LMI_WS_LLM_H = 0, LMI_WS_LLM_QKV = 1, LMI_WS_LLM_ATT = 2, LMI_WS_LLM_GU = 3, LMI_WS_LLM_SQ_A = 4, LMI_WS_LLM_SQ_B = 5, LMI_WS_LLM_COUNT = 6 };
+enum { LMI_WS_VIT_H = 0, LMI_WS_VIT_QKV = 1, LMI_WS_VIT_ATT = 2, LMI_WS_VIT_FF = 3, LMI_WS_VIT_COUNT = 4 };
+int64_t lmi_llm_prefill_workspace_bytes(int64_t rows, int hidden, int n_q_heads, int n_kv_heads, int head_dim, int ff, int dtype, int64_t* offsets);
+int64_t lmi_vit_workspace_bytes(int64_t rows, int hidden, int qkv_width, int ff_padded, int dtype, int64_t* offsets);
+
 /* a12 (next row f2: the decode loop) — the same attention for a few query rows against a long KV cache: the key range is
  * split over workgroups (512 keys each, at most 64 splits), partial (O, max, sum) go to `workspace` and are merged.
  * Replaces the attention inside the decode branch of the reference forward (EVAL:291-333).  Causal (bottom-right), GQA,

@@ -79,6 +79,10 @@ def bind(path: str) -> C.CDLL:
         fn.restype = C.c_int
     lib.lmi_attn_decode_workspace_bytes.argtypes = [_I, _I, _I, _I]
     lib.lmi_attn_decode_workspace_bytes.restype = C.c_int64
+    lib.lmi_llm_prefill_workspace_bytes.argtypes = [C.c_int64, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int64)]
+    lib.lmi_llm_prefill_workspace_bytes.restype = C.c_int64
+    lib.lmi_vit_workspace_bytes.argtypes = [C.c_int64, _I, _I, _I, _I, C.POINTER(C.c_int64)]
+    lib.lmi_vit_workspace_bytes.restype = C.c_int64
     lib.lmi_last_error.argtypes = []
     lib.lmi_last_error.restype = C.c_char_p
     return lib

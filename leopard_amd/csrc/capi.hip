@@ -947,6 +947,45 @@ int lmi_split_hi_lo(const float* x, void* out, int M, int K, int ldx, int ldo, i
     return check_launch("lmi_split_hi_lo");
 }
 
+// ---- caller-owned scratch of a prefill pass ("workspace: size from lmi_*_workspace_bytes"; the library allocates nothing) ----------
+// One contiguous workspace per stage holds every activation buffer that lives between the launches of one pass; `offsets` (nullable)
+// receives the byte offset of each buffer (256-byte aligned; the order is the LMI_WS_* enums of the header).
+static int64_t ws_carve(const int64_t* sizes, int n, int64_t* offsets) {
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (offsets) offsets[i] = off;
+        off += (sizes[i] + 255) / 256 * 256;
+    }
+    return off;
+}
+int64_t lmi_llm_prefill_workspace_bytes(int64_t rows, int hidden, int n_q_heads, int n_kv_heads, int head_dim, int ff, int dtype, int64_t* offsets) {
+    if (rows < 0 || hidden <= 0 || n_q_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || ff <= 0 || (dtype != LMI_F16 && dtype != LMI_BF16)) {
+        fail(LMI_EINVAL, "lmi_llm_prefill_workspace_bytes: bad argument");
+        return -1;
+    }
+    const int64_t es = 2, parts = (hidden + 63) / 64;
+    const int64_t sizes[LMI_WS_LLM_COUNT] = {
+        rows * hidden * es,                                          // LMI_WS_LLM_H    normalised rows / T(x * gamma) handed to q|k|v and gate/up
+        rows * (int64_t)(n_q_heads + 2 * n_kv_heads) * head_dim * es,  // LMI_WS_LLM_QKV  packed q | k | v rows
+        rows * (int64_t)n_q_heads * head_dim * es,                    // LMI_WS_LLM_ATT  attention output = o_proj operand
+        rows * (int64_t)ff * es,                                      // LMI_WS_LLM_GU   SwiGLU product = down_proj operand
+        rows * parts * 4,                                             // LMI_WS_LLM_SQ_A row-square partials feeding gate/up (folded RMSNorm)
+        rows * parts * 4};                                            // LMI_WS_LLM_SQ_B ... feeding the next layer's q|k|v
+    return ws_carve(sizes, LMI_WS_LLM_COUNT, offsets);
+}
+int64_t lmi_vit_workspace_bytes(int64_t rows, int hidden, int qkv_width, int ff_padded, int dtype, int64_t* offsets) {
+    if (rows < 0 || hidden <= 0 || qkv_width <= 0 || ff_padded <= 0 || (dtype != LMI_F16 && dtype != LMI_BF16)) {
+        fail(LMI_EINVAL, "lmi_vit_workspace_bytes: bad argument");
+        return -1;
+    }
+    const int64_t es = 2;
+    const int64_t sizes[LMI_WS_VIT_COUNT] = {rows * hidden * es,     // LMI_WS_VIT_H    LayerNorm output (q|k|v / fc1 operand; the post-LN features)
+                                             rows * (int64_t)qkv_width * es,   // LMI_WS_VIT_QKV
+                                             rows * hidden * es,     // LMI_WS_VIT_ATT  attention output = out_proj operand
+                                             rows * (int64_t)ff_padded * es};  // LMI_WS_VIT_FF   GELU(fc1) = fc2 operand
+    return ws_carve(sizes, LMI_WS_VIT_COUNT, offsets);
+}
+
 int64_t lmi_attn_decode_workspace_bytes(int q_rows, int n_heads, int head_dim, int max_seqlen_k) {
     if (q_rows < 0 || n_heads <= 0 || head_dim <= 0 || max_seqlen_k < 0) return -1;
     const int tiles = (max_seqlen_k + ATT_BKV - 1) / ATT_BKV;      // the most splits any launch shape takes: one per tile, at most 64

@@ -116,6 +116,7 @@ class LeopardEngine:
         # all-gather of the projected visual tokens: None = fp32 (bit-identical to one rank: the rows are merged into the fp32 residual stream,
         # which carries them unrounded through every layer); the 16-bit compute type halves the bytes (58 MB at C3) at one extra rounding
         self._comm_stream = None
+        self._workspaces: Dict[str, torch.Tensor] = {}   # caller-owned scratch per stage (lmi_llm_prefill_workspace_bytes / lmi_vit_workspace_bytes)
         self.graph_encode = False      # capture the vision encode per ViT-input count in a HIP graph (BASELINE config 5)
         self._encode_graphs: Dict[tuple, tuple] = {}   # (ViT-input count, stream) -> (graph, static in, static out)
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
@@ -167,6 +168,21 @@ class LeopardEngine:
 
     def _empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    def _carve(self, which: str, total: int, offsets, specs):
+        """Views into the engine's caller-owned workspace of stage ``which`` ("llm" / "vit"; SURVEY.md 8b: sized by the library's
+        lmi_*_workspace_bytes, owned by the caller): ONE uint8 allocation per stage, grown when a larger pass arrives and reused by every
+        later one, carved at the byte offsets the library returned.  specs: [(rows, cols, dtype)] in LMI_WS_* order."""
+        ws = self._workspaces.get(which)
+        if ws is None or ws.numel() < total:
+            ws = self._workspaces[which] = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
+            if which == "vit":
+                self._encode_graphs.clear()                         # graphs captured over the old workspace point into freed memory
+        out = []
+        for off, (r, c, dt) in zip(offsets, specs):
+            nbytes = r * c * torch.empty(0, dtype=dt).element_size()
+            out.append(ws[off:off + nbytes].view(dt).view(r, c))
+        return out
 
     def _pinned_to_device(self, t: torch.Tensor) -> torch.Tensor:
         """Host tensor -> device without blocking the host on the stream (pinned staging + async copy)."""
@@ -221,10 +237,9 @@ class LeopardEngine:
             return self._vit_layers_fp8(x, n)
         if self.split_operands:
             return self._vit_layers_split(x, n)
-        h = self._empty(M, D)
-        qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0]) if W.vit_layers else None
-        att = self._empty(M, D)
-        ff = self._empty(M, W.vit_ff)
+        qkv_w = W.vit_layers[0].qkv_w.shape[0] if W.vit_layers else 3 * D
+        total, offs = ops.vit_workspace(M, D, qkv_w, W.vit_ff, self.dtype)
+        h, qkv, att, ff = self._carve("vit", total, offs, [(M, D, self.dtype), (M, qkv_w, self.dtype), (M, D, self.dtype), (M, W.vit_ff, self.dtype)])
         scale = hd ** -0.5
         rec = self._rec
         for li, L in enumerate(W.vit_layers):
@@ -458,10 +473,10 @@ class LeopardEngine:
             if cache is not None:
                 cache.length = S
             return self._lm_head(x, last_rows, all_logits)
-        h = self._empty(S, D)
-        qkv = self._empty(S, qw + 2 * kw)
-        att = self._empty(S, qw)
-        gu = self._empty(S, W.llm_ff)
+        parts = (D + 63) // 64
+        total, offs = ops.llm_prefill_workspace(S, D, H, KV, hd, W.llm_ff, self.dtype)
+        h, qkv, att, gu, sq_a, sq_b = self._carve("llm", total, offs, [(S, D, self.dtype), (S, qw + 2 * kw, self.dtype), (S, qw, self.dtype),
+                                                                         (S, W.llm_ff, self.dtype), (S, parts, torch.float32), (S, parts, torch.float32)])
         tmp = self._empty(S, D, dtype=torch.float32) if self.tp_size > 1 else None
         scale = hd ** -0.5
         # Fused schedule (one rank, head_dim 128): the RMSNorms and the RoPE ride in the GEMM epilogues.  Each residual GEMM
@@ -472,10 +487,7 @@ class LeopardEngine:
                  and W.llm_layers[0].qkv_w_rope is not None)
         rec = self._rec
         if fused:
-            parts = D // 64
-            sq_a = self._empty(S, parts, dtype=torch.float32)       # partials feeding gate/up
-            sq_b = self._empty(S, parts, dtype=torch.float32)       # partials feeding the next layer's qkv
-            n_layers = len(W.llm_layers)
+            n_layers = len(W.llm_layers)                            # sq_a: partials feeding gate/up; sq_b: feeding the next layer's qkv
             for i, L in enumerate(W.llm_layers):
                 if i == 0:
                     ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
@@ -585,7 +597,7 @@ class LeopardEngine:
             if keep_parts:
                 vit = self.vision_tower(tiles)
                 visual_tokens = self.project(vit, n_tiles)
-                parts["vit"] = vit
+                parts["vit"] = vit.clone()                       # (the tower's output is a view of the reused "vit" workspace)
             else:
                 visual_tokens = self.encode_images(tiles)
         elif visual_tokens is not None:

@@ -195,6 +195,24 @@ class Ops:
                                                  k_cache.stride(0), int(cache_stride), _ptr(pos_rows), _DT[w_rope.dtype], self._stream(qkv)))
         return qkv
 
+    def llm_prefill_workspace(self, rows, hidden, n_q_heads, n_kv_heads, head_dim, ff, dtype):
+        """lmi_llm_prefill_workspace_bytes -> (total bytes, [byte offset of LMI_WS_LLM_* buffer])."""
+        import ctypes as C
+        offs = (C.c_int64 * 6)()
+        n = int(self.lib.lmi_llm_prefill_workspace_bytes(int(rows), hidden, n_q_heads, n_kv_heads, head_dim, ff, _DT[dtype], offs))
+        if n < 0:
+            raise RuntimeError("lmi_llm_prefill_workspace_bytes: " + self.lib.lmi_last_error().decode())
+        return n, list(offs)
+
+    def vit_workspace(self, rows, hidden, qkv_width, ff_padded, dtype):
+        """lmi_vit_workspace_bytes -> (total bytes, [byte offset of LMI_WS_VIT_* buffer])."""
+        import ctypes as C
+        offs = (C.c_int64 * 4)()
+        n = int(self.lib.lmi_vit_workspace_bytes(int(rows), hidden, qkv_width, ff_padded, _DT[dtype], offs))
+        if n < 0:
+            raise RuntimeError("lmi_vit_workspace_bytes: " + self.lib.lmi_last_error().decode())
+        return n, list(offs)
+
     def decode_workspace_elems(self, q_rows, n_heads, head_dim, max_seqlen_k) -> int:
         n = int(self.lib.lmi_attn_decode_workspace_bytes(q_rows, n_heads, head_dim, max_seqlen_k))
         if n < 0:

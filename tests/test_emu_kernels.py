@@ -42,7 +42,7 @@ def test_abi_exports_every_declared_symbol(ops):
     import os
     declared = _declared_symbols()
     assert len(declared) >= 18 and "lmi_gemm" in declared and "lmi_attn_decode_fwd" in declared
-    bound = set(_lib.SIGNATURES) | {"lmi_last_error", "lmi_attn_decode_workspace_bytes"}
+    bound = set(_lib.SIGNATURES) | {"lmi_last_error", "lmi_attn_decode_workspace_bytes", "lmi_llm_prefill_workspace_bytes", "lmi_vit_workspace_bytes"}
     assert set(declared) == bound, set(declared) ^ bound
     for name in declared:
         assert hasattr(ops.lib, name), name
@@ -942,3 +942,21 @@ def test_attention_rows64_sliding_window_and_reference_moves(ops, variant):
     finally:
         ops.set_option("attn.rows64", 0)
         ops.set_option("attn.rows64_min", 1024)
+
+
+def test_prefill_workspace_api(ops):
+    """SURVEY.md 8b "caller owns every buffer incl. workspace (size from lmi_*_workspace_bytes)": the two prefill-stage size functions return
+    256-byte aligned, non-overlapping buffers in the LMI_WS_* order whose sizes are the activation buffers of one pass, and reject bad
+    arguments with -1 + lmi_last_error."""
+    S, D, H, KV, hd, ff = 7187, 4096, 32, 8, 128, 14336
+    total, offs = ops.llm_prefill_workspace(S, D, H, KV, hd, ff, torch.float16)
+    sizes = [S * D * 2, S * (H + 2 * KV) * hd * 2, S * H * hd * 2, S * ff * 2, S * (D // 64) * 4, S * (D // 64) * 4]
+    assert offs[0] == 0 and all(o % 256 == 0 for o in offs) and total % 256 == 0
+    for i in range(6):
+        end = offs[i + 1] if i + 1 < 6 else total
+        assert sizes[i] <= end - offs[i] < sizes[i] + 256
+    M, Dv = 42 * 676, 1152
+    total_v, offs_v = ops.vit_workspace(M, Dv, 3456, 4352, torch.bfloat16)
+    assert offs_v == sorted(offs_v) and total_v >= M * (2 * Dv + 3456 + 4352) * 2 and total_v < M * (2 * Dv + 3456 + 4352) * 2 + 4 * 256
+    assert ops.lib.lmi_llm_prefill_workspace_bytes(-1, D, H, KV, hd, ff, 0, None) == -1 and b"workspace" in ops.lib.lmi_last_error()
+    assert ops.lib.lmi_vit_workspace_bytes(10, Dv, 3456, 4352, 2, None) == -1                  # LMI_F32 is not a compute type
