@@ -558,6 +558,37 @@ def test_c5_size_batch_properties(ops):
     assert torch.equal(one.logits_last, logits[0])
 
 
+@pytest.mark.gpu
+def test_configs4_fp8_at_the_8x8_size_with_graph_encode(ops):
+    """BASELINE configs[4] AS WRITTEN — batch 8 x 8 images of 1344x896 (320 ViT inputs, 8 x 6861 tokens in one packed pass), fp8 (e4m3)
+    layer linears, HIP-graph-captured encode — at the mid depth, in property form: every sample of the packed fp8 batch reproduces its
+    own single-sample fp8 prefill bit for bit (packing and graph replay change no bit), equal samples give equal logits wherever they
+    sit, the encode really is replayed from a graph, and the fp8 schedule really ran (its logits differ from the f16 schedule's by the
+    e4m3 budget, not by zero)."""
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    u8, ids, plan = sample_inputs(cfg, 8, 1344, 896, seed=11)
+    assert plan.n_vit_inputs == 40
+    tiles = torch.from_numpy(u8).to(DEV)
+    u8b, idsb, _ = sample_inputs(cfg, 8, 1344, 896, seed=12)
+    tiles_b = torch.from_numpy(u8b).to(DEV)
+    f16_one = eng.prefill(ids, tiles).logits_last.clone()
+    eng.enable_fp8(_fp8_calibration(cfg))
+    eng.graph_encode = True
+    one_a = eng.prefill(ids, tiles).logits_last.clone()
+    one_b = eng.prefill(idsb, tiles_b).logits_last.clone()
+    samples = [(ids, tiles), (idsb, tiles_b)] * 4                    # 8 samples, 320 ViT inputs
+    for rep in range(2):                                             # capture of the 320-input encode, then its replay
+        logits, seq_lens = eng.prefill_batch(samples)
+        assert len(seq_lens) == 8 and seq_lens[0] == ids.shape[1] + 40 * 168 and torch.isfinite(logits).all()
+        for i in range(8):
+            assert torch.equal(logits[i], one_a if i % 2 == 0 else one_b), (rep, i)
+    assert any(k[0] == 320 for k in eng._encode_graphs)
+    rel = ((one_a - f16_one).pow(2).mean().sqrt() / f16_one.pow(2).mean().sqrt()).item()
+    print(f"[configs[4] size, mid depth] fp8 vs f16 schedule, relative RMS of the last-position logits: {rel:.3e}")
+    assert 1e-2 < rel < 0.5
+
+
 def test_graph_captured_encode_is_bit_identical(ops):
     """BASELINE config 5's "hipGraph-captured encode": vision tower + projector replayed from a HIP graph per ViT-input count
     == the eager launches, bit for bit, for two different counts and fresh pixel data on every replay."""
