@@ -257,6 +257,14 @@ int lmi_attn_decode_pool(const void* q, const void* k, const void* v, void* out,
                          int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
                          int dtype, void* stream);
 
+/* The tail of a greedy decode step (EVAL:448-452: argmax, stop at eos / max_new_tokens) for B sequences, in device memory only (it sits
+ * inside the captured step): tok[b] = argmax of logits row b over [0, vocab) (lowest index on ties; ids in `suppress` excluded), recorded
+ * in hist[hist_pos[b] % hist_len][b] (hist_pos[b] += 1); budget[b] -= live[b]; a sequence whose token is one of `eos` (entries < 0 unused)
+ * or whose budget reached 0 gets live[b] = 0; pos[b] += live[b], k_len[b] += live[b].  live / budget / hist / k_len / suppress nullable
+ * (null live = every sequence runs on; the batch-1 step passes its one position and key count). */
+int lmi_decode_advance(const float* logits, int B, int vocab, int ld_logits, const int64_t* suppress, int n_suppress, int64_t* tok, int* pos,
+                       int* k_len, int* live, int* budget, const int64_t* eos, int n_eos, int64_t* hist, int* hist_pos, int hist_len, void* stream);
+
 /* RoPE (rotate-half; cos/sin fp32 [S, head_dim/2] built from position_ids and the llama3-scaled inverse
  * frequencies, rotary_pos_embedding.py:48-83,197-239) applied in place to the q and k heads of packed qkv rows
  * [S, ld]; when k_cache/v_cache are non-null also appends rotated K and V to the cache rows cache_pos0.. */

@@ -58,6 +58,7 @@ SIGNATURES = {
     "lmi_gemm_skinny_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _I, _P, _P, _I, _P],
     "lmi_debug_copy": [_P, _P, C.c_int64, _I, _P],
     "lmi_gemm_skinny": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_decode_advance": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     "lmi_lm_head_last": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_comm_unique_id": [_P],
     "lmi_comm_init": [_I, _I, _P, C.POINTER(C.c_void_p)],

@@ -1124,6 +1124,20 @@ int lmi_embed_merge(const int64_t* ids, const int64_t* src, const void* embed_ta
                    (merge_impl<bf16_t>(ids, src, embed_table, visual_tokens, out, S, D, ld_feats, stream)));
 }
 
+int lmi_decode_advance(const float* logits, int B, int vocab, int ld_logits, const int64_t* suppress, int n_suppress, int64_t* tok, int* pos,
+                       int* k_len, int* live, int* budget, const int64_t* eos, int n_eos, int64_t* hist, int* hist_pos, int hist_len, void* stream) {
+    if (!logits || !tok || !pos || B < 0 || vocab <= 0 || ld_logits < vocab || n_suppress < 0 || (n_suppress && !suppress) || n_eos < 0 ||
+        (n_eos && !eos) || (hist && (!hist_pos || hist_len <= 0)))
+        return fail(LMI_EINVAL, "lmi_decode_advance: bad argument");
+    if (B == 0) return LMI_OK;
+    DecodeAdvanceArgs a;
+    a.logits = logits; a.vocab = vocab; a.ld_logits = ld_logits; a.suppress = suppress; a.n_suppress = n_suppress; a.tok = tok; a.pos = pos;
+    a.k_len = k_len; a.live = live; a.budget = budget; a.eos = eos; a.n_eos = n_eos; a.hist = hist; a.hist_pos = hist_pos; a.hist_len = hist_len;
+    a.B = B;
+    LMI_LAUNCH(decode_advance_kernel, dim3(B), dim3(1024), 0, stream, a);
+    return check_launch("lmi_decode_advance");
+}
+
 int lmi_gemv(const void* W, const void* x, const float* bias, void* out, int N, int K, int ldw, int epilogue, int dtype,
              void* stream) {
     if (!W || !x || !out || N <= 0 || K <= 0 || (K & 7) || (ldw & 7) || K > 28 * 512 || (epilogue == 3 && (N & 63)))

@@ -403,6 +403,72 @@ __global__ void embed_merge_kernel(const long* ids, const long* src, const T* ta
 }
 
 // ------------------------------------------------------------------------------------------------
+// The tail of a greedy decode step (EVAL:448-452: argmax, stop at eos / max_new_tokens), for B sequences at once and entirely in
+// device memory, so that it sits inside the captured step: one workgroup per sequence takes the argmax of its logits row (lowest index on
+// ties), writes the token, records it in the sequence's history ring, and applies the stop rule — a sequence that produced an eos id or
+// used up its token budget stops advancing (live = 0: its position and key count freeze; what it produces afterwards is ignored).
+// ------------------------------------------------------------------------------------------------
+struct DecodeAdvanceArgs {
+    const float* logits;      // [B, ld_logits] fp32
+    int vocab, ld_logits;
+    const int64_t* suppress;  // optional: token ids that may never be chosen
+    int n_suppress;
+    int64_t* tok;             // [B] out: the chosen token
+    int* pos;                 // [B] += live
+    int* k_len;               // [B] += live (nullable)
+    int* live;                // [B] nullable: 1 = running (null: always running)
+    int* budget;              // [B] nullable: tokens the sequence may still produce
+    const int64_t* eos;       // [n_eos] (entries < 0 are unused)
+    int n_eos;
+    int64_t* hist;            // [hist_len, B] nullable: hist[hist_pos[b] % hist_len][b] = tok
+    int* hist_pos;            // [B] per-sequence step counter of the ring
+    int hist_len, B;
+};
+__global__ void __launch_bounds__(1024) decode_advance_kernel(DecodeAdvanceArgs a) {
+    __shared__ float best_v[16];
+    __shared__ int best_i[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = a.logits + (long)b * a.ld_logits;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < a.vocab; i += blockDim.x) {
+        float v = row[i];
+        for (int j = 0; j < a.n_suppress; ++j)
+            if (a.suppress[j] == i) v = -INFINITY;
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = shfl_xor(bv, m);
+        const int oi = shfl_xor(bi, m);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { best_v[wave] = bv; best_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        const int nw = (int)(blockDim.x >> 6);
+        for (int w = 1; w < nw; ++w)
+            if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
+        if (bi == 0x7fffffff) bi = 0;                               // a row of NaN / -inf only
+        a.tok[b] = bi;
+        int lv = a.live ? a.live[b] : 1;
+        if (a.hist) {
+            const int hp = a.hist_pos[b];
+            a.hist[(long)(hp % a.hist_len) * a.B + b] = bi;
+            a.hist_pos[b] = hp + 1;
+        }
+        int bud = 1;
+        if (a.budget) { bud = a.budget[b] - lv; a.budget[b] = bud; }
+        bool stop = bud <= 0;
+        for (int j = 0; j < a.n_eos; ++j) stop = stop || (a.eos[j] == (int64_t)bi);
+        if (stop) lv = 0;
+        if (a.live) a.live[b] = lv;
+        a.pos[b] += lv;
+        if (a.k_len) a.k_len[b] += lv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight-streaming GEMV (M = 1): out[n] = W[n,:] . x  — last-token lm_head and the decode step.
 // One wave per output row (per gate/up row pair for SwiGLU); x is held in registers; W streams 16 B / lane.
 // ------------------------------------------------------------------------------------------------

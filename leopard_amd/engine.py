@@ -864,12 +864,8 @@ class LeopardEngine:
                 ops.gemv(L.gu_w, st.h[0], st.gu[0], epilogue=3)
             row_parallel(L.down_w, st.gu[0])
         ops.lm_head_last(W.lm_head, st.x, None, W.final_norm, tc.rms_norm_eps, st.logits.view(1, -1))
-        # greedy choice and position advance stay on the device (torch ops as plumbing; all capturable)
-        if self.suppress_tokens is not None:
-            st.logits.index_fill_(0, self.suppress_tokens, float("-inf"))
-        torch.argmax(st.logits[:tc.vocab_size], dim=0, keepdim=True, out=st.tok)
-        st.pos.add_(1)
-        st.cu_k[1:].add_(1)
+        # greedy choice and position / key-count advance stay on the device, one launch (lmi_decode_advance; capturable)
+        ops.decode_advance(st.logits.view(1, -1), tc.vocab_size, st.tok, st.pos, k_len=st.cu_k[1:], suppress=self.suppress_tokens)
 
     def _decode_run(self, st, cache: KVCache):
         # Tensor parallel: the step holds 2 all-reduces per layer.  Through RcclComm they are plain stream-ordered RCCL launches, which
@@ -1031,7 +1027,7 @@ class LeopardEngine:
         st.budget = torch.full((B,), 1 << 30, dtype=torch.int32, device=dev)
         st.eos = torch.full((self.MAX_EOS,), -1, dtype=torch.int64, device=dev)
         st.hist = torch.zeros(self.HIST, B, dtype=torch.int64, device=dev)
-        st.hist_idx = torch.zeros(1, dtype=torch.int64, device=dev)
+        st.hist_pos = torch.zeros(B, dtype=torch.int32, device=dev)
         st.graph = None
         # bounded: a serving process that sees many batch sizes keeps the pools of the two most recent ones (each is B x capacity KV rows)
         while len(states) >= 2:
@@ -1093,25 +1089,17 @@ class LeopardEngine:
         # head: one pass over lm_head for all B rows (lmi_lm_head_last streams the 1 GB head once PER row)
         ops.rmsnorm(st.x, W.final_norm, st.h, eps)
         ops.gemm_skinny(pk["head"] if pk else W.lm_head, st.h, st.logits, 3, pk is not None)
-        if self.suppress_tokens is not None:
-            st.logits.index_fill_(1, self.suppress_tokens, float("-inf"))
-        torch.argmax(st.logits[:, :tc.vocab_size], dim=1, out=st.tok)
-        # the step's tokens into the history ring; a slot stops advancing (its position / key count freeze, what it produces afterwards is
-        # ignored) once it produced an eos id or used up its token budget — device arithmetic only, no host value
-        st.hist.index_copy_(0, st.hist_idx, st.tok.unsqueeze(0))
-        st.hist_idx.add_(1).remainder_(self.HIST)
-        st.budget.sub_(st.live)
-        stop = (st.tok.unsqueeze(1) == st.eos.unsqueeze(0)).any(dim=1) | (st.budget <= 0)
-        st.live.mul_((~stop).to(torch.int32))
-        st.pos.add_(st.live)
-        st.k_len.add_(st.live)
+        # greedy choice, history ring, stop rule (eos ids / token budget) and position advance of all B slots: ONE launch, device memory only —
+        # a slot that stopped freezes (live = 0) and what it produces afterwards is ignored (lmi_decode_advance)
+        ops.decode_advance(st.logits, tc.vocab_size, st.tok, st.pos, k_len=st.k_len, live=st.live, budget=st.budget, eos=st.eos, hist=st.hist,
+                           hist_pos=st.hist_pos, suppress=self.suppress_tokens)
 
     def _batch_decode_run(self, st):
         if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs:
             self._batch_decode_body(st)
             return
         if st.graph is None:
-            names = ("tok", "pos", "k_len", "live", "budget", "hist", "hist_idx")
+            names = ("tok", "pos", "k_len", "live", "budget", "hist", "hist_pos")
             keep = [getattr(st, n).clone() for n in names]
             side = torch.cuda.Stream(device=self.device)               # warm-up outside capture (function attributes, allocator)
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -1138,7 +1126,7 @@ class LeopardEngine:
         st.tok.copy_(torch.tensor(nxt, dtype=torch.int64))
         st.pos.copy_(torch.tensor(seq_lens, dtype=torch.int32))
         st.k_len.copy_(torch.tensor([s + 1 for s in seq_lens], dtype=torch.int32))
-        st.live.fill_(1); st.budget.fill_(1 << 30); st.eos.fill_(-1); st.hist_idx.zero_()      # the host applies the stop rule here
+        st.live.fill_(1); st.budget.fill_(1 << 30); st.eos.fill_(-1); st.hist_pos.zero_()      # the host applies the stop rule here
         for step in range(max_new_tokens):
             for j in range(B):
                 if not done[j]:
@@ -1187,7 +1175,7 @@ class LeopardEngine:
         st.eos.fill_(-1)
         if eos:
             st.eos[:len(eos)].copy_(torch.tensor(eos, dtype=torch.int64))
-        st.live.zero_(); st.budget.zero_(); st.pos.zero_(); st.k_len.fill_(1); st.tok.zero_(); st.hist_idx.zero_()
+        st.live.zero_(); st.budget.zero_(); st.pos.zero_(); st.k_len.fill_(1); st.tok.zero_(); st.hist_pos.zero_()
         eos_set = set(eos)
         outs: List[Optional[List[int]]] = [None] * len(samples)
         slot_sample = [-1] * B                                       # which sample a slot runs (-1: free)
@@ -1228,7 +1216,7 @@ class LeopardEngine:
             admit(j)
         while any(i >= 0 for i in slot_sample):
             window = self.HIST
-            st.hist_idx.zero_()
+            st.hist_pos.zero_()
             for _ in range(window):
                 self._batch_decode_run(st)
             toks = st.hist.tolist()                                   # ONE host read per window: [HIST][B]

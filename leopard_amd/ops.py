@@ -213,6 +213,13 @@ class Ops:
             raise RuntimeError("lmi_vit_workspace_bytes: " + self.lib.lmi_last_error().decode())
         return n, list(offs)
 
+    def decode_advance(self, logits, vocab, tok, pos, k_len=None, live=None, budget=None, eos=None, hist=None, hist_pos=None, suppress=None):
+        """lmi_decode_advance: greedy choice + stop rule + position advance of B decode sequences, on the device (graph-capturable)."""
+        B = logits.shape[0]
+        self._check(self.lib.lmi_decode_advance(_ptr(logits), B, int(vocab), logits.stride(0), _ptr(suppress), 0 if suppress is None else suppress.numel(),
+                                                _ptr(tok), _ptr(pos), _ptr(k_len), _ptr(live), _ptr(budget), _ptr(eos), 0 if eos is None else eos.numel(),
+                                                _ptr(hist), _ptr(hist_pos), 0 if hist is None else hist.shape[0], self._stream(logits)))
+
     def decode_workspace_elems(self, q_rows, n_heads, head_dim, max_seqlen_k) -> int:
         n = int(self.lib.lmi_attn_decode_workspace_bytes(q_rows, n_heads, head_dim, max_seqlen_k))
         if n < 0:

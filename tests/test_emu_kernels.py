@@ -960,3 +960,40 @@ def test_prefill_workspace_api(ops):
     assert offs_v == sorted(offs_v) and total_v >= M * (2 * Dv + 3456 + 4352) * 2 and total_v < M * (2 * Dv + 3456 + 4352) * 2 + 4 * 256
     assert ops.lib.lmi_llm_prefill_workspace_bytes(-1, D, H, KV, hd, ff, 0, None) == -1 and b"workspace" in ops.lib.lmi_last_error()
     assert ops.lib.lmi_vit_workspace_bytes(10, Dv, 3456, 4352, 2, None) == -1                  # LMI_F32 is not a compute type
+
+
+def test_decode_advance_argmax_stop_rule_and_history(ops):
+    """lmi_decode_advance: per-row argmax (lowest index on ties, suppressed ids excluded), history ring, stop rule (eos ids, budget) and the
+    frozen state of stopped sequences, against a plain restatement."""
+    B, V, ld, H = 5, 1000, 1024, 3
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(B, ld, generator=g)
+    logits[:, V:] = 100.0                                           # padding columns past the vocabulary must be ignored
+    logits[1, 17] = logits[1, 400] = 50.0                           # a tie: the lower index wins
+    logits[2, 5] = 60.0                                             # suppressed: the runner-up must be chosen
+    suppress = torch.tensor([5], dtype=torch.int64)
+    want = []
+    for b in range(B):
+        row = logits[b, :V].clone()
+        row[5] = float("-inf")
+        want.append(int(row.argmax()))
+    want[1] = 17
+    tok = torch.zeros(B, dtype=torch.int64)
+    pos = torch.tensor([10, 20, 30, 40, 50], dtype=torch.int32)
+    k_len = pos + 1
+    live = torch.tensor([1, 1, 0, 1, 1], dtype=torch.int32)         # sequence 2 already stopped
+    budget = torch.tensor([5, 1, 9, 7, 3], dtype=torch.int32)       # sequence 1 produces its last token now
+    eos = torch.tensor([want[3], -1], dtype=torch.int64)            # sequence 3 hits its eos
+    hist = torch.full((H, B), -7, dtype=torch.int64)
+    hist_pos = torch.tensor([0, 1, 2, 3, 4], dtype=torch.int32)
+    ops.decode_advance(logits, V, tok, pos, k_len=k_len, live=live, budget=budget, eos=eos, hist=hist, hist_pos=hist_pos, suppress=suppress)
+    assert tok.tolist() == want
+    assert live.tolist() == [1, 0, 0, 0, 1] and budget.tolist() == [4, 0, 9, 6, 2]
+    assert pos.tolist() == [11, 20, 30, 40, 51] and k_len.tolist() == [12, 21, 31, 41, 52]
+    assert hist_pos.tolist() == [1, 2, 3, 4, 5]
+    for b in range(B):
+        assert int(hist[b % H, b]) == want[b]
+    # the batch-1 form: no live / budget / history
+    t1, p1, k1 = torch.zeros(1, dtype=torch.int64), torch.tensor([7], dtype=torch.int32), torch.tensor([8], dtype=torch.int32)
+    ops.decode_advance(logits[4:5], V, t1, p1, k_len=k1)
+    assert int(t1) == int(logits[4, :V].argmax()) and int(p1) == 8 and int(k1) == 9
