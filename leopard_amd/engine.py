@@ -1247,7 +1247,10 @@ class LeopardEngine:
         ONE packed prefill — all ViT inputs through the tower together, all merged sequences in one varlen causal pass that also
         writes every sample's K/V into a packed cache — then each sample's K/V rows move to its slot of the pooled decode cache (a
         device copy) and ALL samples continue greedily together, one captured decode step per token for the whole batch
-        (``_batch_decode_body``: the weight stream of a step is shared by the batch).  Same tokens as per-sample ``generate``."""
+        (``_batch_decode_body``: the weight stream of a step is shared by the batch).  Same RULE as per-sample ``generate`` and numerically
+        equivalent, not bit-identical: the first new token comes from the same prefill, the continuation's projections are MFMA tiles with folded
+        norms instead of the batch-1 FMA chains, so a greedy choice can differ where the top two logits are within the 16-bit noise (the GPU
+        tests assert equality and, where it fails, exactly such a near tie)."""
         assert self.tp_size == 1, "batched generation is a single-rank feature (replicas scale it out)"
         if len(samples) > self.MAX_DECODE_BATCH:
             outs = []
