@@ -431,12 +431,30 @@ __global__ void __launch_bounds__(1024) decode_advance_kernel(DecodeAdvanceArgs 
     const float* row = a.logits + (long)b * a.ld_logits;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < a.vocab; i += blockDim.x) {
-        float v = row[i];
+    auto take = [&](float v, int i) {
         for (int j = 0; j < a.n_suppress; ++j)
             if (a.suppress[j] == i) v = -INFINITY;
         if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    };
+    // 16 bytes per lane, four loads in flight per thread: the row is 0.5 MB and ONE workgroup scans it — the scan is load latency, not bandwidth
+    const int v4 = ((((size_t)row) & 15) == 0) ? (a.vocab >> 2) : 0;
+    for (int i0 = tid; i0 < v4; i0 += 4 * (int)blockDim.x) {
+        f32x4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            q[u] = i < v4 ? *(const f32x4*)(row + 4 * (long)i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < v4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) take(q[u][e], 4 * i + e);
+            }
+        }
     }
+    for (int i = 4 * v4 + tid; i < a.vocab; i += blockDim.x) take(row[i], i);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const float ov = shfl_xor(bv, m);

@@ -965,7 +965,7 @@ def test_prefill_workspace_api(ops):
 def test_decode_advance_argmax_stop_rule_and_history(ops):
     """lmi_decode_advance: per-row argmax (lowest index on ties, suppressed ids excluded), history ring, stop rule (eos ids, budget) and the
     frozen state of stopped sequences, against a plain restatement."""
-    B, V, ld, H = 5, 1000, 1024, 3
+    B, V, ld, H = 5, 1003, 1024, 3                                  # 250 vector loads + a 3-element tail per row
     g = torch.Generator().manual_seed(3)
     logits = torch.randn(B, ld, generator=g)
     logits[:, V:] = 100.0                                           # padding columns past the vocabulary must be ignored
