@@ -524,7 +524,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-tp", action="store_true", help="N > 1: skip the additional one-sample-on-all-ranks (strong scaling) measurement")
-    ap.add_argument("--tp-timeout", type=float, default=240.0, help="watchdog of the additional tensor-parallel measurement, seconds")
+    ap.add_argument("--tp-timeout", type=float, default=150.0, help="watchdog of the additional tensor-parallel measurement, seconds")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
