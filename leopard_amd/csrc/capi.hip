@@ -476,11 +476,12 @@ int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, in
     return check_launch("lmi_attn_decode_fwd");
 }
 
-template <typename T, bool PACKED>
+std::atomic<int> g_skinny_coalesce{1};       // nn.Linear-layout weights of the M <= 16 kernel: 1 = coalescing lane order + ds_bpermute (LAYOUT 2), 0 = MFMA lane order
+template <typename T, int LAYOUT>
 int skinny_impl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, void* stream,
                 const RopeEpi& rp = RopeEpi(), const SkinnyNorm& nm = SkinnyNorm()) {
     const int units = (epilogue == LMI_SKINNY_SWIGLU || epilogue == 4) ? N / 32 : N / 16;
-#define LMI_SK(E) LMI_LAUNCH((skinny_gemm_kernel<T, E, PACKED>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo, rp, nm)
+#define LMI_SK(E) LMI_LAUNCH((skinny_gemm_kernel<T, E, LAYOUT>), dim3(units), dim3(512), 0, stream, (const T*)W, (const T*)X, out, M, N, K, ldw, ldx, ldo, rp, nm)
     switch (epilogue) {
         case LMI_SKINNY_STORE: LMI_SK(SK_STORE_T); break;
         case LMI_SKINNY_RESIDUAL: LMI_SK(SK_RESID_F32); break;
@@ -564,6 +565,7 @@ int lmi_set_option(const char* key, int value) {
                 return LMI_OK;
             }
     }
+    if (!strcmp(key, "skinny.coalesce")) { g_skinny_coalesce = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.dma")) { g_attn_dma = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "attn.rows64")) {
         if (value < 0 || value > 2) return fail(LMI_EINVAL, "lmi_set_option: attn.rows64 in {0, 1, 2}");
@@ -1058,10 +1060,13 @@ int lmi_gemm_skinny_ex(const void* W, const void* X, void* out, int M, int N, in
         return rc;
     if (M == 0) return LMI_OK;
     if (packed)
-        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)),
-                       (skinny_impl<bf16_t, true>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)));
-    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)),
-                   (skinny_impl<bf16_t, false>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)));
+        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, 1>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)),
+                       (skinny_impl<bf16_t, 1>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)));
+    if (g_skinny_coalesce.load())
+        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, 2>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)),
+                       (skinny_impl<bf16_t, 2>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)));
+    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, 0>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)),
+                   (skinny_impl<bf16_t, 0>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)));
 }
 
 int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed, int dtype,
@@ -1085,10 +1090,13 @@ int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, 
     rp.cos_all = cos_all; rp.sin_all = sin_all; rp.pos = pos_rows_dev; rp.k_cache = k_cache; rp.v_cache = v_cache; rp.ld_cache = ld_cache;
     rp.cache_stride = (long)cache_stride; rp.rope_q = n_q_heads * head_dim; rp.rope_k = n_kv_heads * head_dim;
     if (packed)
-        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, true>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)),
-                       (skinny_impl<bf16_t, true>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
-    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, false>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)),
-                   (skinny_impl<bf16_t, false>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
+        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, 1>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)),
+                       (skinny_impl<bf16_t, 1>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
+    if (g_skinny_coalesce.load())
+        LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, 2>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)),
+                       (skinny_impl<bf16_t, 2>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
+    LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, 0>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)),
+                   (skinny_impl<bf16_t, 0>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
 }
 
 int lmi_rope_qk_rows(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all, const float* sin_all,

@@ -182,6 +182,7 @@ LMI_DEV void lgkm_fence(u32x2 (&lo)[N], u32x2 (&hi)[N]) {
                      : "i"(CNT));
 }
 
+LMI_DEV int shfl_idx(int v, int src) { return __shfl(v, src, 64); }                       // ds_bpermute_b32: lane <- lane src
 LMI_DEV float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 LMI_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 // v_permlane32_swap_b32: lanes 32..63 of `a` trade places with lanes 0..31 of `b` (no LDS round trip)
@@ -355,6 +356,7 @@ inline S emu_shfl_idx(S v, int src) {
     hipemu::wave_sync();
     return r;
 }
+inline int shfl_idx(int v, int src) { return emu_shfl_idx(v, src); }
 inline float shfl_xor(float v, int m) { return emu_shfl_idx(v, lane_id() ^ m); }
 inline int shfl_xor(int v, int m) { return emu_shfl_idx(v, lane_id() ^ m); }
 inline void swap_hi_lo(unsigned& a, unsigned& b) {

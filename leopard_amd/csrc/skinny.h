@@ -12,9 +12,13 @@
 // costs (M / 16) of the weight stream's VMEM issue slots and nothing else.
 // Weight layout.  In the nn.Linear layout a wave instruction gathers 64 separate 16-byte pieces (adjacent lanes = adjacent ROWS):
 // the address path takes one lane per clock, 64 cycles per KiB, and the kernel is bound by VMEM issue (~4 TB/s) instead of HBM.
-// PACKED = true reads weights pre-arranged in the MFMA operand order (leopard_amd.weights.skinny_pack, done once at load):
+// LAYOUT 1 (packed) reads weights pre-arranged in the MFMA operand order (leopard_amd.weights.skinny_pack, done once at load):
 // block (16-row group r, k-step s, 32-k chunk c) is 1 KiB with lane l's 16 bytes at l * 16 — one fully coalesced 1-KiB request
-// per instruction.  Both layouts give the same bits.
+// per instruction.  LAYOUT 2 reads the nn.Linear layout with a COALESCING lane order — lane l takes piece l & 3 of row l >> 2, so four
+// adjacent lanes cover 64 contiguous bytes of a row and a wave instruction is 16 segments of 64 bytes instead of 64 separate 16-byte
+// pieces — and then moves every dword to the lane the MFMA wants it in with one ds_bpermute_b32 (lane 16 g + i <- lane 4 i + g): no second
+// copy of the weights.  LAYOUT 0 = the nn.Linear layout read in the MFMA lane order directly (the slow reference form).  All three give
+// the same bits.
 // Requirements: K % 128 == 0, N % 16 == 0 (SwiGLU: N % 64 == 0, rows interleaved [32 gate | 32 up] as weights.py lays gate/up out),
 // 16-byte aligned rows.
 #pragma once
@@ -46,10 +50,11 @@ struct SkinnyNorm {
     float* rowsq_out;         // [M, N / 16]
 };
 
-template <typename T, int EPI, bool PACKED>
+template <typename T, int EPI, int LAYOUT>
 __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, RopeEpi rp,
                                                           SkinnyNorm nm) {
     typedef typename vec_of<T>::x8 T8;
+    constexpr bool PACKED = (LAYOUT == 1), COAL = (LAYOUT == 2);
     constexpr bool PAIR = (EPI == SK_SWIGLU_T || EPI == SK_QKV_ROPE_T);
     constexpr int NW = PAIR ? 2 : 1;                               // weight row blocks per workgroup (gate, up / first half, rotate-half partner)
     constexpr int DEPTH = PAIR ? 2 : 3;                            // k-steps of loads in flight per wave (<= 128 VGPRs: two workgroups per CU)
@@ -71,7 +76,9 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
 #pragma unroll
     for (int b = 0; b < NW; ++b)
         wrow[b] = PACKED ? W + (long)((row0 + 32 * b) >> 4) * nsteps_all * 2048 + lane * 8      // 16-row group x k-steps x 4 KiB
+                  : COAL ? W + (long)(row0 + 32 * b + (lane >> 2)) * ldw + 8 * (lane & 3)        // row l >> 2, 16-byte piece l & 3
                          : W + (long)(row0 + 32 * b + i) * ldw + 8 * g;
+    const int src_lane = 4 * i + g;                                // COAL: MFMA lane (i, g) = 16 g + i takes what lane 4 i + g loaded
     const T* xrow = X + (long)i * ldx + 8 * g;
     const bool has_x = i < M;
     const int nsteps = K >> 7;
@@ -107,7 +114,16 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int b = 0; b < NW; ++b) acc[b] = mfma16(wv[d][b][c], xv[d][c], acc[b]);
+                    for (int b = 0; b < NW; ++b) {
+                        T8 wf = wv[d][b][c];
+                        if (COAL) {                                 // lane transpose of the 16 x 4 piece grid, one dword at a time
+                            u32x4 raw = __builtin_bit_cast(u32x4, wf);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) raw[e] = (uint32_t)shfl_idx((int)raw[e], src_lane);
+                            wf = __builtin_bit_cast(T8, raw);
+                        }
+                        acc[b] = mfma16(wf, xv[d][c], acc[b]);
+                    }
                 if (s + DEPTH < my_steps) load(d, s + DEPTH);
             }
         }
