@@ -62,6 +62,10 @@ int lmi_abi_version(void);
  *   "attn.stream_kv"  1 = non-temporal K / V tile loads in GQA-packed decode blocks (default), 0 = default cache policy
  *   "gemv.plan"     1 = decode GEMV grid of a whole number of equal workgroups per CU when the shape allows (default), 0 = ~1000 workgroups
  *   "gemm.mid_m" / "gemm.auto_small"  M-complete 384 x 128 tiles for 256 < M <= 384 / small-shape geometries (default 1)
+ *   "attn.rows64"   0 = the production attention kernel for every launch (default); 1 / 2 = long head_dim-128 self-attention prefills take the
+ *                   software-pipelined kernels of csrc/attention64.h (64 rows per wave / 32 rows per wave, two waves per SIMD) — verified, slower
+ *   "attn.rows64_min"  shortest max_seqlen_q that takes them (default 1024)
+ *   "skinny.coalesce"  lmi_gemm_skinny* on nn.Linear-layout weights: 1 = coalescing lane order + ds_bpermute (default), 0 = MFMA lane order
  * Unknown keys and out-of-range values return LMI_EINVAL. */
 int lmi_set_option(const char* key, int value);
 
