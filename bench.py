@@ -298,6 +298,36 @@ def enable_fp8(eng, cfg, args):
     torch.cuda.empty_cache()
 
 
+def fixture_parity(args, ctx, res):
+    """The TIMED step's last-position logits against the committed full-depth oracle fixture of the same sample (tests/golden/c{1,2,3}_full_depth.npz,
+    written by tools/gen_fulldepth_fixtures.py: the fp32 CPU oracle = the reference's arithmetic, EVAL:248-333, on host cores) — the parity figure of
+    the benchmarked configuration, at the benchmarked depth, from the benchmarked run.  Data only: no oracle code runs here.  None when the sample is
+    not one of the fixtures' (other image arguments, rank > 0, several samples in flight) or for a dtype line without a parity claim (fp8)."""
+    import hashlib
+    label = config_label(args).lower()
+    path = os.path.join(REPO, "tests", "golden", f"{label}_full_depth.npz")
+    if res is None or label not in ("c1", "c2", "c3") or not os.path.exists(path) or args.dtype == "fp8":
+        return None
+    z = np.load(path)
+    same_ids = z["ids"].shape == tuple(ctx.ids.shape) and bool((z["ids"] == ctx.ids.cpu().numpy()).all())
+    same_tiles = hashlib.sha256(np.ascontiguousarray(ctx.tiles.cpu().numpy()).tobytes()).digest() == z["tiles_sha256"].tobytes()
+    if not (same_ids and same_tiles):
+        return None
+    ref = torch.from_numpy(z["logits_fp32"])
+    got = res.logits_last.float().cpu()
+    d = got - ref
+    tag = {"f16": "fp16", "bf16": "bf16"}.get(args.dtype)
+    pred = None
+    if tag and f"logits_emu_{tag}" in z.files:
+        pred = float((torch.from_numpy(z[f"logits_emu_{tag}"]) - ref).abs().max() / ref.abs().max())
+    return {"fixture": os.path.relpath(path, REPO), "vs": "fp32 CPU oracle, full depth (27 + 32 layers), last-position logits",
+            "max_abs": round(float(d.abs().max()), 6), "normalised_max": round(float(d.abs().max() / ref.abs().max()), 6),
+            "rel_rms": round(float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), 6), "max_abs_logit": round(float(ref.abs().max()), 4),
+            "argmax_equal": bool(int(got.argmax()) == int(ref.argmax())),
+            "predicted_normalised_max_16bit_operands": None if pred is None else round(pred, 6),
+            "north_star_1e-3": "met" if float(d.abs().max() / ref.abs().max()) <= 1e-3 else "x%.2f" % (float(d.abs().max() / ref.abs().max()) / 1e-3)}
+
+
 def config_label(args) -> str:
     """BASELINE.json configuration the image arguments correspond to (C3 = the metric's own, the default)."""
     key = (args.images, args.width, args.height)
@@ -696,6 +726,8 @@ def main():
         "weight_load_s": round(load_s, 1),
     }
 
+    if rank == 0:
+        out["parity"] = fixture_parity(args, ctxs[0], res if args.inflight == 1 else None)
     if rank == 0 and not args.no_roofline:
         def once():
             with torch.cuda.stream(ctxs[0].stream):
