@@ -59,4 +59,16 @@ if not fp8:
             bad_b += 1
     print(f"batched decode (4 samples x 8 tokens): {max(2, reps // 5)} repetitions, {bad_b} mismatches")
     bad += bad_b
+    # continuous batching (generate_stream: slots retired / re-admitted between replays of one captured step, device-side stop rule)
+    more = samples + [(torch.from_numpy(synth_prompt_ids([], cfg, seed=50 + j)).reshape(1, -1), None) for j in range(3)]
+    eos = (int(ref_b[1][0, samples[1][0].shape[1] + 2]),)          # sample 1 stops at its third new token
+    ref_s, bad_s = None, 0
+    for r in range(max(2, reps // 5)):
+        outs = eng.generate_stream(more, batch_size=3, max_new_tokens=10, eos_token_id=eos)
+        if ref_s is None:
+            ref_s = outs
+        elif not all(torch.equal(a, b) for a, b in zip(ref_s, outs)):
+            bad_s += 1
+    print(f"continuous batching (7 samples, 3 slots, 10 tokens): {max(2, reps // 5)} repetitions, {bad_s} mismatches")
+    bad += bad_s
 sys.exit(1 if bad else 0)
