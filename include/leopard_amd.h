@@ -122,7 +122,15 @@ int lmi_add_rmsnorm(float* x, const void* delta, int delta_dtype, const float* w
  * Requires N % 128 == 0, K % 64 == 0.  A, W are T; bias/addmat fp32 (nullable); addmat row = add_rows[m] when add_rows is
  * given (NaViT bucketised position ids), else m % add_period; row_map (nullable) scatters
  * output row m to row row_map[m].  For LMI_A_PIXEL_SHUFFLE, A is the ViT output [tiles*G*G, K/4] and M counts
- * shuffled rows (tiles*(G/2)^2). */
+ * shuffled rows (tiles*(G/2)^2).
+ *
+ * W layouts (lmi_gemm, lmi_gemm_bias_act, lmi_gemm_ex, lmi_rmsnorm_rope).  ldw > 0: the nn.Linear layout, row n at W + n * ldw.
+ * ldw = LMI_LDW_PACKED(K): W is stored in the operand order the decode kernels stream (lmi_gemm_skinny, packed = 1): 1-KiB blocks
+ * [16-row group][k-step of 128][32-k chunk][lane 16 g + i][8 elements] = W[16 r + i][128 s + 32 c + 8 g + j]; needs K % 128 == 0,
+ * N % 16 == 0, plain A.  That order permutes the 16-byte pieces of the row-major matrix inside (16 rows x 64 k) tiles, and the GEMM's
+ * LDS-DMA lanes pick their source piece: the LDS image, the MFMA order and every output bit are those of the row-major call.  ONE
+ * copy of the LLM weights then serves prefill and decode (leopard_amd.weights.skinny_pack / LeopardEngine.pack_llm_weights). */
+#define LMI_LDW_PACKED(K) (-(K))
 int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
              const int* row_map, int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
              int ps_grid, int dtype, void* stream);

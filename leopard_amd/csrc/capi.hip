@@ -697,6 +697,13 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
                       const int* row_map, int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
                       int ps_grid, int dtype, void* stream, const GemmExtras& x) {
     if (!A || !W || !out) return fail(LMI_EINVAL, "%s: null pointer", who);
+    // ldw = LMI_LDW_PACKED(K) = -K: W in the operand order of lmi_gemm_skinny (one copy of the weights for prefill and decode)
+    const bool w_packed = ldw < 0;
+    if (w_packed) {
+        if (ldw != -K || (K % 128) || (N % 16) || a_mode != LMI_A_PLAIN)
+            return fail(LMI_EINVAL, "%s: packed W needs ldw == -K, K %% 128 == 0, N %% 16 == 0 and a plain A (N=%d K=%d ldw=%d)", who, N, K, ldw);
+        ldw = K;
+    }
     if (M < 0 || N <= 0 || K <= 0 || (N % 128) || (K % GEMM_BK))
         return fail(LMI_EINVAL, "%s: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", who, M, N, K);
     if ((lda & 7) || (ldw & 7) || (ldo & 3) || !aligned16(A) || !aligned16(W) || !aligned16(out) ||
@@ -728,6 +735,7 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     a.ld_cache = x.ld_cache; a.cache_pos0 = x.cache_pos0; a.rope_q = x.rope_q; a.rope_k = x.rope_k;
     a.scale_e8m0 = 0x7f7f7f7f;
     a.out_scale = 1.0f;
+    a.w_packed = w_packed ? 1 : 0;
     // extents for the buffer resources the LDS-DMA reads through (32-bit offsets)
     const long a_rows = (a_mode == LMI_A_PIXEL_SHUFFLE) ? (long)(M / ((ps_grid / 2) * (ps_grid / 2))) * ps_grid * ps_grid : (long)M;
     const long a_cols = (a_mode == LMI_A_PIXEL_SHUFFLE) ? K / 4 : K;

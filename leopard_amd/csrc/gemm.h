@@ -50,6 +50,7 @@ struct GemmArgs {
     int group_m;          // row-tiles per L2 group in the XCD-aware tile order
     int order;            // 0 = each XCD owns a contiguous slab of the grouped order; 1 = XCDs take 32-tile chunks round-robin
     unsigned a_bytes, w_bytes;   // extents of A and W (buffer resources of the LDS-DMA; both < 4 GiB)
+    int w_packed;         // W is stored in the operand order of lmi_gemm_skinny (weights.skinny_pack) instead of row-major: see GemmStager
     // ---- RMSNorm folded into the GEMMs around it (Llama / Mistral layers) ---------------------------------------------------
     // producer (EPI_RESID_F32): besides x += acc, write norm_out[m, n] = T(x[m, n] * norm_gamma[n]) — the NEXT RMSNorm's gain
     // applied, its row scale still missing — and rowsq_out[m, n / 64] = sum of x[m, n..n+63]^2 (one partial per wave column
@@ -138,6 +139,37 @@ LMI_DEV typename GemmFrag<TA>::type gemm_frag_load(const char* tile, int row, in
     } else {
         return *(const typename GemmFrag<TA>::type*)(tile + gemm_lds_off(row, ks * 2 + fh));
     }
+}
+// W operand staged from the PACKED weight order (GemmArgs::w_packed, 16-bit operands).  The packed order keeps the 16-byte pieces of 16
+// consecutive rows with the same k-piece adjacent in memory (what the decode kernel's lanes want), so a DMA lane quad that fetches FOUR
+// CHUNKS OF ONE ROW — the row-major image's lane order — touches four cache lines instead of one (measured: C3 step 150.0 ms against 134.0).
+// The W image therefore changes with the source: every 1-KiB piece (8 rows x 8 chunks) is stored chunk-major — slot (c ^ (piece & 1)) * 8 + j
+// holds chunk c of the piece's row j — so that a lane quad fetches the same chunk of four consecutive rows (64 contiguous bytes, an octet
+// one full 128-byte line, exactly the row-major traffic pattern).  Reads: a 16-lane ds_read_b128 group takes rows 0..7 of an even and
+// of an odd piece at one chunk: 8 consecutive 16-byte slots each, in opposite 128-byte halves of the 256-byte bank row (the parity
+// flip) — conflict-free.  Same fragments, same MFMA order, same bits as the row-major call.
+LMI_DEV int gemm_lds_off_wp(int r, int lc) { return (r >> 3) * 1024 + ((((lc ^ ((r >> 3) & 1)) << 3) + (r & 7)) << 4); }
+// Per-lane W fragment offsets, fixed before the main loop so that the layout choice is a select of three loop invariants and never
+// control flow inside it: for row R0 + fr (R0 a multiple of 32) and chunk lc = 2 ks + fh both images are
+//     R0 * 128 + lane_base + ((lc ^ X) << SH)      row-major: lane_base = fr * 128,                         X = (fr >> 1) & 7, SH = 4
+//                                                  packed:    lane_base = (fr >> 3) * 1024 + (fr & 7) * 16, X = (fr >> 3) & 1, SH = 7
+// (gemm_lds_off / gemm_lds_off_wp with the R0 terms folded: R0 / 2 is a multiple of 8, R0 / 8 is even).
+template <typename TA> struct GemmWOff {
+    static constexpr int KS = GemmFrag<TA>::KS;
+    int ko[KS];
+    LMI_DEV void init(int w_packed, int fr, int fh) {
+        const bool wp = sizeof(TA) == 2 && w_packed;
+        const int lane_base = wp ? (fr >> 3) * 1024 + (fr & 7) * 16 : fr * 128;
+        const int x = wp ? (fr >> 3) & 1 : (fr >> 1) & 7;
+        const int sh = wp ? 7 : 4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ko[ks] = lane_base + (((ks * 2 + fh) ^ x) << sh);
+    }
+};
+template <typename TA>
+LMI_DEV typename GemmFrag<TA>::type gemm_wfrag_load(const char* tile, int r0, int fr, int ks, int fh, const GemmWOff<TA>& wo) {
+    if constexpr (sizeof(TA) == 1) return gemm_frag_load<TA>(tile, r0 + fr, ks, fh);
+    else return *(const typename GemmFrag<TA>::type*)(tile + r0 * 128 + wo.ko[ks]);
 }
 LMI_DEV f32x16 gemm_mma(f16x8 a, f16x8 b, f32x16 c, int) { return mfma32(a, b, c); }
 LMI_DEV f32x16 gemm_mma(bf16x8 a, bf16x8 b, f32x16 c, int) { return mfma32(a, b, c); }
@@ -449,11 +481,18 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
 // and swizzled on the source side; loop-invariant 32-bit lane offsets, the k-tile advances a scalar offset.  Tail rows
 // are clamped to the last valid row (their products are masked on store).  In pixel-shuffle mode logical A row m is the
 // 2x2 neighbourhood of ViT tokens of shuffled token m, its K axis the four (dh, dw) segments of C channels.
+// W in the PACKED order (p.w_packed; 16-bit operands): the layout lmi_gemm_skinny streams — 16-row group rg, 128-k step s, 32-k chunk c
+// form one 1-KiB block at ((rg * K/128 + s) * 4 + c) * 1024 with the 16-byte piece (row i, 8-k piece g) at (16 g + i) * 16 — is a
+// permutation of the 16-byte pieces of the row-major matrix that keeps every row group and every 64-k tile together: tile kt of a
+// row group is the two consecutive blocks at kt * 2048.  An LDS-DMA lane picks its source piece freely, so the same fragments (the same
+// MFMA order, the same bits) are staged from either layout: the loop-invariant lane offset, the scalar step per k-tile and the order
+// of the pieces inside the W image (gemm_lds_off_wp) differ.  One copy of the LLM weights then serves the prefill GEMM and the decode kernels.
 template <int AMODE, typename C, int ES = 2>          // ES = bytes per operand element (2: f16 / bf16, 1: fp8)
 struct GemmStager {
     BufRsrc a_buf, w_buf;
     unsigned a_src[C::A_PASSES], w_src[C::W_PASSES];
     int ps_c, ps_grid, lda;
+    unsigned w_kstep;                                    // bytes a k-tile advances every W lane offset by
     char* wave_base;
 
     LMI_DEV void init(const GemmArgs& p, int m0, int n0, int tid, char* smem, int wave) {
@@ -481,8 +520,17 @@ struct GemmStager {
         for (int ps = 0; ps < C::W_PASSES; ++ps) {
             const int r = ps * C::ROWS_PER_PASS + srow;
             const int lc = pc ^ ((r >> 1) & 7);
-            w_src[ps] = (unsigned)((long)imin(n0 + r, p.N - 1) * p.ldw * ES + lc * 16);
+            if (ES == 2 && p.w_packed) {
+                // chunk-major piece (gemm_lds_off_wp): lane l of the wave's piece = row l & 7, slot l >> 3
+                const int l = tid & 63, rp = ps * C::ROWS_PER_PASS + wave * 8 + (l & 7);
+                const int c = (l >> 3) ^ ((rp >> 3) & 1);
+                const int n = imin(n0 + rp, p.N - 1);
+                w_src[ps] = (unsigned)((long)(n >> 4) * 32 * p.K + (c >> 2) * 1024 + ((c & 3) * 16 + (n & 15)) * 16);
+            } else {
+                w_src[ps] = (unsigned)((long)imin(n0 + r, p.N - 1) * p.ldw * ES + lc * 16);
+            }
         }
+        w_kstep = (ES == 2 && p.w_packed) ? 2048u : 128u;
         ps_c = (AMODE == AMODE_PIXSHUF) ? (p.K >> 2) : 1;    // channels per shuffle segment
         ps_grid = p.ps_grid;
         lda = p.lda;
@@ -501,7 +549,7 @@ struct GemmStager {
             glds16_buf(a_buf, a_src[g], a_off, base + g * (C::ROWS_PER_PASS * 128));
         } else {
             const int gw = g - C::A_PASSES;
-            glds16_buf(w_buf, w_src[gw], (unsigned)kt * 128u, base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
+            glds16_buf(w_buf, w_src[gw], (unsigned)kt * w_kstep, base + C::A_BYTES + gw * (C::ROWS_PER_PASS * 128));
         }
     }
 };
@@ -552,6 +600,8 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
+    GemmWOff<TA> w_off;
+    w_off.init(p.w_packed, fr, fh);
     const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
 
     // ---- prologue: D tiles in flight -----------------------------------------------------------------------------
@@ -578,7 +628,7 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < C::MI; ++i) af[i] = gemm_frag_load<TA>(a_t, wm * C::WTM + i * 32 + fr, ks, fh);
 #pragma unroll
-            for (int i = 0; i < C::NI; ++i) wf[i] = gemm_frag_load<TA>(w_t, wn * C::WTN + i * 32 + fr, ks, fh);
+            for (int i = 0; i < C::NI; ++i) wf[i] = gemm_wfrag_load<TA>(w_t, wn * C::WTN + i * 32, fr, ks, fh, w_off);
             if (do_issue) {
 #pragma unroll
                 for (int g = ks * C::G / KS; g < (ks + 1) * C::G / KS; ++g) issue_piece(g, t_issue, slot_issue);
@@ -651,6 +701,8 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
+    GemmWOff<TA> w_off;
+    w_off.init(p.w_packed, fr, fh);
     const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
 #pragma unroll
     for (int g = 0; g < C::G; ++g) issue_piece(g, 0, 0);
@@ -685,7 +737,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
                 if (FULL || i < nmi) af[i] = gemm_frag_load<TA>(a_t, wm * C::WTM + i * 32 + fr, ks, fh);
 #pragma unroll
             for (int i = 0; i < C::NI; ++i)
-                if (FULL || nmi > 0) wf[i] = gemm_frag_load<TA>(w_t, wn * C::WTN + i * 32 + fr, ks, fh);
+                if (FULL || nmi > 0) wf[i] = gemm_wfrag_load<TA>(w_t, wn * C::WTN + i * 32, fr, ks, fh, w_off);
             if (ks < KS_ISSUE && ISSUE) {
 #pragma unroll
                 for (int g = ks * C::G / KS_ISSUE; g < (ks + 1) * C::G / KS_ISSUE; ++g) issue_piece(g, t + 1, (t + 1) & 1);

@@ -93,7 +93,7 @@ class KVCache:
 
 class LeopardEngine:
     def __init__(self, cfg: LeopardConfig, weights: EngineWeights, ops: Optional[Ops] = None, device=None,
-                 use_tr: bool = True, comm=None):
+                 use_tr: bool = True, comm=None, pack_llm_weights: Optional[bool] = None):
         self.cfg, self.W = cfg, weights
         self.ops = ops if ops is not None else Ops()
         self.dtype = weights.dtype
@@ -127,7 +127,7 @@ class LeopardEngine:
         # distance to the fp32 reference are gone (full-depth logits within north_star's 1e-3; ~1.8x the prefill time).  Prefill only.
         self.split_operands = False
         self.skinny_fold_norm = True   # batched decode: RMSNorms folded into the projections (lmi_gemm_skinny_ex producer / consumer); False: norm launches
-        self.skinny_packed = True      # batched decode: stream the projections from a copy in the MFMA operand order (coalesced 1-KiB loads)
+        self.skinny_packed = True      # batched decode over nn.Linear-layout weights (TP, pack_llm_weights=False): stream a packed second copy
         self.fp8_fused = True          # fp8 schedule: attention writes the fp8 o_proj operand, q|k|v GEMM does RoPE + KV append (False: separate launches)
         self._fp8 = None               # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
         self._rec = None               # calibration recorder callable((tower, layer, site), operand tensor)
@@ -135,6 +135,11 @@ class LeopardEngine:
         self._inv_freq = llama3_inv_freq(tc.head_dim, tc.rope_theta, tc.rope_scaling).to(self.device)
         self._geom_cache: Dict[tuple, tuple] = {}      # seq_lens -> (cu, cos, sin, last_rows) device tensors
         self._vit_cu_cache: Dict[int, torch.Tensor] = {}
+        # ONE copy of the LLM weights (default; LMI_PACK_LLM_WEIGHTS=0 / pack_llm_weights=False keep the nn.Linear layout): see pack_llm_weights
+        if pack_llm_weights is None:
+            pack_llm_weights = os.environ.get("LMI_PACK_LLM_WEIGHTS", "1") == "1"
+        if pack_llm_weights:
+            self.pack_llm_weights()
 
     # ------------------------------------------------------------------------------------------------
     @property
@@ -155,6 +160,55 @@ class LeopardEngine:
         """(query heads, kv heads) this rank computes."""
         tc = self.cfg.text_config
         return (getattr(self.W, "llm_heads", 0) or tc.num_attention_heads, getattr(self.W, "llm_kv_heads", 0) or tc.num_key_value_heads)
+
+    # ---- one copy of the LLM weights ----------------------------------------------------------------------------------------------
+    @property
+    def llm_packed(self) -> bool:
+        from .weights import is_packed
+        return bool(self.W.llm_layers) and is_packed(self.W.llm_layers[0].o_w)
+
+    def pack_llm_weights(self) -> bool:
+        """Store the Llama / Mistral layer linears ONCE, in the operand order the decode kernels stream (weights.skinny_pack), in place.
+        The prefill GEMM stages its LDS image from that order too (ldw = LMI_LDW_PACKED(K): the packed order is a permutation of the
+        16-byte pieces an LDS-DMA lane picks anyway — same image, same MFMA order, same bits, csrc/gemm.h GemmStager), the batch-1 decode
+        step runs on lmi_gemm_skinny with one row, and the natural-order duplicate of q|k|v (1.6 GB for Llama-3.1-8B) is dropped:
+        16.1 GB of layer weights are resident instead of 17.7 GB + a 15 GB second copy for batched decoding.  Single rank, head_dim 128,
+        K % 128 == 0 (the conditions of the batched decode); returns False (and changes nothing) otherwise.  lm_head, embeddings and the
+        vision side keep the nn.Linear layout."""
+        from .weights import as_packed
+        W = self.W
+        if self.llm_packed:
+            return True
+        if not (self.tp_size == 1 and W.llm_layers and all(L.qkv_w_rope is not None for L in W.llm_layers) and self._batch_decode_supported()
+                and self.dtype in (torch.float16, torch.bfloat16)):
+            return False
+        for L in W.llm_layers:
+            for name in ("qkv_w_rope", "o_w", "gu_w", "down_w"):
+                setattr(L, name, as_packed(getattr(L, name)))
+            L.qkv_w = None
+        self._skinny_pack = None
+        return True
+
+    def unpack_llm_weights(self) -> None:
+        """Back to the nn.Linear layout (A/B runs, tools that read the weights)."""
+        from .weights import as_row_major
+        if not self.llm_packed:
+            return
+        for L in self.W.llm_layers:
+            L.qkv_w = self._qkv_natural(L)
+            for name in ("qkv_w_rope", "o_w", "gu_w", "down_w"):
+                setattr(L, name, as_row_major(getattr(L, name)))
+        self._batch_states = {}                               # captured steps hold the packed tensors' launches
+
+    def _qkv_natural(self, L) -> torch.Tensor:
+        """q | k | v projection rows in their natural (checkpoint) order, row-major — kept beside the rope-ordered rows only while the
+        weights are unpacked; rebuilt from them otherwise (rope_permute_rows is its own inverse)."""
+        if L.qkv_w is not None:
+            return L.qkv_w
+        from .weights import as_row_major, rope_permute_rows
+        (H, KV), hd = self._llm_heads(), self.cfg.text_config.head_dim
+        w = as_row_major(L.qkv_w_rope)
+        return torch.cat([rope_permute_rows(w[:(H + KV) * hd], hd), w[(H + KV) * hd:]], dim=0).contiguous()
 
     def _row_parallel(self, a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, tmp: Optional[torch.Tensor]):
         """x += a @ w.T for o_proj / down_proj.  Single rank: fused in the GEMM's fp32 residual epilogue.  Tensor parallel: the
@@ -300,7 +354,8 @@ class LeopardEngine:
         """[W | W] copies of the layer-linear weights (K doubled), built on first use: +0.8 GB (SigLIP) + 14 GB (Llama-3.1-8B)."""
         sw = getattr(self, "_split_w", None)
         if sw is None:
-            dup = lambda w: torch.cat([w, w], dim=1).contiguous()
+            from .weights import as_row_major
+            dup = lambda w: (lambda r: torch.cat([r, r], dim=1).contiguous())(as_row_major(w))
             W = self.W
             sw = self._split_w = {
                 "vit": [(dup(L.qkv_w), dup(L.o_w), dup(L.fc1_w), dup(L.fc2_w)) for L in W.vit_layers],
@@ -508,8 +563,12 @@ class LeopardEngine:
             for i, L in enumerate(W.llm_layers):
                 ops.rmsnorm(x, L.in_norm, h, tc.rms_norm_eps)
                 rec and rec(("llm", i, "h1"), h)
-                ops.gemm(h, L.qkv_w, qkv)
-                ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
+                if L.qkv_w is not None:
+                    ops.gemm(h, L.qkv_w, qkv)
+                    ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
+                else:                                    # packed weights keep the rope-ordered rows only: projection + RoPE + KV append on the normalised rows
+                    ops.rmsnorm_rope(h, L.qkv_w_rope, qkv, None, tc.rms_norm_eps, cos, sin, cache.k[i] if cache else None,
+                                     cache.v[i] if cache else None, 0, H, KV, hd)
                 ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
                               True, self.use_tr, window=tc.sliding_window or 0)
                 rec and rec(("llm", i, "att"), att)
@@ -820,6 +879,8 @@ class LeopardEngine:
         st.h, st.qkv, st.att = self._empty(1, D), self._empty(1, (H + 2 * KV) * hd), self._empty(1, H * hd)
         st.gu = self._empty(1, W.llm_ff)
         st.part = torch.zeros(D, dtype=torch.float32, device=dev)     # tensor parallel: partial o_proj / down_proj row
+        st.sq_a, st.sq_b = self._empty(1, max(D // 16, 1), dtype=torch.float32), self._empty(1, max(D // 16, 1), dtype=torch.float32)
+        st.k_begin = torch.zeros(1, dtype=torch.int32, device=dev)    # packed weights: the step runs on the batched-decode kernels with one row
         st.logits = self._empty(W.lm_head.shape[0], dtype=torch.float32)
         st.cos, st.sin = self.rope_tables(torch.arange(cache.capacity))
         st.ws = torch.empty(self.ops.decode_workspace_elems(1, H, hd, cache.capacity), dtype=torch.float32, device=dev)
@@ -842,6 +903,15 @@ class LeopardEngine:
             self.comm.all_reduce(st.part)
             st.x[0].add_(st.part)
         ops.embed_merge(st.tok, st.src0, W.embed, None, st.x)
+        if self.llm_packed:
+            # one copy of the weights, in the operand order of lmi_gemm_skinny: the batch-1 step is the batched step with one row (measured:
+            # 3.10 ms per step at B = 2 against 3.12 ms for the GEMV step), its KV rows go to this cache, the head keeps the fp32 row
+            self._skinny_layers(st, cache.k, cache.v, cache.capacity,
+                                lambda i: ops.attention_decode(st.qkv[:, :qw], cache.k[i], cache.v[i], st.att, st.cu_q, st.cu_k, 1, cache.capacity, H, KV,
+                                                               hd, hd ** -0.5, st.ws, window=tc.sliding_window or 0))
+            ops.lm_head_last(W.lm_head, st.x, None, W.final_norm, tc.rms_norm_eps, st.logits.view(1, -1))
+            ops.decode_advance(st.logits.view(1, -1), tc.vocab_size, st.tok, st.pos, k_len=st.cu_k[1:], suppress=self.suppress_tokens)
+            return
         fuse = tc.hidden_size == 4096                 # lmi_gemv_rmsnorm: the norm rides in the projection's launch
         for i, L in enumerate(W.llm_layers):
             if fuse and hd == 128 and L.qkv_w_rope is not None:   # norm + projection + RoPE + KV append: one launch
@@ -1037,7 +1107,8 @@ class LeopardEngine:
 
     def _skinny_weights(self):
         """The decode projections + the head in lmi_gemm_skinny's packed (MFMA operand) order — a second copy of the 16-bit LLM weights
-        (15 GB for Llama-3.1-8B; the part has 288 GB), built on the first batched decode and shared by every batch size."""
+        (15 GB for Llama-3.1-8B), built on the first batched decode and shared by every batch size.  Only engines whose weights stay in
+        the nn.Linear layout (tensor parallel, pack_llm_weights=False) need it: the default layout IS this order (pack_llm_weights)."""
         pk = getattr(self, "_skinny_pack", None)
         if pk is None:
             from .weights import skinny_pack
@@ -1045,17 +1116,16 @@ class LeopardEngine:
             # q|k|v: the rope-permuted rows when they exist (RoPE + KV append then ride in the projection's epilogue: lmi_rope_qkv_skinny)
             pk = self._skinny_pack = {"layers": [(skinny_pack(L.qkv_w_rope if L.qkv_w_rope is not None else L.qkv_w), skinny_pack(L.o_w),
                                                   skinny_pack(L.gu_w), skinny_pack(L.down_w)) for L in W.llm_layers],
-                                      "head": skinny_pack(W.lm_head)}
+                                      "head": self._skinny_head()}
         return pk
 
-    def _batch_decode_body(self, st):
-        """One decode step for the B sequences of ``st`` (everything here is host-value free: graph-capturable)."""
+    def _skinny_layers(self, st, k_list, v_list, capacity: int, attend):
+        """The layer stack of a decode step on the M <= 16 kernels (lmi_gemm_skinny*): st.x (fp32 rows) in, st.x out.  K / V rows are appended
+        to k_list[i] / v_list[i] at row m * capacity + pos[m]; ``attend(i)`` runs layer i's attention from st.qkv into st.att."""
         ops, W, tc = self.ops, self.W, self.cfg.text_config
         (H, KV), hd = self._llm_heads(), tc.head_dim
-        qw, eps = H * hd, tc.rms_norm_eps
-        ops.embed_merge(st.tok, st.src, W.embed, None, st.x)
-        pk = self._skinny_weights() if self.skinny_packed else None
-        packed = pk is not None
+        eps = tc.rms_norm_eps
+        pk = None if self.llm_packed or not self.skinny_packed else self._skinny_weights()
         D, n_layers = tc.hidden_size, len(W.llm_layers)
         # folded RMSNorms (as the prefill's fused schedule): every residual projection (o_proj, down_proj) also emits T(x * gamma_next) and
         # per-row partial sums of squares, the projection that consumes them scales its accumulator rows by rstd — only the first
@@ -1064,16 +1134,16 @@ class LeopardEngine:
         for i, L in enumerate(W.llm_layers):
             rope_fused = L.qkv_w_rope is not None and hd == 128
             qkv_w, o_w, gu_w, down_w = pk["layers"][i] if pk else (L.qkv_w_rope if rope_fused else L.qkv_w, L.o_w, L.gu_w, L.down_w)
+            packed = None if pk is None else True            # None: as the weight is marked (weights.is_packed)
             if not fold or i == 0:
                 ops.rmsnorm(st.x, L.in_norm, st.h, eps)
             if rope_fused:
-                ops.rope_qkv_skinny(qkv_w, st.h, st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos, packed,
+                ops.rope_qkv_skinny(qkv_w, st.h, st.qkv, H, KV, hd, st.cos, st.sin, k_list[i], v_list[i], capacity, st.pos, packed,
                                     rowsq_in=st.sq_b if fold and i > 0 else None, norm_eps=eps)
             else:
                 ops.gemm_skinny(qkv_w, st.h, st.qkv, 0, packed)
-                ops.rope_qk_rows(st.qkv, H, KV, hd, st.cos, st.sin, st.k[i], st.v[i], st.capacity, st.pos)
-            ops.attention_decode_pool(st.qkv[:, :qw], st.k[i], st.v[i], st.att, st.cu_q, st.k_begin, st.k_len, st.capacity, H, KV, hd,
-                                      hd ** -0.5, st.ws, window=tc.sliding_window or 0)
+                ops.rope_qk_rows(st.qkv, H, KV, hd, st.cos, st.sin, k_list[i], v_list[i], capacity, st.pos)
+            attend(i)
             if fold:
                 ops.gemm_skinny(o_w, st.att, st.x, 1, packed, norm_out=st.h, norm_gamma=L.post_norm, rowsq_out=st.sq_a)
                 ops.gemm_skinny(gu_w, st.h, st.gu, 2, packed, rowsq_in=st.sq_a, norm_dim=D, norm_eps=eps)
@@ -1086,9 +1156,30 @@ class LeopardEngine:
                 ops.rmsnorm(st.x, L.post_norm, st.h, eps)
                 ops.gemm_skinny(gu_w, st.h, st.gu, 2, packed)
                 ops.gemm_skinny(down_w, st.gu, st.x, 1, packed)
-        # head: one pass over lm_head for all B rows (lmi_lm_head_last streams the 1 GB head once PER row)
+
+    def _skinny_head(self):
+        """lm_head in the packed order for the batched step (shared with _skinny_weights' second copy when there is one)."""
+        h = getattr(self, "_head_pack", None)
+        if h is None:
+            from .weights import as_packed
+            pk = getattr(self, "_skinny_pack", None)
+            h = self._head_pack = as_packed(pk["head"]) if pk else as_packed(self.W.lm_head)
+        return h
+
+    def _batch_decode_body(self, st):
+        """One decode step for the B sequences of ``st`` (everything here is host-value free: graph-capturable)."""
+        ops, W, tc = self.ops, self.W, self.cfg.text_config
+        (H, KV), hd = self._llm_heads(), tc.head_dim
+        qw, eps = H * hd, tc.rms_norm_eps
+        ops.embed_merge(st.tok, st.src, W.embed, None, st.x)
+        self._skinny_layers(st, st.k, st.v, st.capacity,
+                            lambda i: ops.attention_decode_pool(st.qkv[:, :qw], st.k[i], st.v[i], st.att, st.cu_q, st.k_begin, st.k_len, st.capacity,
+                                                                H, KV, hd, hd ** -0.5, st.ws, window=tc.sliding_window or 0))
+        # head: one pass over lm_head for all B rows (lmi_lm_head_last streams the 1 GB head once PER row), from a packed copy of the head
+        # (1 GB, built on the first batched step: the prefill's and the batch-1 step's head kernels read the nn.Linear layout; B = 8 step
+        # 3.29 ms against 3.37 ms from the row-major head in the coalescing lane order)
         ops.rmsnorm(st.x, W.final_norm, st.h, eps)
-        ops.gemm_skinny(pk["head"] if pk else W.lm_head, st.h, st.logits, 3, pk is not None)
+        ops.gemm_skinny(self._skinny_head() if self.skinny_packed else W.lm_head, st.h, st.logits, 3)
         # greedy choice, history ring, stop rule (eos ids / token budget) and position advance of all B slots: ONE launch, device memory only —
         # a slot that stopped freezes (live = 0) and what it produces afterwards is ignored (lmi_decode_advance)
         ops.decode_advance(st.logits, tc.vocab_size, st.tok, st.pos, k_len=st.k_len, live=st.live, budget=st.budget, eos=st.eos, hist=st.hist,
@@ -1140,13 +1231,13 @@ class LeopardEngine:
         return outs
 
     def release_batch_state(self) -> None:
-        """Free the pooled KV caches / captured graphs of the batched decode and the second copy of the LLM weights in the skinny-M
-        operand order (15 GB for Llama-3.1-8B; rebuilt on the next batched call).  Why there are two layouts: the prefill GEMM stages
-        weight ROWS by LDS-DMA (128 contiguous bytes per 8 lanes), the M <= 16 kernel feeds fragments from memory straight into
-        v_mfma_f32_16x16x32 (adjacent lanes = adjacent rows) — from the row-major copy its loads are 64 scattered 16-byte pieces (B = 8
-        step 4.75 ms vs 4.06 ms, profiles/README.md round 3)."""
+        """Free the pooled KV caches / captured graphs of the batched decode and — for engines that keep the nn.Linear layout (tensor
+        parallel, pack_llm_weights=False) — the second copy of the LLM weights in the skinny-M operand order (15 GB for Llama-3.1-8B;
+        rebuilt on the next batched call).  The default layout has no second copy: prefill, batch-1 and batched decode read the same
+        packed tensors (pack_llm_weights)."""
         self._batch_states = {}
         self._skinny_pack = None
+        self._head_pack = None
         if self.device.type == "cuda":
             torch.cuda.empty_cache()
 

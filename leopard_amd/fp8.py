@@ -89,11 +89,12 @@ def calibrate(engine, samples, headroom: float = 2.0) -> Fp8Plan:
         for s in VIT_SITES:
             lay.act[s] = pow2_exp(amax.get(("vit", li, s), 0.0), headroom)
         plan.vit.append(lay)
+    from .weights import as_row_major                       # the 16-bit weights may be stored in the packed order (engine.pack_llm_weights)
     for li, L in enumerate(W.llm_layers):
-        lay = Fp8Layer(lin={"qkv": quantize_linear(ops, L.qkv_w), "o": quantize_linear(ops, L.o_w),
-                            "gu": quantize_linear(ops, L.gu_w), "down": quantize_linear(ops, L.down_w)})
+        lay = Fp8Layer(lin={"qkv": quantize_linear(ops, engine._qkv_natural(L)), "o": quantize_linear(ops, as_row_major(L.o_w)),
+                            "gu": quantize_linear(ops, as_row_major(L.gu_w)), "down": quantize_linear(ops, as_row_major(L.down_w))})
         if getattr(L, "qkv_w_rope", None) is not None:      # the same rows in rope_permute_rows order: q|k|v + RoPE + KV append in ONE fp8 launch
-            lay.lin["qkv_rope"] = quantize_linear(ops, L.qkv_w_rope)
+            lay.lin["qkv_rope"] = quantize_linear(ops, as_row_major(L.qkv_w_rope))
             assert lay.lin["qkv_rope"].e == lay.lin["qkv"].e
         for s in LLM_SITES:
             lay.act[s] = pow2_exp(amax.get(("llm", li, s), 0.0), headroom)

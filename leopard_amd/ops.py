@@ -118,6 +118,12 @@ class Ops:
                                          _DT[out.dtype], self._stream(out)))
         return out
 
+    @staticmethod
+    def _ldw(w):
+        """Leading dimension of a weight for the GEMM entries: LMI_LDW_PACKED(K) = -K when it is stored in the packed order
+        (weights.mark_packed), its row stride otherwise."""
+        return -w.shape[1] if getattr(w, "_lmi_packed", False) else w.stride(0)
+
     def gemm(self, a, w, out, bias=None, addmat=None, row_map=None, epilogue=EPI_STORE, act=ACT_NONE,
              a_mode=A_PLAIN, ps_grid=0, M=None, add_rows=None):
         """out = epilogue(a @ w.T).  a: T [M,K] (or the ViT output for pixel-shuffle mode), w: T [N,K]."""
@@ -126,7 +132,7 @@ class Ops:
             M = a.shape[0]
         add_period = 0 if addmat is None else addmat.shape[0]
         self._check(self.lib.lmi_gemm(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(addmat), _ptr(add_rows), _ptr(row_map), M, N, K,
-                                      a.stride(0), w.stride(0), out.stride(0), add_period, epilogue, act, a_mode,
+                                      a.stride(0), self._ldw(w), out.stride(0), add_period, epilogue, act, a_mode,
                                       ps_grid, _DT[w.dtype], self._stream(out)))
         return out
 
@@ -168,12 +174,14 @@ class Ops:
                                               _ptr(pos_rows), _DT[qkv.dtype], self._stream(qkv)))
         return qkv
 
-    def gemm_skinny(self, w, x, out, epilogue=0, packed=False, rowsq_in=None, norm_dim=0, norm_eps=0.0, norm_out=None, norm_gamma=None, rowsq_out=None):
+    def gemm_skinny(self, w, x, out, epilogue=0, packed=None, rowsq_in=None, norm_dim=0, norm_eps=0.0, norm_out=None, norm_gamma=None, rowsq_out=None):
         """out[M <= 16, .] = epilogue(x @ w.T): the projections of a batched decode step.  epilogue: 0 store T, 1 fp32 +=,
         2 SwiGLU (w rows interleaved [32 gate | 32 up], out [M, N/2]), 3 store fp32.  packed: w is weights.skinny_pack(w) (same shape).
         rowsq_in / norm_out + norm_gamma + rowsq_out: the folded RMSNorm of lmi_gemm_skinny_ex (consumer / producer side)."""
         N, K = w.shape
         M = x.shape[0]
+        if packed is None:
+            packed = getattr(w, "_lmi_packed", False)
         if rowsq_in is None and norm_out is None:
             self._check(self.lib.lmi_gemm_skinny(_ptr(w), _ptr(x), _ptr(out), M, N, K, w.stride(0), x.stride(0), out.stride(0), int(epilogue),
                                                  int(bool(packed)), _DT[w.dtype], self._stream(out)))
@@ -184,11 +192,13 @@ class Ops:
                                                 _ptr(rowsq_out), _DT[w.dtype], self._stream(out)))
         return out
 
-    def rope_qkv_skinny(self, w_rope, x, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, cache_stride, pos_rows, packed=False,
+    def rope_qkv_skinny(self, w_rope, x, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, cache_stride, pos_rows, packed=None,
                         rowsq_in=None, norm_eps=0.0):
         """lmi_rope_qkv_skinny: batched-decode q|k|v projection with RoPE + KV append in the epilogue (w_rope in rope_permute_rows order);
         rowsq_in: consumer side of the folded RMSNorm."""
         M, K = x.shape[0], w_rope.shape[1]
+        if packed is None:
+            packed = getattr(w_rope, "_lmi_packed", False)
         self._check(self.lib.lmi_rope_qkv_skinny(_ptr(w_rope), _ptr(x), _ptr(qkv), M, n_q_heads, n_kv_heads, head_dim, K, w_rope.stride(0), x.stride(0),
                                                  qkv.stride(0), int(bool(packed)), _ptr(rowsq_in), 0 if rowsq_in is None else rowsq_in.shape[1],
                                                  float(norm_eps), _ptr(cos_all), _ptr(sin_all), _ptr(k_cache), _ptr(v_cache),
@@ -250,6 +260,7 @@ class Ops:
 
     def gemv(self, w, x, out, bias=None, epilogue=0):
         N, K = w.shape
+        assert not getattr(w, "_lmi_packed", False), "gemv: the GEMV kernels read the row-major layout"
         self._check(self.lib.lmi_gemv(_ptr(w), _ptr(x), _ptr(bias), _ptr(out), N, K, w.stride(0), epilogue,
                                       _DT[w.dtype], self._stream(out)))
         return out
@@ -257,12 +268,14 @@ class Ops:
     def gemv_rmsnorm(self, w, x_f32, norm_weight, eps, out, epilogue=1):
         """out = epilogue(w @ rmsnorm(x_f32)): the decode step's norm + projection in one launch (K = 4096)."""
         N, K = w.shape
+        assert not getattr(w, "_lmi_packed", False), "gemv_rmsnorm: the GEMV kernels read the row-major layout"
         self._check(self.lib.lmi_gemv_rmsnorm(_ptr(w), _ptr(x_f32), _ptr(norm_weight), float(eps), _ptr(out), N, K, w.stride(0),
                                               epilogue, _DT[w.dtype], self._stream(out)))
         return out
 
     def gemv_rmsnorm_rope(self, w_rope, x_f32, norm_weight, eps, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, pos_dev):
         """lmi_gemv_rmsnorm_rope: the decode step's q|k|v projection with the RMSNorm on its input and RoPE + KV append on its output."""
+        assert not getattr(w_rope, "_lmi_packed", False), "gemv_rmsnorm_rope: the GEMV kernels read the row-major layout"
         self._check(self.lib.lmi_gemv_rmsnorm_rope(_ptr(w_rope), _ptr(x_f32), _ptr(norm_weight), float(eps), _ptr(qkv), n_q_heads, n_kv_heads,
                                                    head_dim, w_rope.shape[1], w_rope.stride(0), _ptr(cos_all), _ptr(sin_all), _ptr(k_cache),
                                                    _ptr(v_cache), k_cache.stride(0), _ptr(pos_dev), _DT[w_rope.dtype], self._stream(qkv)))
@@ -274,6 +287,7 @@ class Ops:
         N, K = w.shape
         n = out.shape[0]
         assert out.dtype == torch.float32 and x_f32.dtype == torch.float32 and (rows is None or rows.dtype == torch.int64)
+        assert not getattr(w, "_lmi_packed", False), "lm_head_last: the GEMV kernels read the row-major layout"
         self._check(self.lib.lmi_lm_head_last(_ptr(w), _ptr(x_f32), _ptr(rows), _ptr(norm_weight), float(eps), _ptr(out), n, N, K,
                                               w.stride(0), x_f32.stride(0), out.stride(0), _DT[w.dtype], self._stream(out)))
         return out
@@ -289,7 +303,7 @@ class Ops:
             assert rowsq_in.dtype == torch.float32 and rowsq_in.is_contiguous() and rowsq_in.shape[0] >= M
         if norm_out is not None:
             assert rowsq_out is not None and rowsq_out.dtype == torch.float32 and rowsq_out.is_contiguous() and rowsq_out.shape == (M, N // 64)
-        self._check(self.lib.lmi_gemm_ex(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), M, N, K, a.stride(0), w.stride(0), out.stride(0), epilogue, act,
+        self._check(self.lib.lmi_gemm_ex(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), M, N, K, a.stride(0), self._ldw(w), out.stride(0), epilogue, act,
                                          _ptr(rowsq_in), parts, int(norm_dim), float(norm_eps), _ptr(norm_out), _ptr(norm_gamma), _ptr(rowsq_out),
                                          0 if norm_out is None else norm_out.stride(0), _DT[w.dtype], self._stream(out)))
         return out
@@ -303,7 +317,7 @@ class Ops:
         assert qkv.shape[1] == (n_q_heads + 2 * n_kv_heads) * head_dim == w_qkv_rope.shape[0]
         self._check(self.lib.lmi_rmsnorm_rope(_ptr(a), _ptr(w_qkv_rope), _ptr(qkv), _ptr(rowsq_in), parts, float(eps), _ptr(cos), _ptr(sin),
                                               _ptr(k_cache), _ptr(v_cache), ldc, int(cache_pos0), M, n_q_heads, n_kv_heads, head_dim, K,
-                                              a.stride(0), w_qkv_rope.stride(0), qkv.stride(0), _DT[w_qkv_rope.dtype], self._stream(qkv)))
+                                              a.stride(0), self._ldw(w_qkv_rope), qkv.stride(0), _DT[w_qkv_rope.dtype], self._stream(qkv)))
         return qkv
 
     def add_rmsnorm(self, x, delta, w, out, eps):

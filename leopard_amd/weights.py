@@ -105,6 +105,39 @@ def skinny_pack(w: torch.Tensor) -> torch.Tensor:
     return v.permute(0, 2, 3, 4, 1, 5).contiguous().view(N, K)          # (r, s, c, g, i, j)
 
 
+def skinny_unpack(w: torch.Tensor) -> torch.Tensor:
+    """Inverse of skinny_pack: the row-major [N, K] matrix again."""
+    N, K = w.shape
+    v = w.contiguous().view(N // 16, K // 128, 4, 4, 16, 8)            # (r, s, c, g, i, j)
+    return v.permute(0, 4, 1, 2, 3, 5).contiguous().view(N, K)          # (r, i, s, c, g, j)
+
+
+# One copy of the LLM weights for every kernel that reads them: the packed order is a permutation of the 16-byte pieces of the row-major
+# matrix that keeps 16-row groups and 64-k tiles together, so the prefill GEMM's LDS-DMA stages the SAME LDS image from it (ldw =
+# LMI_LDW_PACKED(K), csrc/gemm.h GemmStager) and the decode kernels (lmi_gemm_skinny, packed = 1) stream it in coalesced 1-KiB requests.
+# A packed tensor keeps its [N, K] shape and carries a mark that leopard_amd.ops reads when it builds the call.
+def mark_packed(w: torch.Tensor) -> torch.Tensor:
+    w._lmi_packed = True
+    return w
+
+
+def is_packed(w) -> bool:
+    return bool(getattr(w, "_lmi_packed", False))
+
+
+def packable(w: torch.Tensor) -> bool:
+    return w.dim() == 2 and w.shape[0] % 16 == 0 and w.shape[1] % 128 == 0 and w.element_size() == 2
+
+
+def as_packed(w: torch.Tensor) -> torch.Tensor:
+    return w if is_packed(w) else mark_packed(skinny_pack(w))
+
+
+def as_row_major(w: torch.Tensor) -> torch.Tensor:
+    """The nn.Linear layout of a weight whichever way it is stored (a fresh tensor when it was packed)."""
+    return skinny_unpack(w) if is_packed(w) else w
+
+
 @dataclass
 class VitLayerW:
     ln1_w: torch.Tensor; ln1_b: torch.Tensor

@@ -222,3 +222,50 @@ def test_split_operand_mode_removes_the_hand_over_roundings(setup):
     assert cache.length == res.seq_len and bool(cache.k[1][:cache.length].abs().sum() > 0)          # K / V still appended by the q|k|v epilogue
     eng.split_operands = False
     assert torch.equal(eng.prefill(ids, u8, all_logits=True).logits_all, base)
+
+
+def test_one_copy_of_the_llm_weights_serves_prefill_and_decode(setup):
+    """LeopardEngine.pack_llm_weights (default): the layer linears live ONCE, in the operand order of the decode kernels; the prefill
+    GEMM reads that order (ldw = LMI_LDW_PACKED(K)) bit-identically, batch-1 and batched decode stream the same tensors (no second
+    copy is ever built), the natural-order q|k|v duplicate is gone and comes back from the rope-ordered rows on request."""
+    from leopard_amd.weights import is_packed
+    ops = setup[0]
+    cfg = LeopardConfig(                                             # hidden 256: the fused schedule (folded norms, RoPE in the epilogue) applies
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16, image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                               vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+    mk = lambda: EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    W0, W1 = mk(), mk()
+    plain = LeopardEngine(cfg, W0, ops=ops, device="cpu", pack_llm_weights=False)
+    eng = LeopardEngine(cfg, W1, ops=ops, device="cpu")
+    assert eng.llm_packed and not plain.llm_packed
+    L0, L1 = W0.llm_layers[1], W1.llm_layers[1]
+    assert L1.qkv_w is None and all(is_packed(getattr(L1, n)) for n in ("qkv_w_rope", "o_w", "gu_w", "down_w")) and not is_packed(W1.lm_head)
+    assert torch.equal(eng._qkv_natural(L1), L0.qkv_w)
+    layer_bytes = lambda W: sum(t.numel() * t.element_size() for L in W.llm_layers for t in (L.qkv_w, L.qkv_w_rope, L.o_w, L.gu_w, L.down_w) if t is not None)
+    assert layer_bytes(W1) < layer_bytes(W0)
+    rng = np.random.default_rng(26)
+    u8 = torch.from_numpy(rng.integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
+    ids = torch.tensor([[5, 250, 9, 250, 17, 33]])
+    a, b = plain.prefill(ids, u8, all_logits=True), eng.prefill(ids, u8, all_logits=True)
+    assert torch.equal(a.logits_all, b.logits_all)                   # prefill: the same bits from either layout
+    plain.fuse_norm_rope = eng.fuse_norm_rope = False                # un-fused schedule: q|k|v from the rope-ordered rows (RoPE on the fp32 sums)
+    a2, b2 = plain.prefill(ids, u8), eng.prefill(ids, u8)
+    assert (a2.logits_last - b2.logits_last).abs().max() <= 2e-3 * float(a2.logits_last.abs().max())
+    plain.fuse_norm_rope = eng.fuse_norm_rope = True
+    # decode: batch 1 runs on the batched-decode kernels with one row — tokens equal the GEMV step's and generate_batch's
+    samples = [(ids, u8), (torch.tensor([[7, 8, 9]]), None)]
+    for s_ids, s_tiles in samples:
+        assert torch.equal(plain.generate(s_ids, s_tiles, max_new_tokens=5, eos_token_id=()), eng.generate(s_ids, s_tiles, max_new_tokens=5, eos_token_id=()))
+    outs = eng.generate_batch(samples, max_new_tokens=5, eos_token_id=())
+    assert all(torch.equal(o, eng.generate(i, t, max_new_tokens=5, eos_token_id=())) for o, (i, t) in zip(outs, samples))
+    assert getattr(eng, "_skinny_pack", None) is None                # nothing was copied for the batched step
+    # precision modes read row-major views of the same tensors
+    eng.split_operands = plain.split_operands = True
+    assert torch.equal(plain.prefill(ids, u8).logits_last, eng.prefill(ids, u8).logits_last)
+    eng.split_operands = plain.split_operands = False
+    # and back
+    eng.unpack_llm_weights()
+    assert not eng.llm_packed and all(torch.equal(getattr(L1, n), getattr(L0, n)) for n in ("qkv_w", "qkv_w_rope", "o_w", "gu_w", "down_w"))
+    assert torch.equal(eng.prefill(ids, u8, all_logits=True).logits_all, a.logits_all)

@@ -336,6 +336,35 @@ def test_gemm_lds_swizzle_is_conflict_free():
                 assert len(slots) == 16
 
 
+def test_gemm_packed_w_image_is_conflict_free_and_its_dma_is_coalesced():
+    """gemm.h gemm_lds_off_wp (W staged from the packed weight order): (a) the ds_read_b128 lane groups hit 16 distinct slots of the bank
+    row; (b) every lane quad of an LDS-DMA instruction fetches 64 contiguous bytes and every octet one aligned 128-byte line of the
+    packed matrix — the traffic pattern of the row-major image; (c) slot <-> (row, chunk) is a bijection of the 1-KiB piece."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    off_wp = lambda r, lc: (r >> 3) * 1024 + ((((lc ^ ((r >> 3) & 1)) << 3) + (r & 7)) << 4)
+    for ks in range(4):
+        for base in (0, 32, 64, 96):
+            for g in groups:
+                assert len({(off_wp(base + (lane & 31), 2 * ks + (lane >> 5)) % 256) // 16 for lane in g}) == 16
+    K = 512
+    for piece in range(4):                                               # pieces of a pass: rows 8 piece .. + 7
+        src, dst = [], set()
+        for l in range(64):
+            rp = piece * 8 + (l & 7)
+            c = (l >> 3) ^ ((rp >> 3) & 1)
+            n = 48 + rp                                                  # some tile origin (multiple of 16 rows)
+            src.append((n >> 4) * 32 * K + (c >> 2) * 1024 + ((c & 3) * 16 + (n & 15)) * 16)
+            assert off_wp(rp, c) == piece * 1024 + l * 16                # LDS-DMA is lane-linear: lane l lands on slot l of the piece
+            dst.add((rp, c))
+        assert len(dst) == 64
+        for q in range(0, 64, 4):
+            assert [src[q + i] - src[q] for i in range(4)] == [0, 16, 32, 48] and src[q] % 64 == 0
+        for o in range(0, 64, 8):
+            assert src[o] % 128 == 0 and src[o + 7] - src[o] == 112
+
+
 def test_attention_d72_v_image_is_conflict_free():
     """attention.h att_vpos72: ds_read_b64_tr_b16 serves the two 32-lane halves of a wave in one LDS cycle each when the 32
     eight-byte pieces cover the 256-byte bank row exactly.  A half reads, for one 32-wide d-block, the four 16-byte chunks of
@@ -997,3 +1026,67 @@ def test_decode_advance_argmax_stop_rule_and_history(ops):
     t1, p1, k1 = torch.zeros(1, dtype=torch.int64), torch.tensor([7], dtype=torch.int32), torch.tensor([8], dtype=torch.int32)
     ops.decode_advance(logits[4:5], V, t1, p1, k_len=k1)
     assert int(t1) == int(logits[4, :V].argmax()) and int(p1) == 8 and int(k1) == 9
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 6, 10])
+def test_gemm_reads_packed_weights_bit_identically(ops, cfg):
+    """ldw = LMI_LDW_PACKED(K): the prefill GEMM stages the same LDS image from the operand order the decode kernels stream
+    (weights.skinny_pack), so every output bit equals the row-major call's — plain, SwiGLU, folded-norm producer and q|k|v + RoPE epilogues,
+    ragged M, an N that is not a multiple of the tile width; and the skinny kernel reads the very same tensor."""
+    from leopard_amd.weights import as_packed, as_row_major, interleave_gate_up, is_packed, rope_permute_rows
+    dtype = torch.float16
+    if cfg >= 0:
+        ops.set_option("gemm.config", cfg)
+    try:
+        M, N, K = 300, 384, 512
+        a, w = rnd((M, K), dtype, 170 + cfg), rnd((N, K), dtype, 180 + cfg, 0.1)
+        wp = as_packed(w)
+        assert is_packed(wp) and not is_packed(w) and torch.equal(as_row_major(wp), w) and not torch.equal(wp, w)
+        bias = rnd((N,), torch.float32, 90)
+        o1, o2 = torch.full((M, N), float("nan"), dtype=dtype), torch.full((M, N), float("nan"), dtype=dtype)
+        ops.gemm(a, w, o1, bias=bias)
+        ops.gemm(a, wp, o2, bias=bias)
+        assert torch.equal(o1, o2)
+        # SwiGLU + consumer side of the folded norm
+        F = 192
+        wi = interleave_gate_up(rnd((F, K), dtype, 11, 0.2), rnd((F, K), dtype, 12, 0.2))
+        sq = rnd((M, K // 64), torch.float32, 5).abs() + 0.5
+        g1, g2 = torch.full((M, F), float("nan"), dtype=dtype), torch.full((M, F), float("nan"), dtype=dtype)
+        ops.gemm_ex(a, wi, g1, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq, norm_dim=K, norm_eps=1e-5)
+        ops.gemm_ex(a, as_packed(wi), g2, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq, norm_dim=K, norm_eps=1e-5)
+        assert torch.equal(g1, g2)
+        # residual + producer side
+        x1 = rnd((M, N), torch.float32, 7)
+        x2 = x1.clone()
+        gam = rnd((N,), torch.float32, 8)
+        h1, h2 = torch.zeros(M, N, dtype=dtype), torch.zeros(M, N, dtype=dtype)
+        s1, s2 = torch.zeros(M, N // 64), torch.zeros(M, N // 64)
+        ops.gemm_ex(a, w, x1, epilogue=_lib.EPI_RESIDUAL, norm_out=h1, norm_gamma=gam, rowsq_out=s1)
+        ops.gemm_ex(a, wp, x2, epilogue=_lib.EPI_RESIDUAL, norm_out=h2, norm_gamma=gam, rowsq_out=s2)
+        assert torch.equal(x1, x2) and torch.equal(h1, h2) and torch.equal(s1, s2)
+        # q|k|v + RoPE + KV append (2 q heads, 1 kv head of 128)
+        H, KV, hd = 2, 1, 128
+        wq = rnd(((H + 2 * KV) * hd, K), dtype, 21, 0.1)
+        wr = torch.cat([rope_permute_rows(wq[:(H + KV) * hd]), wq[(H + KV) * hd:]], dim=0).contiguous()
+        ang = torch.rand(M, hd // 2, generator=torch.Generator().manual_seed(3)) * 6.28
+        cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+        outs = []
+        for wt in (wr, as_packed(wr)):
+            qkv = torch.full((M, (H + 2 * KV) * hd), float("nan"), dtype=dtype)
+            kc, vc = torch.zeros(M + 8, KV * hd, dtype=dtype), torch.zeros(M + 8, KV * hd, dtype=dtype)
+            ops.rmsnorm_rope(a, wt, qkv, None, 1e-5, cos, sin, kc, vc, 4, H, KV, hd)
+            outs.append((qkv, kc, vc))
+        assert all(torch.equal(p, q) for p, q in zip(*outs))
+        # the decode kernel streams the same tensor
+        xs = rnd((5, K), dtype, 31)
+        d1, d2 = torch.zeros(5, N, dtype=dtype), torch.zeros(5, N, dtype=dtype)
+        ops.gemm_skinny(w, xs, d1, 0)
+        ops.gemm_skinny(wp, xs, d2, 0)
+        assert torch.equal(d1, d2)
+    finally:
+        ops.set_option("gemm.config", -1)
+    # rejected: a K that is not a multiple of 128, a stride that is not -K
+    with pytest.raises(RuntimeError, match="packed W"):
+        bad = torch.zeros(128, 192, dtype=dtype)
+        bad._lmi_packed = True
+        ops.gemm(torch.zeros(8, 192, dtype=dtype), bad, torch.zeros(8, 128, dtype=dtype))

@@ -705,3 +705,54 @@ def test_gemm_mid_m_complete_tile_m312(ops, dtype):
     finally:
         ops.set_option("gemm.mid_m", 1)
     assert rel_err(outs[1], outs[0].float()) <= 2 * eps(dtype)
+
+
+# ---- one copy of the LLM weights: the prefill GEMM reading the packed (decode) order ------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 5, 7, 10])
+def test_gemm_packed_weights_bit_identical_at_llama_shapes(ops, dtype, cfg):
+    """ldw = LMI_LDW_PACKED(K) at the C3 / C2 Llama shapes on every tile geometry: residual + folded-norm producer (o_proj, down_proj),
+    SwiGLU + folded-norm consumer (gate/up), q|k|v + RoPE + KV append — every output bit equals the row-major call's (the W image is
+    staged chunk-major from the packed order: same fragments, same MFMA order), three launches each."""
+    from leopard_amd import _lib
+    from leopard_amd.weights import as_packed, interleave_gate_up, rope_permute_rows
+    ops.set_option("gemm.config", cfg)
+    try:
+        for M, N, K in ((7187, 4096, 4096), (1242, 4096, 14336)):
+            a, w, _, _ = operands(M, N, K, dtype, 0.02)
+            wp = as_packed(w)
+            g = torch.Generator(device=DEV).manual_seed(5)
+            x0 = torch.randn(M, N, generator=g, device=DEV)
+            gam = torch.randn(N, generator=g, device=DEV)
+            def resid(wt):
+                x, h, sq = x0.clone(), torch.zeros(M, N, dtype=dtype, device=DEV), torch.zeros(M, N // 64, device=DEV)
+                ops.gemm_ex(a, wt, x, epilogue=_lib.EPI_RESIDUAL, norm_out=h, norm_gamma=gam, rowsq_out=sq)
+                return torch.cat([x, h.float(), sq], 1)
+            assert torch.equal(run3(lambda: resid(w)), run3(lambda: resid(wp))), f"residual {M}x{N}x{K} cfg {cfg}"
+            del wp
+        M, F, K = 7187, 14336, 4096
+        g = torch.Generator(device=DEV).manual_seed(6)
+        a = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+        wi = interleave_gate_up((torch.randn(F, K, generator=g, device=DEV) * 0.02).to(dtype), (torch.randn(F, K, generator=g, device=DEV) * 0.02).to(dtype))
+        sq = (torch.rand(M, K // 64, generator=g, device=DEV) + 0.5) * 64
+        wip = as_packed(wi)
+        def gate_up(wt):
+            out = torch.full((M, F), float("nan"), dtype=dtype, device=DEV)
+            return ops.gemm_ex(a, wt, out, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq, norm_dim=K, norm_eps=1e-5)
+        assert torch.equal(run3(lambda: gate_up(wi)), run3(lambda: gate_up(wip))), f"gate/up cfg {cfg}"
+        del wi, wip
+        nq, nkv, D = 32, 8, 128
+        N = (nq + 2 * nkv) * D
+        w = (torch.randn(N, K, generator=g, device=DEV) * 0.02).to(dtype)
+        wr = torch.cat([rope_permute_rows(w[:(nq + nkv) * D]), w[(nq + nkv) * D:]], 0).contiguous()
+        wrp = as_packed(wr)
+        ang = torch.rand(M, D // 2, generator=g, device=DEV) * 6.28
+        cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+        def qkv(wt):
+            out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+            kc, vc = torch.zeros(M, nkv * D, dtype=dtype, device=DEV), torch.zeros(M, nkv * D, dtype=dtype, device=DEV)
+            ops.rmsnorm_rope(a, wt, out, sq, 1e-5, cos, sin, kc, vc, 0, nq, nkv, D)
+            return torch.cat([out, kc, vc], 1)
+        assert torch.equal(run3(lambda: qkv(wr)), run3(lambda: qkv(wrp))), f"q|k|v + RoPE cfg {cfg}"
+    finally:
+        ops.set_option("gemm.config", -1)

@@ -68,7 +68,9 @@ def main():
 
     def apply(kv):
         for k in touched:
-            if k.startswith("eng."):
+            if k == "eng.llm_packed":                   # one copy of the LLM weights (packed order) vs the nn.Linear layout
+                eng.pack_llm_weights() if kv.get(k, 1) else eng.unpack_llm_weights()
+            elif k.startswith("eng."):
                 setattr(eng, k[4:], bool(kv.get(k, 1)))
             else:
                 ops.set_option(k, kv.get(k, DEFAULTS[k]))
