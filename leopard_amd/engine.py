@@ -187,6 +187,7 @@ class LeopardEngine:
                 setattr(L, name, as_packed(getattr(L, name)))
             L.qkv_w = None
         self._skinny_pack = None
+        self._batch_states = {}                               # steps captured over a second copy of the weights
         return True
 
     def unpack_llm_weights(self) -> None:
@@ -198,7 +199,8 @@ class LeopardEngine:
             L.qkv_w = self._qkv_natural(L)
             for name in ("qkv_w_rope", "o_w", "gu_w", "down_w"):
                 setattr(L, name, as_row_major(getattr(L, name)))
-        self._batch_states = {}                               # captured steps hold the packed tensors' launches
+        self._batch_states = {}                               # captured steps hold the packed tensors' launches (batch-1 states re-capture: _decode_run)
+        self._head_pack = None
 
     def _qkv_natural(self, L) -> torch.Tensor:
         """q | k | v projection rows in their natural (checkpoint) order, row-major — kept beside the rope-ordered rows only while the
@@ -885,6 +887,7 @@ class LeopardEngine:
         st.cos, st.sin = self.rope_tables(torch.arange(cache.capacity))
         st.ws = torch.empty(self.ops.decode_workspace_elems(1, H, hd, cache.capacity), dtype=torch.float32, device=dev)
         st.graph = None
+        st.layout = self.llm_packed                                   # a captured step replays the launches of the weight layout it was captured on
         cache._decode_state = st
         return st
 
@@ -943,6 +946,8 @@ class LeopardEngine:
         # lmi_allreduce on the device), so the step stays ONE graph replay per token; over a torch.distributed group (gloo in the
         # CPU tests, host-staged) it cannot be captured and runs eagerly.
         from .dist import RcclComm
+        if getattr(st, "layout", self.llm_packed) != self.llm_packed:      # pack_llm_weights / unpack_llm_weights since the capture
+            st.graph, st.layout = None, self.llm_packed
         tp_capturable = self.tp_size == 1 or (isinstance(self.comm, RcclComm) and self.tp_decode_graph)
         if self.ops.emulated or self.device.type != "cuda" or not self.use_graphs or not tp_capturable or getattr(st, "graph_failed", False):
             self._decode_body(st, cache)
