@@ -1,5 +1,6 @@
 #include "hipemu.h"
 
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <ucontext.h>
@@ -7,10 +8,43 @@
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+// Fibre switch.  glibc's swapcontext saves / restores the signal mask with a system call on every switch, and a lock-step emulation of
+// 64-wide shuffles switches millions of times per test; on x86-64 the switch is therefore the six callee-saved registers + the stack
+// pointer, by hand (every fibre runs the same code with the same floating-point control state).  Other hosts keep ucontext.
+#if defined(__x86_64__)
+#define HIPEMU_FAST_SWITCH 1
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+#else
+#define HIPEMU_FAST_SWITCH 0
+#endif
+
 namespace hipemu {
 namespace {
 struct Fiber {
     ucontext_t ctx;
+    void* sp = nullptr;            // fast switch: the fibre's saved stack pointer
     char* stack = nullptr;
     bool done = false;
     bool waiting = false;
@@ -19,6 +53,7 @@ struct Fiber {
 constexpr size_t kStack = 256 * 1024;
 std::vector<Fiber> fibers;
 ucontext_t main_ctx;
+void* main_sp = nullptr;
 int cur = -1;
 const std::function<void()>* body_fn = nullptr;
 int bar_count = 0;
@@ -32,13 +67,33 @@ unsigned long ticks = 0;     // bumped on every barrier arrival / thread exit: t
 
 void yield() {
     Fiber& f = fibers[cur];
+#if HIPEMU_FAST_SWITCH
+    hipemu_switch(&f.sp, main_sp);
+#else
     swapcontext(&f.ctx, &main_ctx);
+#endif
 }
 void trampoline() {
     (*body_fn)();
     fibers[cur].done = true;
+#if HIPEMU_FAST_SWITCH
+    hipemu_switch(&fibers[cur].sp, main_sp);
+    abort();                                   // a finished fibre is never resumed
+#else
     swapcontext(&fibers[cur].ctx, &main_ctx);
+#endif
 }
+#if HIPEMU_FAST_SWITCH
+// first activation: hipemu_switch pops six zeroed registers and "returns" into trampoline with the stack aligned as after a call
+void prepare(Fiber& f) {
+    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+    void** x = (void**)(top - 8);              // rsp after the ret: 8 mod 16, holds a null return address for trampoline
+    x[0] = nullptr;
+    x[-1] = (void*)&trampoline;
+    for (int i = 2; i <= 7; ++i) x[-i] = nullptr;
+    f.sp = (void*)(x - 7);
+}
+#endif
 }  // namespace
 
 char* dyn_smem() { return smem.data(); }
@@ -84,11 +139,15 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
                     f.done = false;
                     f.waiting = false;
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+#if HIPEMU_FAST_SWITCH
+                    prepare(f);
+#else
                     getcontext(&f.ctx);
                     f.ctx.uc_stack.ss_sp = f.stack;
                     f.ctx.uc_stack.ss_size = kStack;
                     f.ctx.uc_link = &main_ctx;
                     makecontext(&f.ctx, (void (*)())trampoline, 0);
+#endif
                 }
                 int alive = n_threads;
                 long spins = 0;
@@ -99,7 +158,11 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
                         if (f.done) continue;
                         cur = t;
                         threadIdx = f.tid;
+#if HIPEMU_FAST_SWITCH
+                        hipemu_switch(&main_sp, f.sp);
+#else
                         swapcontext(&main_ctx, &f.ctx);
+#endif
                         if (f.done) { --alive; ++ticks; }
                     }
                     if (ticks == before) {
