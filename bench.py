@@ -288,12 +288,19 @@ def cpu_baseline_idefics2():
 FP8_DETAIL = ("fp8 e4m3fn operands (static power-of-two scales, fp32 accumulate) for the qkv / out / fc1 / fc2 linears of the 27 SigLIP "
               "layers and the qkv / o / gate-up / down linears of the 32 Llama layers; f16 attention, patch embed, projector; fp32 "
               "residual stream, norms and head")
+FP8_ATTN_DETAIL = ("; Llama attention arithmetic on the fp8 pipe as well: e4m3 q / k / v (static scales) and e4m3 P, QK^T and PV on "
+                   "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 softmax statistics and accumulators (--fp8-attention 0: the f16 attention)")
+
+
+def fp8_detail(args):
+    return FP8_DETAIL.replace("f16 attention, patch embed", "f16 SigLIP attention, patch embed") + FP8_ATTN_DETAIL if getattr(args, "fp8_attention", 0) else FP8_DETAIL
 
 
 def enable_fp8(eng, cfg, args):
     """Static activation scales from a 16-bit prefill of a DIFFERENT synthetic sample (other images, other prompt)."""
     u8, ids_np, _, _, _ = make_sample(cfg, 2, args.width, args.height, seed=977)
     eng.enable_fp8([(torch.from_numpy(ids_np).reshape(1, -1), torch.from_numpy(u8).to(eng.device))])
+    eng.fp8_attention = bool(getattr(args, "fp8_attention", 0))        # the calibration above recorded the q / k / v ranges either way
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
 
@@ -382,7 +389,7 @@ def bench_c5(args, dev, dtype, rank, world, D):
            "value": round(world * n_samples * n_img * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           **({"dtype_detail": FP8_DETAIL} if args.dtype == "fp8" else {}),
+           **({"dtype_detail": fp8_detail(args)} if args.dtype == "fp8" else {}),
            "config": {"workload": f"C5 shape: {n_samples} samples x {n_img} x (1344x896) -> {n_tiles} ViT inputs, "
                                   f"{sum(seq_lens)} tokens packed in one varlen pass; SigLIP-SO400M + Llama-3.1-8B prefill to "
                                   "last-token logits; synthetic seeded weights", "parallelism": f"sample-sharded x{world}"},
@@ -548,6 +555,8 @@ def main():
                          "figure is measured as well and reported under \"tp\" in the same JSON line")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (lmi_set_option), e.g. gemm.wide=7 for A/B runs")
     ap.add_argument("--no-fuse", action="store_true", help="A/B: separate RMSNorm / RoPE launches instead of the fused GEMM epilogues")
+    ap.add_argument("--fp8-attention", type=int, default=1, choices=[0, 1],
+                    help="--dtype fp8: 1 = the Llama layers' QK^T and PV on the fp8 matrix pipe too (lmi_attn_prep_fp8 + lmi_attn_fp8_fwd), 0 = the f16 attention")
     ap.add_argument("--graph-encode", action="store_true", help="capture the vision encode (ViT + projector) in a HIP graph per ViT-input count")
     ap.add_argument("--split-operands", action="store_true",
                     help="precision mode (NOT the headline): hi + lo split A operands for every layer linear, GEMMs at 2 K — full-depth logits within 1e-3 of fp32")
@@ -705,7 +714,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         **({"precision_mode": "split operands: every A operand of every ViT / LLM layer linear handed over as hi + lo 16-bit values, GEMMs at 2 K "
                               "(algorithmic FLOPs below are the model's, not the doubled MFMA work)"} if args.split_operands else {}),
-        **({"dtype_detail": FP8_DETAIL, "prefill_mfma_frac_note": "algorithmic FLOPs / time against the 2.5 PF 16-bit peak (mixed-precision step)"}
+        **({"dtype_detail": fp8_detail(args), "prefill_mfma_frac_note": "algorithmic FLOPs / time against the 2.5 PF 16-bit peak (mixed-precision step)"}
            if args.dtype == "fp8" else {}),
         "config": {"workload": f"{config_label(args)}: {args.images}x({args.width}x{args.height}) images -> {n_tiles} ViT inputs (364x364), "
                                f"{n_tiles * cfg.tokens_per_tile} visual tokens, S={S}; SigLIP-SO400M/14 (27L) + Llama-3.1-8B (32L) "

@@ -203,6 +203,22 @@ int lmi_rope_qkv_fp8(const void* A8, const void* Wqkv8, void* qkv, int scale_exp
                      void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int lda, int ldw, int ldo,
                      int out_dtype, void* stream);
 
+/* fp8 schedule: the attention ARITHMETIC of the Llama / Mistral layers on the fp8 matrix pipe too (BASELINE configs[4] "fp8 MFMA ViT+LLM
+ * prefill": QK^T and PV on v_mfma_scale_f32_32x32x64_f8f6f4; the layers' self-attention, megatron_patch/model/llava/transformer.py:678-885).
+ * Causal or full self-attention over packed sequences, head_dim 128, GQA.  Two launches per layer:
+ *   lmi_attn_prep_fp8  q | k | v rows (16-bit, rotated; [rows, ld]: q heads | k heads | v heads) -> q8 rows [rows, ldq8] = e4m3(q * q_scale) and,
+ *                      per kv head and 64-key tile, an 8-KiB K image and an 8-KiB transposed V image (e4m3(k * k_scale), e4m3(v * v_scale);
+ *                      k_img / v_img: n_kv_heads * n_tiles * 8192 bytes each).  tile_base (device, [n_seq + 1]): tile_base[s] = the first tile of
+ *                      sequence s, tile_base[s + 1] - tile_base[s] = ceil(len_s / 64), tile_base[n_seq] = n_tiles.
+ *   lmi_attn_fp8_fwd   softmax(q k^T * softmax_scale) v from those operands; P is rounded to e4m3, sums and O stay fp32.  Output either T rows
+ *                      (out, ldo) or, out_fp8 != null, e4m3(O * out_fp8_scale) — the o_proj operand of the fp8 schedule. */
+int lmi_attn_prep_fp8(const void* qkv, int ld, const int* cu_seqlens, const int* tile_base, int n_seq, int n_tiles, int n_q_heads, int n_kv_heads,
+                      int head_dim, float q_scale, float k_scale, float v_scale, void* q8, int ldq8, void* k_img, void* v_img, int dtype,
+                      void* stream);
+int lmi_attn_fp8_fwd(const void* q8, int ldq8, const void* k_img, const void* v_img, void* out, int ldo, void* out_fp8, int ldo8, float out_fp8_scale,
+                     const int* cu_seqlens, const int* tile_base, int n_seq, int n_tiles, int max_seqlen, int n_heads, int n_kv_heads, int head_dim,
+                     float softmax_scale, float q_scale, float k_scale, float v_scale, int causal, int dtype, void* stream);
+
 /* LayerNorm (b != null) / RMSNorm (b == null) of the fp32 stream written straight as an fp8 GEMM operand: out = fp8(norm(x) * out_scale). */
 int lmi_norm_fp8(const float* x, const float* w, const float* b, void* out, int M, int D, int ldx, int ldo, float eps, float out_scale,
                  void* stream);

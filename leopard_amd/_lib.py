@@ -50,6 +50,8 @@ SIGNATURES = {
     "lmi_gemv_rmsnorm_rope": [_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],
     "lmi_attn_decode_pool": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, C.c_int64, _I, _P],
     "lmi_rope_qk_rows": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, C.c_int64, _P, _I, _P],
+    "lmi_attn_prep_fp8": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _I, _P, _P, _I, _P],
+    "lmi_attn_fp8_fwd": [_P, _I, _P, _P, _P, _I, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _I, _P],
     "lmi_attn_varlen_fwd_fp8": [_P, _P, _P, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "lmi_rope_qkv_fp8": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_split_hi_lo": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -10,6 +10,7 @@
 
 #include "attention.h"
 #include "attention64.h"
+#include "attention_fp8.h"
 #include "elementwise.h"
 #include "patch_embed.h"
 #include "gemm.h"
@@ -535,6 +536,14 @@ int rope_entry(const char* who, void* qkv, int S, int ld, int n_q_heads, int n_k
 }
 
 
+template <typename T>
+static int attn_fp8_impl(const AttnFp8Args& a, int n_seq, int causal, void* stream) {
+    const dim3 grid((unsigned)(a.n_qblocks * a.n_heads * n_seq));
+    if (causal) LMI_LAUNCH((attn_fwd_fp8_kernel<T, true>), grid, dim3(ATT_THREADS), 4 * ATT8_IMG, stream, a);
+    else LMI_LAUNCH((attn_fwd_fp8_kernel<T, false>), grid, dim3(ATT_THREADS), 4 * ATT8_IMG, stream, a);
+    return check_launch("lmi_attn_fp8_fwd");
+}
+
 extern "C" {
 
 const char* lmi_last_error(void) { return g_err; }
@@ -936,6 +945,50 @@ int lmi_attn_varlen_fwd_fp8(const void* q, const void* k, const void* v, void* o
     if (!out_fp8) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd_fp8: null pointer");
     return attn_varlen_entry("lmi_attn_varlen_fwd_fp8", q, k, v, nullptr, nullptr, 0, out_fp8, ldo8, out_scale, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads,
                              n_kv_heads, head_dim, ldq, ldk, ldv, 0, scale, causal, window, 1, dtype, stream);
+}
+
+// ---- fp8 attention arithmetic (attention_fp8.h): operand preparation + forward ----------------------------------------------------
+int lmi_attn_prep_fp8(const void* qkv, int ld, const int* cu_seqlens, const int* tile_base, int n_seq, int n_tiles, int n_q_heads, int n_kv_heads,
+                      int head_dim, float q_scale, float k_scale, float v_scale, void* q8, int ldq8, void* k_img, void* v_img, int dtype,
+                      void* stream) {
+    if (!qkv || !cu_seqlens || !tile_base || !q8 || !k_img || !v_img) return fail(LMI_EINVAL, "lmi_attn_prep_fp8: null pointer");
+    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_attn_prep_fp8: head_dim %d (only 128)", head_dim);
+    if (n_seq < 0 || n_tiles < 0 || n_q_heads <= 0 || n_kv_heads <= 0 || (n_q_heads % n_kv_heads) || (ld & 7) || (ldq8 & 15) ||
+        ld < (n_q_heads + 2 * n_kv_heads) * 128 || ldq8 < n_q_heads * 128 || !aligned16(qkv) || !aligned16(q8) || !aligned16(k_img) || !aligned16(v_img) ||
+        !(q_scale > 0.f) || !(k_scale > 0.f) || !(v_scale > 0.f))
+        return fail(LMI_EINVAL, "lmi_attn_prep_fp8: bad argument (16-byte aligned pointers, ld %% 8 == 0, ldq8 %% 16 == 0, positive scales)");
+    if ((long)n_tiles * ATT8_IMG >= (1L << 32)) return fail(LMI_EINVAL, "lmi_attn_prep_fp8: %d key tiles per kv head exceed a 4 GiB image", n_tiles);
+    if (n_seq == 0 || n_tiles == 0) return LMI_OK;
+    AttnPrepArgs a;
+    a.qkv = qkv; a.cu = cu_seqlens; a.tile_base = tile_base; a.q8 = (uint8_t*)q8; a.k_img = (uint8_t*)k_img; a.v_img = (uint8_t*)v_img;
+    a.ld = ld; a.ldq8 = ldq8; a.n_seq = n_seq; a.n_tiles = n_tiles; a.n_heads = n_q_heads; a.n_kv_heads = n_kv_heads;
+    a.q_scale = q_scale; a.k_scale = k_scale; a.v_scale = v_scale;
+    const dim3 grid((unsigned)n_tiles, (unsigned)(2 * n_kv_heads + n_q_heads));
+    if (dtype == LMI_F16) LMI_LAUNCH((attn_prep_fp8_kernel<f16_t>), grid, dim3(256), 0, stream, a);
+    else if (dtype == LMI_BF16) LMI_LAUNCH((attn_prep_fp8_kernel<bf16_t>), grid, dim3(256), 0, stream, a);
+    else return fail(LMI_EINVAL, "lmi_attn_prep_fp8: dtype must be LMI_F16 or LMI_BF16");
+    return check_launch("lmi_attn_prep_fp8");
+}
+
+int lmi_attn_fp8_fwd(const void* q8, int ldq8, const void* k_img, const void* v_img, void* out, int ldo, void* out_fp8, int ldo8, float out_fp8_scale,
+                     const int* cu_seqlens, const int* tile_base, int n_seq, int n_tiles, int max_seqlen, int n_heads, int n_kv_heads, int head_dim,
+                     float softmax_scale, float q_scale, float k_scale, float v_scale, int causal, int dtype, void* stream) {
+    if (!q8 || !k_img || !v_img || (!out && !out_fp8) || !cu_seqlens || !tile_base) return fail(LMI_EINVAL, "lmi_attn_fp8_fwd: null pointer");
+    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_attn_fp8_fwd: head_dim %d (only 128)", head_dim);
+    if (n_seq < 0 || n_tiles < 0 || max_seqlen < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads) || (ldq8 & 15) || ldq8 < n_heads * 128 ||
+        (out && ((ldo & 7) || ldo < n_heads * 128 || !aligned16(out))) || (out_fp8 && ((ldo8 & 7) || ldo8 < n_heads * 128 || ((uintptr_t)out_fp8 & 7))) ||
+        !aligned16(q8) || !aligned16(k_img) || !aligned16(v_img) || !(q_scale > 0.f) || !(k_scale > 0.f) || !(v_scale > 0.f))
+        return fail(LMI_EINVAL, "lmi_attn_fp8_fwd: bad argument");
+    if ((long)n_tiles * ATT8_IMG >= (1L << 32)) return fail(LMI_EINVAL, "lmi_attn_fp8_fwd: %d key tiles per kv head exceed a 4 GiB image", n_tiles);
+    if (n_seq == 0 || max_seqlen == 0 || n_tiles == 0) return LMI_OK;
+    AttnFp8Args a;
+    a.q8 = (const uint8_t*)q8; a.k_img = (const uint8_t*)k_img; a.v_img = (const uint8_t*)v_img; a.out = out_fp8 ? nullptr : out; a.out_fp8 = (uint8_t*)out_fp8;
+    a.cu = cu_seqlens; a.tile_base = tile_base; a.ldq8 = ldq8; a.ldo = ldo; a.ldo8 = ldo8; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads;
+    a.n_tiles = n_tiles; a.n_qblocks = (max_seqlen + ATT_BQ - 1) / ATT_BQ;
+    a.c2 = softmax_scale * 1.4426950408889634f / (q_scale * k_scale);
+    a.inv_v_scale = 1.0f / v_scale;
+    a.out_fp8_scale = out_fp8_scale;
+    LMI_DISPATCH_T(dtype, (attn_fp8_impl<f16_t>(a, n_seq, causal, stream)), (attn_fp8_impl<bf16_t>(a, n_seq, causal, stream)));
 }
 
 int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* out_f32, int ldo32, const int* cu_seqlens_q,

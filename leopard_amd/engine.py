@@ -129,6 +129,7 @@ class LeopardEngine:
         self.skinny_fold_norm = True   # batched decode: RMSNorms folded into the projections (lmi_gemm_skinny_ex producer / consumer); False: norm launches
         self.skinny_packed = True      # batched decode over nn.Linear-layout weights (TP, pack_llm_weights=False): stream a packed second copy
         self.fp8_fused = True          # fp8 schedule: attention writes the fp8 o_proj operand, q|k|v GEMM does RoPE + KV append (False: separate launches)
+        self.fp8_attention = os.environ.get("LMI_FP8_ATTENTION", "0") == "1"   # fp8 schedule: QK^T and PV of the Llama layers on the fp8 pipe too (attention_fp8.h)
         self._fp8 = None               # leopard_amd.fp8.Fp8Plan: fp8 operands for the ViT / LLM layer linears (enable_fp8; configs[4])
         self._rec = None               # calibration recorder callable((tower, layer, site), operand tensor)
         tc = cfg.text_config
@@ -524,7 +525,7 @@ class LeopardEngine:
             self.trace("llm.embed", x)
         if self.fp8 is not None or (self.split_operands and self.tp_size == 1):
             if self.fp8 is not None:
-                self._llm_layers_fp8(x, cache, cu, cos, sin, max_len)
+                self._llm_layers_fp8(x, cache, cu, cos, sin, max_len, seq_lens)
             else:
                 self._llm_layers_split(x, cache, cu, cos, sin, max_len)
             if cache is not None:
@@ -571,6 +572,8 @@ class LeopardEngine:
                 else:                                    # packed weights keep the rope-ordered rows only: projection + RoPE + KV append on the normalised rows
                     ops.rmsnorm_rope(h, L.qkv_w_rope, qkv, None, tc.rms_norm_eps, cos, sin, cache.k[i] if cache else None,
                                      cache.v[i] if cache else None, 0, H, KV, hd)
+                if rec:                                  # operands of the fp8 attention arithmetic (rotated q / k, v)
+                    rec(("llm", i, "q"), qkv[:, :qw]); rec(("llm", i, "k"), qkv[:, qw:qw + kw]); rec(("llm", i, "v"), qkv[:, qw + kw:])
                 ops.attention(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale,
                               True, self.use_tr, window=tc.sliding_window or 0)
                 rec and rec(("llm", i, "att"), att)
@@ -586,9 +589,11 @@ class LeopardEngine:
             cache.length = S
         return self._lm_head(x, last_rows, all_logits)
 
-    def _llm_layers_fp8(self, x, cache, cu, cos, sin, max_len):
+    def _llm_layers_fp8(self, x, cache, cu, cos, sin, max_len, seq_lens=None):
         """The Llama layers with fp8 linears (leopard_amd.fp8): RMSNorm -> fp8 operand in one launch, the SwiGLU epilogue of
-        gate/up writes down_proj's fp8 operand; q|k|v, RoPE, the KV cache and the attention stay 16-bit, the stream fp32."""
+        gate/up writes down_proj's fp8 operand; q|k|v, RoPE and the KV cache stay 16-bit, the stream fp32.  ``fp8_attention``: the
+        attention's two products run on the fp8 matrix pipe as well (lmi_attn_prep_fp8 + lmi_attn_fp8_fwd: e4m3 q, k, v and P with the
+        static scales of the plan; the cache keeps the 16-bit K / V for the decode)."""
         ops, W, tc, P = self.ops, self.W, self.cfg.text_config, self.fp8
         S, D = x.shape
         (H, KV), hd = self._llm_heads(), tc.head_dim
@@ -601,6 +606,17 @@ class LeopardEngine:
         att = self._empty(S, qw)
         scale = hd ** -0.5
         fused = self.fp8_fused and self.use_tr          # (the fp8-output attention lives in the LDS-DMA kernel, the production one)
+        a8 = (self.fp8_attention and fused and hd == 128 and seq_lens is not None and not (tc.sliding_window or 0)
+              and all(k in Q.act for Q in P.llm for k in ("q", "k", "v")))
+        if a8:
+            tiles = [(int(l) + 63) // 64 for l in seq_lens]
+            key = ("a8", tuple(int(l) for l in seq_lens))
+            tb = self._geom_cache.get(key)
+            if tb is None:
+                tb = self._geom_cache[key] = self._pinned_to_device(torch.tensor([0] + list(np.cumsum(tiles)), dtype=torch.int32))
+            n_tiles = sum(tiles)
+            q8 = self._empty(S, qw, dtype=u8)
+            k_img, v_img = self._empty(KV * n_tiles * 8192, dtype=u8), self._empty(KV * n_tiles * 8192, dtype=u8)
         for i, (L, Q) in enumerate(zip(W.llm_layers, P.llm)):
             ops.norm_fp8(x, L.in_norm, None, h8, tc.rms_norm_eps, 2.0 ** Q.act["h1"])
             if fused and hd == 128 and "qkv_rope" in Q.lin:
@@ -609,7 +625,12 @@ class LeopardEngine:
             else:
                 ops.gemm_fp8(h8, Q.lin["qkv"].w8, qkv, scale_exp=Q.out_exp("h1", "qkv"))
                 ops.rope_qk(qkv, H, KV, hd, cos, sin, cache.k[i] if cache else None, cache.v[i] if cache else None, 0)
-            if fused:
+            if a8:
+                sq, sk, sv = 2.0 ** Q.act["q"], 2.0 ** Q.act["k"], 2.0 ** Q.act["v"]
+                ops.attn_prep_fp8(qkv, cu, tb, n_tiles, H, KV, hd, sq, sk, sv, q8, k_img, v_img)
+                ops.attention_fp8(q8, k_img, v_img, att8, cu, tb, n_tiles, max_len, H, KV, hd, scale, sq, sk, sv, causal=True,
+                                  out_fp8_scale=2.0 ** Q.act["att"], dtype=self.dtype)
+            elif fused:
                 ops.attention_fp8out(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att8, 2.0 ** Q.act["att"], cu, cu, max_len, H, KV, hd, scale,
                                      True, window=tc.sliding_window or 0)
             else:

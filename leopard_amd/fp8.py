@@ -24,6 +24,7 @@ import torch
 F8_MAX = 448.0
 VIT_SITES = ("h1", "att", "h2", "ff")
 LLM_SITES = ("h1", "att", "h2", "gu")
+ATTN_SITES = ("q", "k", "v")          # operands of the fp8 attention arithmetic (engine.fp8_attention): rotated q / k and v of every Llama layer
 
 
 def pow2_exp(amax: float, headroom: float) -> int:
@@ -98,5 +99,8 @@ def calibrate(engine, samples, headroom: float = 2.0) -> Fp8Plan:
             assert lay.lin["qkv_rope"].e == lay.lin["qkv"].e
         for s in LLM_SITES:
             lay.act[s] = pow2_exp(amax.get(("llm", li, s), 0.0), headroom)
+        for s in ATTN_SITES:
+            if ("llm", li, s) in amax:
+                lay.act[s] = pow2_exp(amax[("llm", li, s)], headroom)
         plan.llm.append(lay)
     return plan

@@ -364,6 +364,23 @@ class Ops:
                                                      float(scale), int(bool(causal)), int(window), _DT[q.dtype], self._stream(out32)))
         return out32
 
+    def attn_prep_fp8(self, qkv, cu, tile_base, n_tiles, n_q_heads, n_kv_heads, head_dim, q_scale, k_scale, v_scale, q8, k_img, v_img):
+        """lmi_attn_prep_fp8: rotated q | k | v rows -> e4m3 q rows + per (kv head, 64-key tile) K / transposed-V LDS images (uint8 buffers)."""
+        self._check(self.lib.lmi_attn_prep_fp8(_ptr(qkv), qkv.stride(0), _ptr(cu), _ptr(tile_base), cu.numel() - 1, int(n_tiles), n_q_heads, n_kv_heads,
+                                               head_dim, float(q_scale), float(k_scale), float(v_scale), _ptr(q8), q8.stride(0), _ptr(k_img), _ptr(v_img),
+                                               _DT[qkv.dtype], self._stream(q8)))
+
+    def attention_fp8(self, q8, k_img, v_img, out, cu, tile_base, n_tiles, max_seqlen, n_heads, n_kv_heads, head_dim, scale, q_scale, k_scale, v_scale,
+                      causal=True, out_fp8_scale=None, dtype=None):
+        """lmi_attn_fp8_fwd: QK^T and PV on the fp8 matrix pipe from the operands of attn_prep_fp8.  out: T rows, or (out_fp8_scale given) uint8
+        rows = e4m3(O * out_fp8_scale); dtype: the 16-bit type of the schedule when the output is fp8."""
+        f8 = out_fp8_scale is not None
+        self._check(self.lib.lmi_attn_fp8_fwd(_ptr(q8), q8.stride(0), _ptr(k_img), _ptr(v_img), None if f8 else _ptr(out), 0 if f8 else out.stride(0),
+                                              _ptr(out) if f8 else None, out.stride(0) if f8 else 0, float(out_fp8_scale or 0.0), _ptr(cu), _ptr(tile_base),
+                                              cu.numel() - 1, int(n_tiles), int(max_seqlen), n_heads, n_kv_heads, head_dim, float(scale), float(q_scale),
+                                              float(k_scale), float(v_scale), int(bool(causal)), _DT[dtype if f8 else out.dtype], self._stream(out)))
+        return out
+
     def attention_fp8out(self, q, k, v, out8, out_scale: float, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, scale, causal, window=0):
         """lmi_attn_varlen_fwd_fp8: the attention output written as e4m3(O * out_scale) bytes (uint8 [total_q, n_heads * head_dim])."""
         n_seq = cu_q.numel() - 1

@@ -204,3 +204,119 @@ def test_engine_fp8_schedule_matches_fp8_emulating_oracle(ops):
             delattr(ops, name)
     eng.fp8 = None                                         # reverts to the 16-bit schedule bit for bit
     assert torch.equal(eng.prefill(ids, u8, all_logits=True).logits_all, base)
+
+
+def _e4m3(x):
+    return x.clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("causal,lens,dtype", [(True, [150, 64, 1], torch.float16), (False, [70], torch.bfloat16), (True, [257], torch.float16)])
+def test_attention_fp8_operands_and_products(ops, causal, lens, dtype):
+    """lmi_attn_prep_fp8 + lmi_attn_fp8_fwd (attention_fp8.h): QK^T and PV on the fp8 matrix pipe.  (a) the prepared operands are exactly
+    e4m3(x * scale) in the documented places — q8 rows, the swizzled K image, the transposed V image in key-slot order, zeros past a
+    sequence's end; (b) the attention equals, to the rounding of P alone, an fp32 softmax attention over those e4m3 operands — packed
+    sequences of ragged lengths, GQA, causal and full; T and fp8 outputs agree."""
+    H, KV, D = 4, 2, 128
+    S = sum(lens)
+    g = torch.Generator().manual_seed(S)
+    qkv = (torch.randn(S, (H + 2 * KV) * D, generator=g) * 1.5).to(dtype)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    tiles = [(L + 63) // 64 for L in lens]
+    tb = torch.tensor([0] + list(np.cumsum(tiles)), dtype=torch.int32)
+    NT = int(tb[-1])
+    sq, sk, sv = 32.0, 16.0, 64.0
+    q8 = torch.zeros(S, H * D, dtype=torch.uint8)
+    k_img = torch.full((KV * NT * 8192,), 0xAA, dtype=torch.uint8)
+    v_img = torch.full((KV * NT * 8192,), 0xAA, dtype=torch.uint8)
+    ops.attn_prep_fp8(qkv, cu, tb, NT, H, KV, D, sq, sk, sv, q8, k_img, v_img)
+    qf, kf, vf = qkv[:, :H * D].float(), qkv[:, H * D:(H + KV) * D].float(), qkv[:, (H + KV) * D:].float()
+    q_ref, k_ref, v_ref = _e4m3(qf * sq), _e4m3(kf * sk), _e4m3(vf * sv)
+    assert torch.equal(q8.view(torch.float8_e4m3fn).float(), q_ref.float())
+    # decode the images back to [kv head][key row][d]
+    slot_key = [(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) for hi in range(2) for b in range(2) for r in range(16)]
+    kd = torch.zeros(KV, NT * 64, D)
+    vd = torch.zeros(KV, NT * 64, D)
+    ki, vi = k_img.view(KV, NT, 8192), v_img.view(KV, NT, 8192)
+    for h in range(KV):
+        for t in range(NT):
+            kt, vt = ki[h, t].view(torch.float8_e4m3fn).float(), vi[h, t].view(torch.float8_e4m3fn).float()
+            for r in range(64):
+                for c in range(8):
+                    o = r * 128 + ((c ^ ((r >> 1) & 7)) << 4)
+                    kd[h, t * 64 + r, c * 16:(c + 1) * 16] = kt[o:o + 16]
+            for d in range(D):
+                for c in range(4):
+                    o = d * 64 + ((c ^ ((d >> 2) & 3)) << 4)
+                    for e in range(16):
+                        vd[h, t * 64 + slot_key[c * 16 + e], d] = vt[o + e]
+    outs = []
+    for s_i, L in enumerate(lens):
+        r0, t0 = int(cu[s_i]), int(tb[s_i]) * 64
+        for h in range(KV):
+            assert torch.equal(kd[h, t0:t0 + L], k_ref[r0:r0 + L, h * D:(h + 1) * D].float())
+            assert torch.equal(vd[h, t0:t0 + L], v_ref[r0:r0 + L, h * D:(h + 1) * D].float())
+            pad = tiles[s_i] * 64 - L
+            assert pad == 0 or (kd[h, t0 + L:t0 + L + pad].abs().max() == 0 and vd[h, t0 + L:t0 + L + pad].abs().max() == 0)
+        # fp32 attention over the e4m3 operands
+        qs = q_ref[r0:r0 + L].float().view(L, H, D).transpose(0, 1) / sq
+        ks = k_ref[r0:r0 + L].float().view(L, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0) / sk
+        vs = v_ref[r0:r0 + L].float().view(L, KV, D).transpose(0, 1).repeat_interleave(H // KV, 0) / sv
+        sc = (qs @ ks.transpose(-1, -2)) * D ** -0.5
+        if causal:
+            sc = sc.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
+        outs.append((torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(L, H * D))
+    ref = torch.cat(outs, 0)
+    out = torch.full((S, H * D), float("nan"), dtype=dtype)
+    ops.attention_fp8(q8, k_img, v_img, out, cu, tb, NT, max(lens), H, KV, D, D ** -0.5, sq, sk, sv, causal=causal)
+    err = (out.float() - ref).abs().max().item()
+    assert not torch.isnan(out.float()).any() and err <= 0.04 * ref.abs().max().item(), err      # P carries 3 mantissa bits; everything else is exact or fp32
+    o8 = torch.zeros(S, H * D, dtype=torch.uint8)
+    ops.attention_fp8(q8, k_img, v_img, o8, cu, tb, NT, max(lens), H, KV, D, D ** -0.5, sq, sk, sv, causal=causal, out_fp8_scale=64.0, dtype=dtype)
+    assert (o8.view(torch.float8_e4m3fn).float() / 64.0 - out.float()).abs().max().item() <= 0.07 * out.float().abs().max().item()
+
+
+def test_engine_fp8_attention_arithmetic_is_an_option_of_the_fp8_schedule(ops):
+    """engine.fp8_attention: calibration records the rotated q / k / v of every Llama layer, the schedule then runs lmi_attn_prep_fp8 +
+    lmi_attn_fp8_fwd instead of the 16-bit attention (packed samples of different lengths, the KV cache still receives the 16-bit K / V), and
+    the logits stay within the fp8 schedule's own error of the fp8-linears-only result."""
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    from leopard_amd.engine import KVCache, LeopardEngine
+    from leopard_amd.weights import EngineWeights, SynthSource
+    cfg = LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16, image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                               vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+    dtype = torch.float16
+    eng = LeopardEngine(cfg, EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", dtype), dtype), ops=ops, device="cpu")
+    u8 = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
+    ids = torch.tensor([[5, 250, 9, 250, 17, 33] + list(range(40, 110))])             # 84 rows: two key tiles, the second ragged
+    base = eng.prefill(ids, u8).logits_last.clone()
+    plan = eng.enable_fp8([(ids, u8)])
+    assert all(k in lay.act for lay in plan.llm for k in ("q", "k", "v"))
+    lin_only = eng.prefill(ids, u8).logits_last.clone()
+    calls, orig = [], {}
+    for name in ("attn_prep_fp8", "attention_fp8", "attention_fp8out"):
+        orig[name] = getattr(ops, name)
+        setattr(ops, name, (lambda f, n: (lambda *a, **k: (calls.append(n), f(*a, **k))[1]))(orig[name], name))
+    try:
+        eng.fp8_attention = True
+        cache = KVCache(cfg, 128, dtype, "cpu")
+        got = eng.prefill(ids, u8, cache=cache).logits_last
+        # two Llama layers on the fp8 attention; the one SigLIP layer keeps the 16-bit arithmetic with the fp8 output
+        assert calls.count("attn_prep_fp8") == 2 and calls.count("attention_fp8") == 2 and calls.count("attention_fp8out") == 1
+        eng.fp8_attention = False
+        cache2 = KVCache(cfg, 128, dtype, "cpu")
+        eng.prefill(ids, u8, cache=cache2)
+        assert torch.equal(cache.k[0][:cache.length], cache2.k[0][:cache2.length])       # layer 0's K rows do not depend on the attention arithmetic
+        eng.fp8_attention = True
+        two, _ = eng.prefill_batch([(ids, u8), (torch.tensor([[7, 8, 9]]), None)])        # packed: per-sequence tile bases
+        assert (two[0] - got).abs().max() == 0
+    finally:
+        eng.fp8_attention = False
+        for name, fn in orig.items():
+            setattr(ops, name, fn)
+    scale = base.abs().max().item()
+    e_lin = (lin_only - base).abs().max().item() / scale
+    e_a8 = (got - base).abs().max().item() / scale
+    assert e_a8 <= 3.0 * e_lin + 1e-2, (e_lin, e_a8)

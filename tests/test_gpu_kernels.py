@@ -619,3 +619,44 @@ def test_rope_rows_and_decode_pool_vs_per_sequence(ops):
         ops.attention_decode(one[:, :H * hd], kc, vc, o1, torch.tensor([0, 1], dtype=torch.int32, device=DEV),
                              torch.tensor([0, L], dtype=torch.int32, device=DEV), 1, cap, H, KV, hd, hd ** -0.5, ws1)
         assert torch.equal(o1[0], out[s]), s
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_attention_fp8_arithmetic_at_the_llama_shape(ops, dtype):
+    """lmi_attn_prep_fp8 + lmi_attn_fp8_fwd at the C3 Llama shape (S = 7187 + a ragged second sequence, 32 q / 8 kv heads x 128, causal): q8 is
+    exactly e4m3(q * scale); the attention equals the 16-bit kernel run on the SAME e4m3 operand values (exact in 16 bits) up to the e4m3
+    rounding of P; three launches are bit-identical; the fp8 output form agrees with the 16-bit one."""
+    H, KV, D = 32, 8, 128
+    lens = [7187, 300]
+    S = sum(lens)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    qkv = (torch.randn(S, (H + 2 * KV) * D, generator=g, device=DEV) * 1.5).to(dtype)
+    cu = torch.tensor([0, lens[0], S], dtype=torch.int32, device=DEV)
+    tiles = [(L + 63) // 64 for L in lens]
+    tb = torch.tensor([0, tiles[0], sum(tiles)], dtype=torch.int32, device=DEV)
+    NT = sum(tiles)
+    sq, sk, sv = 32.0, 32.0, 64.0
+    q8 = torch.zeros(S, H * D, dtype=torch.uint8, device=DEV)
+    k_img = torch.zeros(KV * NT * 8192, dtype=torch.uint8, device=DEV)
+    v_img = torch.zeros(KV * NT * 8192, dtype=torch.uint8, device=DEV)
+    ops.attn_prep_fp8(qkv, cu, tb, NT, H, KV, D, sq, sk, sv, q8, k_img, v_img)
+    e4 = lambda x, s_: (x.float() * s_).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(q8.view(torch.float8_e4m3fn).float(), e4(qkv[:, :H * D], sq).float())
+    deq = torch.cat([e4(qkv[:, :H * D], sq).float() / sq, e4(qkv[:, H * D:(H + KV) * D], sk).float() / sk,
+                     e4(qkv[:, (H + KV) * D:], sv).float() / sv], 1).to(dtype).contiguous()         # e4m3 values are exact in both 16-bit types
+    ref = torch.zeros(S, H * D, dtype=dtype, device=DEV)
+    ops.attention(deq[:, :H * D], deq[:, H * D:(H + KV) * D], deq[:, (H + KV) * D:], ref, cu, cu, max(lens), H, KV, D, D ** -0.5, True)
+    outs = []
+    for _ in range(3):
+        out = torch.full((S, H * D), float("nan"), dtype=dtype, device=DEV)
+        ops.attention_fp8(q8, k_img, v_img, out, cu, tb, NT, max(lens), H, KV, D, D ** -0.5, sq, sk, sv, causal=True)
+        outs.append(out)
+    assert not torch.isnan(outs[0].float()).any()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    err = (outs[0].float() - ref.float()).abs()
+    scale = ref.float().abs().max().item()
+    print(f"[fp8 attention {dtype}] vs the 16-bit kernel on the same e4m3 operands: max {err.max().item() / scale:.3e} of max|O|, rms {err.pow(2).mean().sqrt().item() / ref.float().pow(2).mean().sqrt().item():.3e}")
+    assert not torch.isnan(outs[0].float()).any() and err.max().item() <= 0.05 * scale
+    o8 = torch.zeros(S, H * D, dtype=torch.uint8, device=DEV)
+    ops.attention_fp8(q8, k_img, v_img, o8, cu, tb, NT, max(lens), H, KV, D, D ** -0.5, sq, sk, sv, causal=True, out_fp8_scale=64.0, dtype=dtype)
+    assert (o8.view(torch.float8_e4m3fn).float() / 64.0 - outs[0].float()).abs().max().item() <= 0.07 * scale

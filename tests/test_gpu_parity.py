@@ -337,6 +337,15 @@ def test_full_depth_fp8_c1_vs_oracle(ops, full_depth_oracle):
           f"HIP vs emulating oracle: {n2:.3e} / {r2:.3e};  argmax equal = {int(got.argmax()) == int(ref.argmax())}")
     assert 0.7 * pr <= r <= 1.4 * pr
     assert r2 <= 1.8 * pr
+    # the Llama layers' attention arithmetic on the fp8 pipe as well (engine.fp8_attention: e4m3 q / k / v / P): a few more e4m3 roundings
+    # per layer on top of the eight operands of its four linears — the error of the line stays of the same size
+    eng.fp8_attention = True
+    got8 = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV)).logits_last.cpu()
+    _, n8, r8 = err_stats(got8, ref)
+    _, _, r88 = err_stats(got8, got)
+    print(f"[c1 full depth fp8 + fp8 attention arithmetic] normalised-max {n8:.3e} rel-rms {r8:.3e} vs fp32 (fp8 linears only: {r:.3e});  vs the fp8-linears "
+          f"result: rel-rms {r88:.3e};  argmax equal = {int(got8.argmax()) == int(ref.argmax())}")
+    assert not torch.isnan(got8).any() and r8 <= 2.0 * pr
     del eng
     torch.cuda.empty_cache()
 
