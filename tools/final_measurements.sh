@@ -7,6 +7,7 @@ cp gpurun_out/traffic/gemm_hbm_traffic.json gpurun_out/final/ 2>/dev/null
 timeout 400 python bench.py --steps 10 --warmup 3 > gpurun_out/final/bench_c3_f16.json 2> gpurun_out/final/bench_c3_f16.err
 timeout 200 python bench.py --dtype bf16 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/final/bench_c3_bf16.json 2>/dev/null
 timeout 200 python bench.py --dtype fp8 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/final/bench_c3_fp8.json 2>/dev/null
+timeout 200 python bench.py --dtype fp8 --fp8-attention 0 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/final/bench_c3_fp8_f16_attention.json 2>/dev/null
 timeout 300 python bench.py --workload llava-c5 --graph-encode --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_c5_f16_graph.json 2>/dev/null
 timeout 300 python bench.py --workload llava-c5 --dtype fp8 --graph-encode --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_c5_fp8_graph.json 2>/dev/null
 timeout 300 python bench.py --workload idefics2-c4 --steps 10 --warmup 3 > gpurun_out/final/bench_idefics2_c4.json 2>/dev/null
