@@ -66,6 +66,8 @@ class _Emu:
     fp8_block = 0         # 0 = per-tensor fp8 scales (what the engine does); 32 = per-32-element E8M0 block scales (study only)
     operand_dtype = None  # fp8 schedule (BASELINE config 5): the A operands AND the weights of the ViT / LLM layer linears are
                           # float8_e4m3fn with per-tensor power-of-two scales; everything else stays at ``dtype``
+    fp8_attention = False # fp8 schedule with engine.fp8_attention (csrc/attention_fp8.h): the rotated q / k, v (per-tensor power-of-two
+                          # scales) and the probabilities entering P.V of the LLM layers are e4m3 as well; row sums and accumulators fp32
     _wcache: dict = {}
 
 
@@ -114,14 +116,16 @@ def _tr(name: str, x: Tensor) -> None:
 
 
 class emulate_rounding:
-    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None, exact_sites=(), fp8_block: int = 0):
+    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None, exact_sites=(), fp8_block: int = 0, fp8_attention: bool = False):
         self.dtype, self.trace, self.operand_dtype, self.exact_sites = dtype, trace, operand_dtype, frozenset(exact_sites)
         self.fp8_block = fp8_block
+        self.fp8_attention = bool(fp8_attention) and operand_dtype is not None
 
     def __enter__(self):
         self._old = (_Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused)
-        self._old_sites, self._old_block = _Emu.exact_sites, _Emu.fp8_block
+        self._old_sites, self._old_block, self._old_a8 = _Emu.exact_sites, _Emu.fp8_block, _Emu.fp8_attention
         _Emu.fp8_block = self.fp8_block
+        _Emu.fp8_attention = self.fp8_attention
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype = self.dtype, self.trace, self.operand_dtype
         _Emu.exact_sites = self.exact_sites
         if self.operand_dtype is not None:
@@ -130,7 +134,7 @@ class emulate_rounding:
 
     def __exit__(self, *exc):
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused = self._old
-        _Emu.exact_sites, _Emu.fp8_block = self._old_sites, self._old_block
+        _Emu.exact_sites, _Emu.fp8_block, _Emu.fp8_attention = self._old_sites, self._old_block, self._old_a8
         _Emu._wcache.clear()
         return False
 
@@ -248,13 +252,17 @@ def gelu_tanh(x: Tensor) -> Tensor:
     return F.gelu(x, approximate="tanh")
 
 
-def _softmax_q(scores: Tensor) -> Tensor:
+def _softmax_q(scores: Tensor, fp8_p: bool = False) -> Tensor:
     """fp32 softmax; under emulate_rounding() the probabilities that enter the P.V product are rounded like the
-    kernel's P operand while the normaliser stays the fp32 sum of the UNROUNDED exponentials (as in the kernel)."""
+    kernel's P operand while the normaliser stays the fp32 sum of the UNROUNDED exponentials (as in the kernel).
+    fp8_p (attention_fp8.h): that operand is e4m3 — exp(s - max) <= 1 rounded directly (the kernel's P is the same value times a power
+    of two <= 2^8, its deferred reference: the same relative rounding, and fewer values flushed at the bottom of the range)."""
     if _Emu.dtype is None:
         return torch.softmax(scores, dim=-1, dtype=torch.float32)
     m = scores.amax(dim=-1, keepdim=True)
     e = torch.exp(scores - m)
+    if fp8_p:
+        return e.to(_Emu.operand_dtype).to(torch.float32) / e.sum(dim=-1, keepdim=True)
     return _q(e) / e.sum(dim=-1, keepdim=True)
 
 
@@ -434,6 +442,9 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
     k = _q(k * cos + rotate_half(k) * sin)
     if kv_out is not None:
         kv_out.append((k, v))
+    a8 = _Emu.fp8_attention and _Emu.operand_dtype is not None   # lmi_attn_prep_fp8: the attention reads e4m3 copies of the 16-bit q / k / v
+    if a8:
+        q, k, v = _fp8_round(q), _fp8_round(k), _fp8_round(v)
     rep = H // KV                                               # GQA repeat, XFMR:829-836
     kk = k.repeat_interleave(rep, dim=1)
     vv = v.repeat_interleave(rep, dim=1)
@@ -448,7 +459,7 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
         if getattr(tc, "sliding_window", None):                 # Mistral: query i sees keys j with i - j < window
             causal = causal & (ar[s0:s1, None] - ar[None, :s1] < tc.sliding_window)
         sc = sc.masked_fill(~causal, float("-inf"))
-        o[:, :, s0:s1] = torch.matmul(_softmax_q(sc), vv[:, :, :s1])
+        o[:, :, s0:s1] = torch.matmul(_softmax_q(sc, fp8_p=a8), vv[:, :, :s1])
     o = o.transpose(1, 2).reshape(B, S, H * hd)
     o = _qa(o if "attn_out" in _Emu.exact_sites else _q(o), "attn_out")
     x = r + F.linear(o, _wq(W[p + "self_attn.o_proj.weight"]))

@@ -320,3 +320,18 @@ def test_engine_fp8_attention_arithmetic_is_an_option_of_the_fp8_schedule(ops):
     e_lin = (lin_only - base).abs().max().item() / scale
     e_a8 = (got - base).abs().max().item() / scale
     assert e_a8 <= 3.0 * e_lin + 1e-2, (e_lin, e_a8)
+    # and it sits where the oracle that also rounds q / k / v / P to e4m3 predicts (emulate_rounding(..., fp8_attention=True))
+    from leopard_amd.synth import synth_state_dict_numpy
+    from leopard_amd.tiler import siglip_normalize
+    from oracle import leopard_oracle as O
+    Wt = O.weights_from_numpy(synth_state_dict_numpy(cfg))
+    pix = torch.from_numpy(siglip_normalize(u8.numpy()))
+    exact = O.prefill_logits(ids, pix, Wt, cfg)[0, -1]
+    with O.emulate_rounding(dtype, operand_dtype=torch.float8_e4m3fn, fp8_attention=True):
+        emu = O.prefill_logits(ids, pix, Wt, cfg)[0, -1]
+    with O.emulate_rounding(dtype, operand_dtype=torch.float8_e4m3fn):
+        emu_lin = O.prefill_logits(ids, pix, Wt, cfg)[0, -1]
+    rr = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    predicted, measured = rr(emu, exact), rr(got, exact)
+    assert not torch.equal(emu, emu_lin)                        # the option changes the emulation
+    assert 0.4 * predicted <= measured <= 2.5 * predicted, (predicted, measured)

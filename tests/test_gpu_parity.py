@@ -312,6 +312,17 @@ def test_mid_config_fp8_vs_oracle(ops, mid_oracle):
     assert r > 3 * r16                                       # the fp8 schedule ran
     assert 0.7 * vpr <= vr <= 1.4 * vpr and 0.7 * pr <= r <= 1.4 * pr
     assert r2 <= 1.8 * pr
+    # the Llama attention arithmetic on the fp8 pipe as well (engine.fp8_attention): predicted by the oracle that also rounds q / k / v / P
+    eng.fp8_attention = True
+    res8 = eng.prefill(ids.to(DEV), torch.from_numpy(u8).to(DEV), all_logits=True).logits_all.cpu()
+    eng.fp8_attention = False
+    with O.emulate_rounding(torch.float16, operand_dtype=torch.float8_e4m3fn, fp8_attention=True):
+        emu8 = O.prefill_logits(ids, torch.from_numpy(siglip_normalize(u8)), W, cfg)[0]
+    _, n8, r8 = err_stats(res8, logits[0])
+    _, pn8, pr8 = err_stats(emu8, logits[0])
+    _, _, r88 = err_stats(res8, res.logits_all.cpu())
+    print(f"[mid fp8 + fp8 attention arithmetic] logits_all: measured ({n8:.2e}, {r8:.2e}) predicted ({pn8:.2e}, {pr8:.2e});  vs the fp8-linears result: rel-rms {r88:.2e}")
+    assert 0.7 * pr8 <= r8 <= 1.4 * pr8 and r88 > 0
     # the captured vision encode follows the schedule: graphs taken under fp8 replay fp8, and are dropped when the plan is removed
     eng.graph_encode = True
     t8 = torch.from_numpy(u8).to(DEV)
