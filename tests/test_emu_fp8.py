@@ -335,3 +335,27 @@ def test_engine_fp8_attention_arithmetic_is_an_option_of_the_fp8_schedule(ops):
     predicted, measured = rr(emu, exact), rr(got, exact)
     assert not torch.equal(emu, emu_lin)                        # the option changes the emulation
     assert 0.4 * predicted <= measured <= 2.5 * predicted, (predicted, measured)
+
+
+def test_attention_fp8_entries_reject_bad_arguments(ops):
+    """lmi_attn_prep_fp8 / lmi_attn_fp8_fwd fail loudly (LMI_EINVAL + message) instead of launching on a head size, stride or scale they cannot serve;
+    empty work is a no-op."""
+    H, KV, D, S = 2, 1, 128, 70
+    qkv = torch.zeros(S, (H + 2 * KV) * D, dtype=torch.float16)
+    cu = torch.tensor([0, S], dtype=torch.int32)
+    tb = torch.tensor([0, 2], dtype=torch.int32)
+    q8 = torch.zeros(S, H * D, dtype=torch.uint8)
+    k_img, v_img = torch.zeros(KV * 2 * 8192, dtype=torch.uint8), torch.zeros(KV * 2 * 8192, dtype=torch.uint8)
+    out = torch.zeros(S, H * D, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="head_dim"):
+        ops.attn_prep_fp8(qkv, cu, tb, 2, H, KV, 64, 1.0, 1.0, 1.0, q8, k_img, v_img)
+    with pytest.raises(RuntimeError, match="scales"):
+        ops.attn_prep_fp8(qkv, cu, tb, 2, H, KV, D, 0.0, 1.0, 1.0, q8, k_img, v_img)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        ops.attn_prep_fp8(qkv, cu, tb, 2, H, KV, D, 1.0, 1.0, 1.0, torch.zeros(S, (H - 1) * D, dtype=torch.uint8), k_img, v_img)   # q8 rows narrower than the heads
+    with pytest.raises(RuntimeError, match="head_dim"):
+        ops.attention_fp8(q8, k_img, v_img, out, cu, tb, 2, S, H, KV, 96, 0.1, 1.0, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        ops.attention_fp8(q8, k_img, v_img, out, cu, tb, 2, S, 3, 2, D, 0.1, 1.0, 1.0, 1.0)               # 3 query heads over 2 kv heads
+    ops.attn_prep_fp8(qkv, cu, tb, 0, H, KV, D, 1.0, 1.0, 1.0, q8, k_img, v_img)                            # no tiles: nothing to do
+    ops.attention_fp8(q8, k_img, v_img, out, cu, tb, 0, S, H, KV, D, 0.1, 1.0, 1.0, 1.0)
