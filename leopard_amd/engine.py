@@ -165,8 +165,18 @@ class LeopardEngine:
     # ---- one copy of the LLM weights ----------------------------------------------------------------------------------------------
     @property
     def llm_packed(self) -> bool:
+        """True when the layer linears are stored in the packed order.  The layout of a tensor is a mark on the tensor object
+        (weights.mark_packed), which a copy (.clone() / .to()) does not carry: the engine remembers what it packed and refuses to run on a
+        weight set whose marks disagree with that, instead of reading a packed matrix as row-major."""
         from .weights import is_packed
-        return bool(self.W.llm_layers) and is_packed(self.W.llm_layers[0].o_w)
+        L0 = self.W.llm_layers[0] if self.W.llm_layers else None
+        marked = L0 is not None and is_packed(L0.o_w)
+        want = getattr(self.W, "_llm_packed", None)
+        if want is not None and L0 is not None and any(is_packed(getattr(L0, n)) != want for n in ("qkv_w_rope", "o_w", "gu_w", "down_w")
+                                                       if getattr(L0, n) is not None):
+            raise RuntimeError("LLM layer weights were replaced by copies that lost their layout mark (weights.mark_packed); "
+                               "call engine.pack_llm_weights() / unpack_llm_weights() instead of copying packed tensors")
+        return marked
 
     def pack_llm_weights(self) -> bool:
         """Store the Llama / Mistral layer linears ONCE, in the operand order the decode kernels stream (weights.skinny_pack), in place.
@@ -187,6 +197,7 @@ class LeopardEngine:
             for name in ("qkv_w_rope", "o_w", "gu_w", "down_w"):
                 setattr(L, name, as_packed(getattr(L, name)))
             L.qkv_w = None
+        W._llm_packed = True
         self._skinny_pack = None
         self._batch_states = {}                               # steps captured over a second copy of the weights
         return True
@@ -196,10 +207,12 @@ class LeopardEngine:
         from .weights import as_row_major
         if not self.llm_packed:
             return
+        self.W._llm_packed = None                             # in transition
         for L in self.W.llm_layers:
             L.qkv_w = self._qkv_natural(L)
             for name in ("qkv_w_rope", "o_w", "gu_w", "down_w"):
                 setattr(L, name, as_row_major(getattr(L, name)))
+        self.W._llm_packed = False
         self._batch_states = {}                               # captured steps hold the packed tensors' launches (batch-1 states re-capture: _decode_run)
         self._head_pack = None
 
@@ -518,6 +531,7 @@ class LeopardEngine:
         qw, kw = H * hd, KV * hd
         cu, cos, sin, last_rows, cu_list = self.sequence_geometry(seq_lens)
         assert cu_list[-1] == S
+        self.llm_packed                                   # raises when a packed weight was replaced by a copy without its layout mark
         if cache is not None:       # one sequence, or a pool holding the packed rows of several (generate_batch splits it afterwards)
             assert cache.length == 0 and cache.capacity >= S
         max_len = max(int(l) for l in seq_lens)

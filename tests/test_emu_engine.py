@@ -281,3 +281,16 @@ def test_one_copy_of_the_llm_weights_serves_prefill_and_decode(setup):
     eng.unpack_llm_weights()
     assert not eng.llm_packed and all(torch.equal(getattr(L1, n), getattr(L0, n)) for n in ("qkv_w", "qkv_w_rope", "o_w", "gu_w", "down_w"))
     assert torch.equal(eng.prefill(ids, u8, all_logits=True).logits_all, a.logits_all)
+
+
+def test_a_packed_weight_that_lost_its_mark_is_refused(setup):
+    """The layout of a weight is a mark on the tensor object; a copy does not carry it.  The engine remembers that it packed and refuses such a weight
+    set instead of reading a packed matrix as row-major."""
+    ops, cfg, _ = setup
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    assert eng.llm_packed
+    for L in W.llm_layers:
+        L.o_w = L.o_w.clone()                                        # the mark is gone, the bytes are still in the packed order
+    with pytest.raises(RuntimeError, match="layout mark"):
+        eng.prefill(torch.tensor([[7, 8, 9]]), None)
