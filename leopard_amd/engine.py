@@ -202,6 +202,23 @@ class LeopardEngine:
         self._batch_states = {}                               # steps captured over a second copy of the weights
         return True
 
+    def pack_vit_weights(self, packed: bool = True) -> int:
+        """A/B knob (default: not applied): the SigLIP layer linears in the packed order as well — the GEMM's W staging reads 2-KiB-contiguous
+        row groups instead of 128-byte row segments 2.3 / 8.7 KiB apart (the effect that made the Llama GEMMs 0.7 % faster).  Same bits.  Returns
+        the number of tensors converted.  The fp8 plan and the split-operand copies are built from row-major views either way."""
+        from .weights import as_packed, as_row_major, is_packed, packable
+        n = 0
+        for L in self.W.vit_layers:
+            for name in ("qkv_w", "o_w", "fc1_w", "fc2_w"):
+                w = getattr(L, name)
+                if packed and not is_packed(w) and packable(w) and w.shape[0] % 128 == 0:
+                    setattr(L, name, as_packed(w)); n += 1
+                elif not packed and is_packed(w):
+                    setattr(L, name, as_row_major(w)); n += 1
+        if n:
+            self._encode_graphs.clear()                       # captured encodes replay the launches of the old layout
+        return n
+
     def unpack_llm_weights(self) -> None:
         """Back to the nn.Linear layout (A/B runs, tools that read the weights)."""
         from .weights import as_row_major

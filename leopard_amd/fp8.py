@@ -85,8 +85,9 @@ def calibrate(engine, samples, headroom: float = 2.0) -> Fp8Plan:
         engine._rec, engine.fuse_norm_rope, engine.fp8, engine.graph_encode = old
     W, ops, plan = engine.W, engine.ops, Fp8Plan()
     for li, L in enumerate(W.vit_layers):
-        lay = Fp8Layer(lin={"qkv": quantize_linear(ops, L.qkv_w), "o": quantize_linear(ops, L.o_w),
-                            "fc1": quantize_linear(ops, L.fc1_w), "fc2": quantize_linear(ops, L.fc2_w)})
+        from .weights import as_row_major as _rm                 # engine.pack_vit_weights may have packed them
+        lay = Fp8Layer(lin={"qkv": quantize_linear(ops, _rm(L.qkv_w)), "o": quantize_linear(ops, _rm(L.o_w)),
+                            "fc1": quantize_linear(ops, _rm(L.fc1_w)), "fc2": quantize_linear(ops, _rm(L.fc2_w))})
         for s in VIT_SITES:
             lay.act[s] = pow2_exp(amax.get(("vit", li, s), 0.0), headroom)
         plan.vit.append(lay)

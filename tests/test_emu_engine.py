@@ -294,3 +294,26 @@ def test_a_packed_weight_that_lost_its_mark_is_refused(setup):
         L.o_w = L.o_w.clone()                                        # the mark is gone, the bytes are still in the packed order
     with pytest.raises(RuntimeError, match="layout mark"):
         eng.prefill(torch.tensor([[7, 8, 9]]), None)
+
+
+def test_vit_weights_in_the_packed_order_give_the_same_bits(setup):
+    """LeopardEngine.pack_vit_weights (an A/B knob): the SigLIP linears read from the packed order by the same GEMM — identical features and logits,
+    also through the split-operand mode; and back."""
+    ops, cfg, _ = setup
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", torch.float16), torch.float16)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    u8 = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
+    ids = torch.tensor([[5, 250, 9, 250, 17]])
+    a = eng.prefill(ids, u8, keep_parts=True)
+    assert eng.pack_vit_weights() == 4 * len(W.vit_layers)
+    b = eng.prefill(ids, u8, keep_parts=True)
+    assert torch.equal(a.parts["vit"], b.parts["vit"]) and torch.equal(a.logits_last, b.logits_last)
+    eng.split_operands = True
+    s1 = eng.prefill(ids, u8).logits_last.clone()
+    eng.split_operands = False
+    assert eng.pack_vit_weights(False) == 4 * len(W.vit_layers)
+    eng._split_w = None
+    eng.split_operands = True
+    assert torch.equal(eng.prefill(ids, u8).logits_last, s1)
+    eng.split_operands = False
+    assert torch.equal(eng.prefill(ids, u8).logits_last, a.logits_last)

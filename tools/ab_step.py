@@ -68,7 +68,9 @@ def main():
 
     def apply(kv):
         for k in touched:
-            if k == "eng.llm_packed":                   # one copy of the LLM weights (packed order) vs the nn.Linear layout
+            if k == "eng.vit_packed":                   # SigLIP layer linears in the packed order (LeopardEngine.pack_vit_weights)
+                eng.pack_vit_weights(bool(kv.get(k, 0)))
+            elif k == "eng.llm_packed":                   # one copy of the LLM weights (packed order) vs the nn.Linear layout
                 eng.pack_llm_weights() if kv.get(k, 1) else eng.unpack_llm_weights()
             elif k.startswith("eng."):
                 setattr(eng, k[4:], bool(kv.get(k, 1)))
