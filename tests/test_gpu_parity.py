@@ -607,6 +607,16 @@ def test_configs4_fp8_at_the_8x8_size_with_graph_encode(ops):
     rel = ((one_a - f16_one).pow(2).mean().sqrt() / f16_one.pow(2).mean().sqrt()).item()
     print(f"[configs[4] size, mid depth] fp8 vs f16 schedule, relative RMS of the last-position logits: {rel:.3e}")
     assert 1e-2 < rel < 0.5
+    # the configuration bench.py times for configs[4]: the Llama attention arithmetic on the fp8 pipe as well (per-sequence tile images of the
+    # packed batch) — the same property: every sample of the packed batch == its own prefill, bit for bit
+    eng.fp8_attention = True
+    a8_a, a8_b = eng.prefill(ids, tiles).logits_last.clone(), eng.prefill(idsb, tiles_b).logits_last.clone()
+    logits8, _ = eng.prefill_batch(samples)
+    for i in range(8):
+        assert torch.equal(logits8[i], a8_a if i % 2 == 0 else a8_b), i
+    rel8 = ((a8_a - one_a).pow(2).mean().sqrt() / one_a.pow(2).mean().sqrt()).item()
+    print(f"[configs[4] size, mid depth] + fp8 attention arithmetic: relative RMS vs the fp8-linears logits {rel8:.3e}")
+    assert torch.isfinite(logits8).all() and 0 < rel8 < 0.5
 
 
 def test_graph_captured_encode_is_bit_identical(ops):
