@@ -546,6 +546,15 @@ def measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler):
             "prefill_mfma_frac_of_n_gpus": round(fl["total"] / 1e12 / (elapsed / args.steps) / (MFMA_PEAK_TFLOPS * world), 4)}
 
 
+DEFAULT_PRECISION = "fast"
+PRECISION_NOTE = {
+    "fast": "fast: one rounding of every activation to the 16-bit compute type per MFMA-operand hand-over",
+    "lo4": "lo4: fast + the MX fp4 image of every layer-linear operand's rounding residual multiplied with an fp4 weight image into the same "
+           "accumulators (v_mfma_scale_f32_32x32x64_f8f6f4, + 25 % matrix time; algorithmic FLOPs below are the model's, not the extra MFMA work)",
+    "split": "split operands: every A operand of every ViT / LLM layer linear handed over as hi + lo 16-bit values, GEMMs at 2 K "
+             "(algorithmic FLOPs below are the model's, not the doubled MFMA work)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -572,6 +581,9 @@ def main():
     ap.add_argument("--graph-encode", action="store_true", help="capture the vision encode (ViT + projector) in a HIP graph per ViT-input count")
     ap.add_argument("--split-operands", action="store_true",
                     help="precision mode (NOT the headline): hi + lo split A operands for every layer linear, GEMMs at 2 K — full-depth logits within 1e-3 of fp32")
+    ap.add_argument("--precision", default=None, choices=["fast", "lo4", "split"],
+                    help="schedule of the 16-bit engines (DESIGN.md 2.1): fast = one rounding per operand hand-over; lo4 = + the fp4 correction "
+                         "phase (logits within north_star's 1e-3 at full depth); split = hi + lo 16-bit operand pairs at 2 K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-tp", action="store_true", help="N > 1: skip the additional one-sample-on-all-ranks (strong scaling) measurement")
@@ -634,7 +646,11 @@ def main():
     eng = LeopardEngine(cfg, W, ops=ops, device=dev)
     eng.fuse_norm_rope = not args.no_fuse
     eng.graph_encode = args.graph_encode
-    eng.split_operands = args.split_operands
+    if args.split_operands:
+        args.precision = "split"
+    if args.precision is None:
+        args.precision = DEFAULT_PRECISION if args.dtype == "f16" else "fast"
+    eng.precision = args.precision
     load_s = time.perf_counter() - t0
 
     class Ctx:
@@ -724,8 +740,7 @@ def main():
         "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        **({"precision_mode": "split operands: every A operand of every ViT / LLM layer linear handed over as hi + lo 16-bit values, GEMMs at 2 K "
-                              "(algorithmic FLOPs below are the model's, not the doubled MFMA work)"} if args.split_operands else {}),
+        "precision_mode": PRECISION_NOTE[args.precision],
         **({"dtype_detail": fp8_detail(args), "prefill_mfma_frac_note": "algorithmic FLOPs / time against the 2.5 PF 16-bit peak (mixed-precision step)"}
            if args.dtype == "fp8" else {}),
         "config": {"workload": f"{config_label(args)}: {args.images}x({args.width}x{args.height}) images -> {n_tiles} ViT inputs (364x364), "

@@ -254,6 +254,39 @@ int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* 
                             const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                             int ldq, int ldk, int ldv, float scale, int causal, int window, int dtype, void* stream);
 
+/* Low-bit correction phase (LeopardEngine.precision = "lo4") — the cheap way to north_star's "logits within 1e-3".
+ * The reference runs fp32 (evaluations/models/llava_multiimg_siglip_anyres.py:373,322-333); a 16-bit-operand MFMA path differs from it by
+ * ONE rounding of every activation handed to a matrix operand.  That residual x - T(x) only needs a few bits: producers hand it over as
+ * an MX fp4 image (e2m1; one E8M0 power-of-two scale per 32 consecutive k), the weight has an fp4 image with one E8M0 scale per row, and
+ * after its 16-bit k-loop the GEMM runs K4 / 256 more k-tiles of v_mfma_scale_f32_32x32x64_f8f6f4 on the two images INTO THE SAME
+ * ACCUMULATORS: + 25 % matrix-pipe time instead of + 100 % for the hi + lo 16-bit pair, ~80 % of the rounding removed.
+ * Images: row-major, element k of a row in nibble k & 1 of byte k >> 1; K4 = K rounded up to a multiple of 256 elements, zero codes and
+ * zero scale bytes in the padding; lda4 / ldw4 / ld_out4 in BYTES; a4_scale [M, lds4] with lds4 >= K4 / 32; w4_scale [N].
+ * lmi_lo4: inputs (a4, a4_scale, w4, w4_scale: all four) consumed by this launch, outputs (out4, out4_scale: both or neither) = the image of
+ * the residual of this launch's own 16-bit result — `out` for LMI_EPI_STORE (+ activation) and LMI_EPI_SWIGLU, `norm_out` for the
+ * RESIDUAL producer mode — for the next GEMM. */
+typedef struct lmi_lo4 {
+    const void* a4; const void* a4_scale; const void* w4; const void* w4_scale;
+    int lda4, ldw4, lds4, k4;
+    void* out4; void* out4_scale;
+    int ld_out4, ld_out4s;
+} lmi_lo4;
+/* lmi_gemm_ex / lmi_rmsnorm_rope with the correction phase (plain A, row-major or packed W for the 16-bit pass, K >= 128). */
+int lmi_gemm_lo4(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
+                 const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, const float* norm_gamma, float* rowsq_out,
+                 int ld_norm, const lmi_lo4* lo, int dtype, void* stream);
+int lmi_rmsnorm_rope_lo4(const void* A, const void* Wqkv, void* qkv, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_table,
+                         const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads,
+                         int head_dim, int K, int lda, int ldw, int ldo, const lmi_lo4* lo, int dtype, void* stream);
+/* fp32 activation [M, K] (K % 32 == 0) -> hi = T(x) [M, ldh] + the fp4 image of x - T(x) [M, ld4 bytes] + its block scales [M, lds]
+ * (attention outputs: lmi_attn_varlen_fwd_f32 hands over fp32). */
+int lmi_split_lo4(const float* x, void* hi, void* lo4, void* scales, int M, int K, int K4, int ldx, int ldh, int ld4, int lds, int dtype, void* stream);
+/* LayerNorm (b != null) / RMSNorm (b == null) writing T(y) and the fp4 image of y - T(y) in one launch (D % 32 == 0, D <= 4096). */
+int lmi_norm_lo4(const float* x, const float* w, const float* b, void* out, void* out4, void* scales, int M, int D, int K4, int ldx, int ldo,
+                 int ld4, int lds, float eps, int dtype, void* stream);
+/* Weight image, once at load: W T [N, K] row-major (ldw elements) -> fp4 [N, ld4 bytes] + one E8M0 scale per row [N]. */
+int lmi_quantize_w4(const void* W, void* w4, void* scales, int N, int K, int K4, int ldw, int ld4, int dtype, void* stream);
+
 /* Caller-owned scratch of a prefill pass (SURVEY.md 8b "workspace: size from lmi_*_workspace_bytes"; the library allocates nothing).
  * One contiguous, 256-byte aligned workspace per stage holds every activation buffer that lives between the launches of one pass — the
  * Llama / Mistral layer stack over `rows` packed sequence rows (reference: LlamaForCausalLM.forward, EVAL:322-333), the SigLIP layer

@@ -20,6 +20,13 @@ A_PLAIN, A_PIXEL_SHUFFLE = 0, 1
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 
+
+class Lo4Desc(C.Structure):
+    """``lmi_lo4`` of include/leopard_amd.h: the fp4 images a GEMM with the low-bit correction phase consumes / produces."""
+    _fields_ = [("a4", _P), ("a4_scale", _P), ("w4", _P), ("w4_scale", _P), ("lda4", _I), ("ldw4", _I), ("lds4", _I), ("k4", _I),
+                ("out4", _P), ("out4_scale", _P), ("ld_out4", _I), ("ld_out4s", _I)]
+
+
 # name -> argtypes  (restype is int unless noted); mirrors include/leopard_amd.h one to one
 SIGNATURES = {
     "lmi_abi_version": [],
@@ -55,6 +62,11 @@ SIGNATURES = {
     "lmi_attn_varlen_fwd_fp8": [_P, _P, _P, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "lmi_rope_qkv_fp8": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_split_hi_lo": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "lmi_gemm_lo4": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _P, _P, _I, C.POINTER(Lo4Desc), _I, _P],
+    "lmi_rmsnorm_rope_lo4": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(Lo4Desc), _I, _P],
+    "lmi_split_lo4": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lmi_norm_lo4": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "lmi_quantize_w4": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lmi_attn_varlen_fwd_f32": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "lmi_rope_qkv_skinny": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P, _P, _P, _I, C.c_int64, _P, _I, _P],
     "lmi_gemm_skinny_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _I, _P, _P, _I, _P],

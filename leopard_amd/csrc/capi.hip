@@ -14,6 +14,7 @@
 #include "elementwise.h"
 #include "patch_embed.h"
 #include "gemm.h"
+#include "lowbit.h"
 #include "skinny.h"
 
 using namespace lmi;
@@ -163,6 +164,54 @@ int launch_gemm(const GemmArgs& a, void* stream) {
         case 10: return launch_gemm_cfg<T, EPI, ACT, AMODE, CfgM>(a, stream);
         default: return launch_gemm_cfg<T, EPI, ACT, AMODE, Cfg0>(a, stream);
     }
+}
+
+// ---- low-bit correction phase (lmi_gemm_lo4): the production geometries only, mapped like the fp8 family -------------------------------------
+template <typename T, int EPI, int ACT, typename C>
+int launch_gemm_lo4_ring(const GemmArgs& a, void* stream) {
+    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    static std::atomic<uint64_t> attr_done{0};
+    allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE_PLAIN, C, T, true>, C::SMEM_LO4, attr_done);
+    LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE_PLAIN, C, T, true>), dim3(tiles), dim3(C::NT), C::SMEM_LO4, stream, a);
+    return check_launch("lmi_gemm_lo4");
+}
+template <typename T, int EPI, int ACT>
+int launch_gemm_lo4(const GemmArgs& a, void* stream) {
+    switch (choose_gemm_cfg(a)) {
+        case 2: case 3: case 4: return launch_gemm_lo4_ring<T, EPI, ACT, Cfg2>(a, stream);
+        case 5: case 6: case 7: case 1: {
+            const int tiles = ((a.M + Cfg1::BM - 1) / Cfg1::BM) * ((a.N + Cfg1::BN - 1) / Cfg1::BN);
+            static std::atomic<uint64_t> attr_done{0};
+            allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE_PLAIN, Cfg1, 0, T, true>, Cfg1::SMEM_LO4, attr_done);
+            LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE_PLAIN, Cfg1, 0, T, true>), dim3(tiles), dim3(Cfg1::NT), Cfg1::SMEM_LO4, stream, a);
+            return check_launch("lmi_gemm_lo4");
+        }
+        case 8: case 9: return launch_gemm_lo4_ring<T, EPI, ACT, CfgS>(a, stream);
+        case 10: return launch_gemm_lo4_ring<T, EPI, ACT, CfgM>(a, stream);
+        default: return launch_gemm_lo4_ring<T, EPI, ACT, Cfg0>(a, stream);
+    }
+}
+template <typename T>
+int dispatch_gemm_lo4(const GemmArgs& a, int epi, int act, void* stream) {
+    switch (epi) {
+        case LMI_EPI_STORE:
+            if (act == LMI_ACT_NONE) return launch_gemm_lo4<T, EPI_STORE_T, ACT_NONE>(a, stream);
+            if (act == LMI_ACT_GELU_TANH) return launch_gemm_lo4<T, EPI_STORE_T, ACT_GELU_TANH>(a, stream);
+            break;
+        case LMI_EPI_RESIDUAL:
+            if (act == LMI_ACT_NONE) return launch_gemm_lo4<T, EPI_RESID_F32, ACT_NONE>(a, stream);
+            break;
+        case LMI_EPI_STORE_F32:
+            if (act == LMI_ACT_NONE) return launch_gemm_lo4<T, EPI_STORE_F32, ACT_NONE>(a, stream);
+            break;
+        case LMI_EPI_SWIGLU:
+            if (act == LMI_ACT_NONE) return launch_gemm_lo4<T, EPI_SWIGLU_T, ACT_NONE>(a, stream);
+            break;
+        case LMI_EPI_QKV_ROPE:
+            if (act == LMI_ACT_NONE) return launch_gemm_lo4<T, EPI_QKV_ROPE_T, ACT_NONE>(a, stream);
+            break;
+    }
+    return fail(LMI_EINVAL, "lmi_gemm_lo4: unsupported epilogue/act combination (%d, %d)", epi, act);
 }
 
 // ---- fp8 operands (lmi_gemm_fp8): the production geometries only ---------------------------------------------------------------
@@ -381,6 +430,13 @@ int norm_impl(const float* x, const float* w, const float* b, void* out, int M, 
     return check_launch(what);
 }
 
+template <typename T, bool RMS>
+int norm_lo4_impl(const float* x, const float* w, const float* b, void* out, NormLo4 lo, int M, int D, int ldx, int ldo, float eps, void* stream) {
+    const int grid = (M + 3) / 4;
+    if (D <= 1536) LMI_LAUNCH((norm_kernel<T, RMS, 3, true>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps, 1.0f, lo);
+    else LMI_LAUNCH((norm_kernel<T, RMS, 8, true>), dim3(grid), dim3(256), 0, stream, x, w, b, (T*)out, M, D, ldx, ldo, eps, 1.0f, lo);
+    return check_launch("lmi_norm_lo4");
+}
 template <typename T, typename DT>
 int add_rmsnorm_impl(float* x, const void* delta, const float* w, void* out, int M, int D, int ldx, int ldd, int ldo, float eps,
                             void* stream) {
@@ -704,7 +760,7 @@ struct GemmExtras {
 };
 static int gemm_entry(const char* who, const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
                       const int* row_map, int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,
-                      int ps_grid, int dtype, void* stream, const GemmExtras& x) {
+                      int ps_grid, int dtype, void* stream, const GemmExtras& x, const lmi_lo4* lo = nullptr) {
     if (!A || !W || !out) return fail(LMI_EINVAL, "%s: null pointer", who);
     // ldw = LMI_LDW_PACKED(K) = -K: W in the operand order of lmi_gemm_skinny (one copy of the weights for prefill and decode)
     const bool w_packed = ldw < 0;
@@ -752,6 +808,28 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     if (a_bytes >= (1L << 32) || w_bytes >= (1L << 32))
         return fail(LMI_EINVAL, "%s: operand extent >= 4 GiB (A %ld, W %ld bytes)", who, a_bytes, w_bytes);
     a.a_bytes = (unsigned)a_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.A4 = nullptr; a.W4 = nullptr; a.a4_scale = nullptr; a.w4_scale = nullptr; a.lda4 = a.ldw4 = a.lds4 = a.K4 = 0;
+    a.a4_bytes = a.w4_bytes = a.a4s_bytes = 0;
+    a.out4 = nullptr; a.out4_scale = nullptr; a.ld_out4 = a.ld_out4s = 0;
+    if (lo) {                                                       // low-bit correction phase (lmi_gemm_lo4 / lmi_rmsnorm_rope_lo4)
+        const int k4 = (K + 255) / 256 * 256;
+        if (!lo->a4 || !lo->a4_scale || !lo->w4 || !lo->w4_scale || lo->k4 != k4 || K < 128 || a_mode != LMI_A_PLAIN || (lo->lda4 & 15) ||
+            (lo->ldw4 & 15) || lo->lda4 < k4 / 2 || lo->ldw4 < k4 / 2 || (lo->lds4 & 3) || lo->lds4 < k4 / 32 || !aligned16(lo->a4) || !aligned16(lo->w4) ||
+            ((uintptr_t)lo->a4_scale & 3))
+            return fail(LMI_EINVAL, "%s: lo4 needs all four images, k4 == K rounded up to 256 (%d), K >= 128, a plain A, 16-byte aligned images with "
+                        "lda4 / ldw4 %% 16 == 0 and >= k4 / 2, lds4 %% 4 == 0 and >= k4 / 32", who, k4);
+        if ((lo->out4 != nullptr) != (lo->out4_scale != nullptr) ||
+            (lo->out4 && (((uintptr_t)lo->out4 & 3) || (lo->ld_out4 & 3) || lo->ld_out4s <= 0 ||
+                          !(epilogue == LMI_EPI_SWIGLU || epilogue == LMI_EPI_STORE || (epilogue == LMI_EPI_RESIDUAL && x.norm_out)) || a.swiglu_f32)))
+            return fail(LMI_EINVAL, "%s: lo4 output needs out4 and out4_scale, ld_out4 %% 4 == 0, and the STORE / SWIGLU epilogue or the RESIDUAL producer mode", who);
+        const long a4b = (long)(M - 1) * lo->lda4 + k4 / 2, w4b = (long)(N - 1) * lo->ldw4 + k4 / 2, sb = (long)(M - 1) * lo->lds4 + k4 / 32;
+        if (a4b >= (1L << 32) || w4b >= (1L << 32)) return fail(LMI_EINVAL, "%s: lo4 image extent >= 4 GiB", who);
+        a.A4 = lo->a4; a.W4 = lo->w4; a.a4_scale = (const uint8_t*)lo->a4_scale; a.w4_scale = (const uint8_t*)lo->w4_scale;
+        a.lda4 = lo->lda4; a.ldw4 = lo->ldw4; a.lds4 = lo->lds4; a.K4 = k4;
+        a.a4_bytes = (unsigned)a4b; a.w4_bytes = (unsigned)w4b; a.a4s_bytes = (unsigned)sb;
+        a.out4 = lo->out4; a.out4_scale = (uint8_t*)lo->out4_scale; a.ld_out4 = lo->ld_out4; a.ld_out4s = lo->ld_out4s;
+        LMI_DISPATCH_T(dtype, dispatch_gemm_lo4<f16_t>(a, epilogue, act, stream), dispatch_gemm_lo4<bf16_t>(a, epilogue, act, stream));
+    }
     // (Measured and dropped, profiles/r03_ab_tail_split_and_prologue.txt: computing the last 256-column tile of SigLIP q|k|v / fc1 with a
     // second, finer launch so that the tile count drops from 6.07 / 7.37 to 5.64 / 6.94 rounds of 256 workgroups — 0.13 % SLOWER over the
     // C3 step.  An almost-empty last round is cheap on this part: the idle CUs draw no power and the rest clock up.)
@@ -817,6 +895,71 @@ int lmi_rmsnorm_rope(const void* A, const void* Wqkv, void* qkv, const float* ro
     const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
     return gemm_entry("lmi_rmsnorm_rope", A, Wqkv, qkv, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldw, ldo, 0, LMI_EPI_QKV_ROPE, LMI_ACT_NONE,
                       LMI_A_PLAIN, 0, dtype, stream, x);
+}
+
+int lmi_gemm_lo4(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
+                 const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, const float* norm_gamma, float* rowsq_out,
+                 int ld_norm, const lmi_lo4* lo, int dtype, void* stream) {
+    if (!lo) return fail(LMI_EINVAL, "lmi_gemm_lo4: null lo4 descriptor (use lmi_gemm_ex)");
+    if (epilogue == LMI_EPI_QKV_ROPE) return fail(LMI_EINVAL, "lmi_gemm_lo4: the q|k|v + RoPE epilogue is reached through lmi_rmsnorm_rope_lo4");
+    GemmExtras x;
+    x.rowsq_in = rowsq_in; x.rowsq_parts = rowsq_parts; x.norm_dim = norm_dim; x.norm_eps = norm_eps;
+    x.norm_out = norm_out; x.norm_gamma = norm_gamma; x.rowsq_out = rowsq_out; x.ld_norm = ld_norm;
+    return gemm_entry("lmi_gemm_lo4", A, W, out, bias, nullptr, nullptr, nullptr, M, N, K, lda, ldw, ldo, 0, epilogue, act, LMI_A_PLAIN, 0, dtype,
+                      stream, x, lo);
+}
+
+int lmi_rmsnorm_rope_lo4(const void* A, const void* Wqkv, void* qkv, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_table,
+                         const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads,
+                         int head_dim, int K, int lda, int ldw, int ldo, const lmi_lo4* lo, int dtype, void* stream) {
+    if (!lo) return fail(LMI_EINVAL, "lmi_rmsnorm_rope_lo4: null lo4 descriptor (use lmi_rmsnorm_rope)");
+    if (head_dim != 128) return fail(LMI_EINVAL, "lmi_rmsnorm_rope_lo4: head_dim %d (only 128: a wave's 64 columns hold half a head)", head_dim);
+    if (!cos_table || !sin_table || n_q_heads <= 0 || n_kv_heads <= 0 || ((k_cache != nullptr) != (v_cache != nullptr)) ||
+        (k_cache && ((ld_cache & 7) || !aligned16(k_cache) || !aligned16(v_cache))) || (ldo & 7) || !aligned16(cos_table) || !aligned16(sin_table))
+        return fail(LMI_EINVAL, "lmi_rmsnorm_rope_lo4: bad argument");
+    GemmExtras x;
+    x.rowsq_in = rowsq_in; x.rowsq_parts = rowsq_parts; x.norm_dim = K; x.norm_eps = norm_eps;
+    x.rope_cos = cos_table; x.rope_sin = sin_table; x.k_cache = k_cache; x.v_cache = v_cache; x.ld_cache = ld_cache; x.cache_pos0 = cache_pos0;
+    x.rope_q = n_q_heads * head_dim; x.rope_k = n_kv_heads * head_dim;
+    const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
+    return gemm_entry("lmi_rmsnorm_rope_lo4", A, Wqkv, qkv, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldw, ldo, 0, LMI_EPI_QKV_ROPE, LMI_ACT_NONE,
+                      LMI_A_PLAIN, 0, dtype, stream, x, lo);
+}
+
+int lmi_split_lo4(const float* x, void* hi, void* lo4, void* scales, int M, int K, int K4, int ldx, int ldh, int ld4, int lds, int dtype, void* stream) {
+    if (!x || !hi || !lo4 || !scales || M < 0 || K <= 0 || (K & 31) || K4 != (K + 255) / 256 * 256 || (ldx & 3) || (ldh & 7) || ldh < K || (ld4 & 3) ||
+        ld4 < K4 / 2 || lds < K4 / 32 || !aligned16(x) || !aligned16(hi) || ((uintptr_t)lo4 & 3))
+        return fail(LMI_EINVAL, "lmi_split_lo4: bad argument (M=%d K=%d K4=%d; K %% 32 == 0, K4 = K rounded up to 256, ld4 >= K4 / 2, lds >= K4 / 32)", M, K, K4);
+    if (M == 0) return LMI_OK;
+    const int grid = grid_for((long)M * (K4 >> 3), 256);
+    if (dtype == LMI_F16) LMI_LAUNCH((split_lo4_kernel<f16_t>), dim3(grid), dim3(256), 0, stream, x, (f16_t*)hi, (uint8_t*)lo4, (uint8_t*)scales, M, K, K4, ldx, ldh, ld4, lds);
+    else if (dtype == LMI_BF16) LMI_LAUNCH((split_lo4_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, x, (bf16_t*)hi, (uint8_t*)lo4, (uint8_t*)scales, M, K, K4, ldx, ldh, ld4, lds);
+    else return fail(LMI_EINVAL, "lmi_split_lo4: dtype must be LMI_F16 or LMI_BF16");
+    return check_launch("lmi_split_lo4");
+}
+
+int lmi_norm_lo4(const float* x, const float* w, const float* b, void* out, void* out4, void* scales, int M, int D, int K4, int ldx, int ldo,
+                 int ld4, int lds, float eps, int dtype, void* stream) {
+    if (!x || !w || !out || !out4 || !scales || M < 0 || D <= 0 || (D & 31) || D > 4096 || K4 != (D + 255) / 256 * 256 || (ldx & 3) || (ldo & 7) ||
+        (ld4 & 3) || ld4 < K4 / 2 || lds < K4 / 32 || !aligned16(x) || !aligned16(w) || !aligned16(out) || ((uintptr_t)out4 & 3) || (b && !aligned16(b)))
+        return fail(LMI_EINVAL, "lmi_norm_lo4: bad argument (M=%d D=%d K4=%d; D %% 32 == 0, D <= 4096, K4 = D rounded up to 256)", M, D, K4);
+    if (M == 0) return LMI_OK;
+    NormLo4 lo;
+    lo.out4 = (uint8_t*)out4; lo.scales = (uint8_t*)scales; lo.ld4 = ld4; lo.lds = lds; lo.K4 = K4;
+    if (dtype == LMI_F16) return b ? norm_lo4_impl<f16_t, false>(x, w, b, out, lo, M, D, ldx, ldo, eps, stream) : norm_lo4_impl<f16_t, true>(x, w, b, out, lo, M, D, ldx, ldo, eps, stream);
+    if (dtype == LMI_BF16) return b ? norm_lo4_impl<bf16_t, false>(x, w, b, out, lo, M, D, ldx, ldo, eps, stream) : norm_lo4_impl<bf16_t, true>(x, w, b, out, lo, M, D, ldx, ldo, eps, stream);
+    return fail(LMI_EINVAL, "lmi_norm_lo4: dtype must be LMI_F16 or LMI_BF16");
+}
+
+int lmi_quantize_w4(const void* W, void* w4, void* scales, int N, int K, int K4, int ldw, int ld4, int dtype, void* stream) {
+    if (!W || !w4 || !scales || N <= 0 || K <= 0 || (K & 7) || K4 != (K + 255) / 256 * 256 || (ldw & 7) || ldw < K || (ld4 & 15) || ld4 < K4 / 2 ||
+        !aligned16(W) || !aligned16(w4))
+        return fail(LMI_EINVAL, "lmi_quantize_w4: bad argument (N=%d K=%d K4=%d; K %% 8 == 0, K4 = K rounded up to 256, ld4 %% 16 == 0 and >= K4 / 2)", N, K, K4);
+    const int grid = (N + 3) / 4;
+    if (dtype == LMI_F16) LMI_LAUNCH((quantize_w4_kernel<f16_t>), dim3(grid), dim3(256), 0, stream, (const f16_t*)W, (uint8_t*)w4, (uint8_t*)scales, N, K, K4, ldw, ld4);
+    else if (dtype == LMI_BF16) LMI_LAUNCH((quantize_w4_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)W, (uint8_t*)w4, (uint8_t*)scales, N, K, K4, ldw, ld4);
+    else return fail(LMI_EINVAL, "lmi_quantize_w4: dtype must be LMI_F16 or LMI_BF16");
+    return check_launch("lmi_quantize_w4");
 }
 
 int lmi_rope_qkv_fp8(const void* A8, const void* Wqkv8, void* qkv, int scale_exp, const float* cos_table, const float* sin_table, void* k_cache,

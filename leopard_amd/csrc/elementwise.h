@@ -113,9 +113,17 @@ __global__ void resample_u8_kernel(const uint8_t* src, uint8_t* dst, int rows, i
 // LayerNorm (SigLIP, eps 1e-6) / RMSNorm (Llama, eps 1e-5): fp32 stream row -> 16-bit GEMM operand row.
 // One wave per row, row kept in registers, statistics in fp32 with two passes (mean, then centred variance).
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool RMS, int MAXV>     // MAXV = max 8-element chunks per lane (D <= MAXV*512)
+// LO4 (lmi_norm_lo4): besides T(y) the kernel writes the MX fp4 image of the rounding residuals y - T(y) and its block scales (the A
+// operand of a GEMM with the low-bit correction phase, lowbit.h); a lane's 8 elements are a quarter of a 32-element block, D % 32 == 0,
+// images K4 = D rounded up to 256 wide (zero padding written here).
+struct NormLo4 {
+    uint8_t* out4;
+    uint8_t* scales;
+    int ld4, lds, K4;
+};
+template <typename T, bool RMS, int MAXV, bool LO4 = false>     // MAXV = max 8-element chunks per lane (D <= MAXV*512)
 __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* w, const float* b, T* out,
-                                                   int M, int D, int ldx, int ldo, float eps, float out_scale) {
+                                                   int M, int D, int ldx, int ldo, float eps, float out_scale, NormLo4 lo = NormLo4()) {
     typedef typename vec_of<T>::x8 T8;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -157,11 +165,13 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
         rstd = 1.0f / sqrtf(q / (float)D + eps);
     }
     T* orow = out + (long)row * ldo;
+    float lo_y[LO4 ? MAXV : 1][8];                                   // LO4: the normalised values, encoded wave-uniformly below
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = i * 64 + lane;
         if (c < nvec) {
             T8 o;
+            float yv[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x4 ww = *(const f32x4*)(w + c * 8 + 4 * h);
@@ -169,6 +179,7 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float y = ww[e] * (v[i][h][e] * rstd);
+                        yv[4 * h + e] = y;
                         o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);       // fp8 operand: static power-of-two scale
                     }
                 } else {
@@ -176,11 +187,36 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float y = (v[i][h][e] - mean) * rstd * ww[e] + bb[e];
+                        yv[4 * h + e] = y;
                         o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);
                     }
                 }
             }
-            *(T8*)(orow + c * 8) = o;
+            if constexpr (!(LO4 && sizeof(T) == 2)) *(T8*)(orow + c * 8) = o;
+            if constexpr (LO4 && sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lo_y[i][e] = yv[e];
+            }
+        }
+    }
+    if constexpr (LO4 && sizeof(T) == 2) {
+        // every lane of the wave takes part in the quad exchange (idle lanes on zeros: they also write the zero padding up to K4);
+        // nvec % 4 == 0, so a block's four lanes are live or idle together
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = i * 64 + lane;
+            if (i * 64 >= (lo.K4 >> 3)) break;                       // wave-uniform
+            float yv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) yv[e] = c < nvec ? lo_y[i][e] : 0.f;
+            T8 o;
+            unsigned sb;
+            const unsigned codes = lo4_encode8<T>(yv, o, sb);
+            if (c < nvec) *(T8*)(orow + c * 8) = o;
+            if (c < (lo.K4 >> 3)) {
+                *(unsigned*)(lo.out4 + (long)row * lo.ld4 + c * 4) = codes;
+                if ((lane & 3) == 0) lo.scales[(long)row * lo.lds + (c >> 2)] = (uint8_t)sb;
+            }
         }
     }
 }

@@ -80,6 +80,23 @@ struct GemmArgs {
     int swiglu_f32;              // EPI_SWIGLU_T with an fp32 destination (split-operand precision mode: the product goes to lmi_split_hi_lo)
     int scale_e8m0;
     float out_scale;             // fp8 OUTPUTS (T = fp8_t: GELU / SwiGLU results handed to the next fp8 GEMM): value * out_scale, then e4m3
+    // ---- low-bit correction phase (LO4 instantiations; DESIGN.md 2.1 "precision mode") ------------------------------------------------------
+    // The 16-bit A operand is T(x); the distance of the HIP path from the fp32 reference is that one rounding per hand-over.  The producer
+    // also hands over the residual x - T(x) as an MX fp4 image A4 (e2m1, one E8M0 scale per 32 k: a4_scale[m][k / 32]) and the weight has an
+    // fp4 image W4 (one E8M0 scale per row: w4_scale[n]); after the K / 64 16-bit k-tiles the SAME accumulators take K4 / 256 k-tiles of
+    // v_mfma_scale_f32_32x32x64_f8f6f4 on the two images (4 x the 16-bit rate: + 25 % matrix time), which removes ~80 % of the rounding.
+    // Images are row-major, K4 = K rounded up to 256 elements wide (zero codes in the padding), lda4 / ldw4 in BYTES.
+    const void* A4;
+    const void* W4;
+    const uint8_t* a4_scale;
+    const uint8_t* w4_scale;
+    int lda4, ldw4, lds4, K4;
+    unsigned a4_bytes, w4_bytes, a4s_bytes;
+    // producer side (LO4 instantiations): the fp4 image + block scales of the residual of THIS launch's 16-bit output — `out` for the
+    // STORE (+ activation) and SwiGLU epilogues, `norm_out` for the RESIDUAL producer mode — written next to it (null = not wanted)
+    void* out4;
+    uint8_t* out4_scale;
+    int ld_out4, ld_out4s;       // bytes per row of out4 / of out4_scale
 };
 
 constexpr int GEMM_BK = 64;
@@ -97,6 +114,8 @@ struct GemmCfg {
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int SMEM = STAGES * STAGE_BYTES;
     static constexpr int SMEM_TOTAL = SMEM + BM * 4;             // + the row scales of a folded RMSNorm (GemmRowScale)
+    static constexpr int SC_BYTES = BM * 8;                      // LO4: 8 E8M0 block scales per A row and fp4 k-tile, one slot per ring stage
+    static constexpr int SMEM_LO4 = SMEM_TOTAL + STAGES * SC_BYTES;
     static constexpr int D = STAGES - 1;                       // prefetch distance in k-tiles (>= 1)
     static_assert(STAGES >= 2, "ring needs at least two slots");
     static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows vs threads");
@@ -174,6 +193,53 @@ LMI_DEV typename GemmFrag<TA>::type gemm_wfrag_load(const char* tile, int r0, in
 LMI_DEV f32x16 gemm_mma(f16x8 a, f16x8 b, f32x16 c, int) { return mfma32(a, b, c); }
 LMI_DEV f32x16 gemm_mma(bf16x8 a, bf16x8 b, f32x16 c, int) { return mfma32(a, b, c); }
 LMI_DEV f32x16 gemm_mma(v8i a, v8i b, f32x16 c, int scale_e8m0) { return mfma32_fp8(a, b, c, scale_e8m0); }
+// the 16 bytes of a 16-bit fragment as the fp4 operand of the correction phase (the v8i overload only keeps fp8 instantiations well-formed)
+LMI_DEV u32x4 frag_bits(f16x8 f) { return __builtin_bit_cast(u32x4, f); }
+LMI_DEV u32x4 frag_bits(bf16x8 f) { return __builtin_bit_cast(u32x4, f); }
+LMI_DEV u32x4 frag_bits(v8i f) { return u32x4{(uint32_t)f[0], (uint32_t)f[1], (uint32_t)f[2], (uint32_t)f[3]}; }
+template <int N, typename F> LMI_DEV void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
+// ---- low-bit correction phase: block scales of the A residual image -----------------------------------------------------------------------
+// Per fp4 k-tile (256 k = 8 blocks) every A row has 8 scale bytes.  They travel like the operands: one 4-byte LDS-DMA piece per thread
+// (thread t -> dword t of the tile's [BM][2] dword image; rows past M read zeros through the buffer's range check = scale 2^-127) into a
+// per-stage slot behind the row scales of the folded norm.  A lane (fr, fh) reads its row's two dwords once per k-tile; block 2 ks + fh
+// of the tile is byte (ks & 1) * 2 + fh of dword ks >> 1, so the odd half-wave shifts its dwords right by 8 and both halves select bytes
+// 0 / 2 with the instruction's op_sel.  The weight image has ONE scale per row: two bytes per lane, loaded before the main loop.
+template <typename C>
+struct GemmLo4 {
+    static constexpr int SP = (2 * C::BM + C::NT - 1) / C::NT;    // 4-byte pieces per thread per k-tile
+    BufRsrc s_buf;
+    unsigned s_src[SP];
+    char* sc_base;            // slot 0 of the scale ring
+    int wave_off;
+    int w_sc[C::NI];
+    LMI_DEV void init(const GemmArgs& p, int m0, int n0, int tid, int wave, int wn, int fr, char* smem) {
+        s_buf = make_buf(p.a4_scale, p.a4s_bytes);
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            const int idx = j * C::NT + tid;                      // dword of the [BM][2] image: row idx >> 1, half idx & 1
+            s_src[j] = (unsigned)((long)(m0 + (idx >> 1)) * p.lds4 + (idx & 1) * 4);
+        }
+        sc_base = smem + C::SMEM_TOTAL;
+        wave_off = wave * 256;
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) w_sc[ni] = (int)p.w4_scale[imin(n0 + wn * C::WTN + ni * 32 + fr, p.N - 1)];
+    }
+    LMI_DEV void issue(int kt, int slot) const {
+#pragma unroll
+        for (int j = 0; j < SP; ++j)
+            if (j * C::NT + wave_off / 4 < 2 * C::BM)             // wave-uniform (2 BM % 64 == 0)
+                glds4_buf(s_buf, s_src[j], (unsigned)kt * 8u, sc_base + slot * C::SC_BYTES + j * C::NT * 4 + wave_off);
+    }
+    // scale dwords of row `row` of the tile for this lane's k-half: lo = blocks 0..3, hi = blocks 4..7 (bytes 0 / 2 after the shift)
+    LMI_DEV void read(int slot, int row, int fh, int& lo, int& hi) const {
+        const u32x2 d = *(const u32x2*)(sc_base + slot * C::SC_BYTES + row * 8);
+        lo = (int)(d[0] >> (fh * 8));
+        hi = (int)(d[1] >> (fh * 8));
+    }
+};
 
 // XCD-aware, grouped tile order.  Tiles are linearised in groups of `group_m` row-tiles, row-tile fastest, so that 32
 // consecutive ids form a (group_m x 32/group_m)-tile patch whose current k-tiles one XCD's 4 MiB L2 can hold.  Workgroup b runs on XCD
@@ -285,7 +351,7 @@ struct GemmRowScale {
 // the epilogues that may finish a folded RMSNorm (the others never carry the row-scale registers)
 template <int EPI> struct GemmCanScale { static constexpr bool value = (EPI == EPI_STORE_T || EPI == EPI_SWIGLU_T || EPI == EPI_QKV_ROPE_T); };
 
-template <typename T, int EPI, int ACT, typename C, typename Put>
+template <typename T, int EPI, int ACT, typename C, bool OUT4 = false, typename Put>
 LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, int wn, int lane, char* stage, const float* rstd_lds) {
     typedef typename vec_of<T>::x8 T8;
     constexpr int RS = GemmImage<C::WTN>::RS;
@@ -302,7 +368,8 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
     // A row is still covered by 8 consecutive lanes, so stores stay whole 128/256-byte row segments.
     // (not in producer mode: there the 8 lanes of a row sum their squares with a fixed shuffle tree, and the pairing of column
     // groups in that tree must not depend on the row's position — bit-identical partials wherever a row sits in a packed batch)
-    const int oc = ((LPR == 8 && !PAIRED && !(EPI == EPI_RESID_F32 && p.norm_out)) ? ((lane + 7 * ((r_in >> 1) & 1)) & 7) : (lane % LPR)) * 8;
+    // (nor when the residual image of the output is wanted: a 32-column block must sit in one lane quad, below)
+    const int oc = ((LPR == 8 && !PAIRED && !(EPI == EPI_RESID_F32 && p.norm_out) && !(OUT4 && p.out4)) ? ((lane + 7 * ((r_in >> 1) & 1)) & 7) : (lane % LPR)) * 8;
     // source columns of this lane in the image: plain = oc..oc+7; SwiGLU = gate block, up block 32 columns further;
     // RoPE = first-half block, rotate-half partner block 32 columns further
     const int sc = PAIRED ? (oc >> 5) * 64 + (oc & 31) : oc;
@@ -393,6 +460,21 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     o[e] = OutCvt<T>::cvt(fast_silu(g0[e]) * u0[e] * os);
                     o[4 + e] = OutCvt<T>::cvt(fast_silu(g1[e]) * u1[e] * os);
                 }
+                if constexpr (OUT4 && sizeof(T) == 2) {
+                    if (p.out4) {                                    // (wave-uniform) residual image of the products: a row's 4 lanes = one 32-column block
+                        float y[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { y[e] = fast_silu(g0[e]) * u0[e]; y[4 + e] = fast_silu(g1[e]) * u1[e]; }
+                        unsigned sb;
+                        const unsigned codes = lo4_encode8<T>(y, o, sb);
+                        if (m < p.M) {
+                            const long orow4 = p.row_map ? (long)p.row_map[m] : (long)m;
+                            const int col = (nw0 >> 1) + oc;
+                            *(unsigned*)((char*)p.out4 + orow4 * p.ld_out4 + (col >> 1)) = codes;
+                            if ((lane & 3) == 0) p.out4_scale[orow4 * p.ld_out4s + (col >> 5)] = (uint8_t)sb;
+                        }
+                    }
+                }
                 if (m < p.M) {
                     const long orow = p.row_map ? (long)p.row_map[m] : (long)m;
                     if (p.swiglu_f32) {                              // wave-uniform: the unrounded products
@@ -452,7 +534,27 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 for (int e = 0; e < 4; ++e) sq = __builtin_fmaf(v1[it][e], v1[it][e], sq);
                 sq += shfl_xor(sq, 1); sq += shfl_xor(sq, 2); sq += shfl_xor(sq, 4);
             }
+            // residual image of the 16-bit values handed to the next GEMM (every lane takes part in the quad exchange, rows past M included)
+            unsigned codes4 = 0, sb4 = 0;
+            T8 o4;
+            if constexpr (OUT4 && sizeof(T) == 2 && (EPI == EPI_STORE_T || EPI == EPI_RESID_F32)) {
+                if (p.out4 && (EPI == EPI_STORE_T || p.norm_out)) {
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[e] = EPI == EPI_STORE_T ? v0[it][e] : v0[it][e] * gam0[e];
+                        y[4 + e] = EPI == EPI_STORE_T ? v1[it][e] : v1[it][e] * gam1[e];
+                    }
+                    codes4 = lo4_encode8<T>(y, o4, sb4);
+                }
+            }
             if (mb + it * RPI + r_in >= p.M) continue;
+            if constexpr (OUT4 && sizeof(T) == 2 && (EPI == EPI_STORE_T || EPI == EPI_RESID_F32)) {
+                if (p.out4 && (EPI == EPI_STORE_T || p.norm_out)) {
+                    *(unsigned*)((char*)p.out4 + orow[it] * p.ld_out4 + ((nw0 + oc) >> 1)) = codes4;
+                    if ((lane & 3) == 0) p.out4_scale[orow[it] * p.ld_out4s + ((nw0 + oc) >> 5)] = (uint8_t)sb4;
+                }
+            }
             if (EPI == EPI_STORE_T) {
                 T8 o;
                 const float os = (sizeof(T) == 1) ? p.out_scale : 1.0f;
@@ -536,6 +638,24 @@ struct GemmStager {
         lda = p.lda;
         wave_base = smem + wave * 1024;
     }
+    // Low-bit correction phase: from here on the pieces come from the fp4 images (row-major, 128 bytes = 256 k per k-tile and row; plain
+    // A mode).  Called between the last 16-bit piece and the first fp4 piece; pieces already in flight do not depend on these registers.
+    LMI_DEV void switch_lo4(const GemmArgs& p, int m0, int n0, int tid) {
+        a_buf = make_buf(p.A4, p.a4_bytes);
+        w_buf = make_buf(p.W4, p.w4_bytes);
+        const int srow = tid >> 3, pc = tid & 7;
+#pragma unroll
+        for (int ps = 0; ps < C::A_PASSES; ++ps) {
+            const int r = ps * C::ROWS_PER_PASS + srow;
+            a_src[ps] = (unsigned)((long)imin(m0 + r, p.M - 1) * p.lda4 + ((pc ^ ((r >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int ps = 0; ps < C::W_PASSES; ++ps) {
+            const int r = ps * C::ROWS_PER_PASS + srow;
+            w_src[ps] = (unsigned)((long)imin(n0 + r, p.N - 1) * p.ldw4 + ((pc ^ ((r >> 1) & 7)) << 4));
+        }
+        w_kstep = 128u;
+    }
     // one LDS-DMA instruction: piece g (0..G-1) of k-tile kt into ring slot `slot`
     LMI_DEV void issue(int g, int kt, int slot) const {
         char* base = wave_base + slot * C::STAGE_BYTES;
@@ -570,10 +690,11 @@ LMI_DEV void gemm_put32(const f32x16 (&acc)[C::NI][C::MI], int mi, int lane, cha
             *(f32x4*)(stage + fr * RS + (ni * 32 + q * 8 + fh * 4) * 4) = v;
         }
 }
-template <typename T, int EPI, int ACT, int AMODE, typename C, typename TA = T>
+template <typename T, int EPI, int ACT, int AMODE, typename C, typename TA = T, bool LO4 = false>
 __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     typedef typename GemmFrag<TA>::type Frag;
     constexpr int KS = GemmFrag<TA>::KS, ES = (int)sizeof(TA);
+    static_assert(!LO4 || (sizeof(TA) == 2 && AMODE == AMODE_PLAIN), "the low-bit correction phase follows a 16-bit pass over a plain A");
     LMI_DYN_SMEM(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = wave_id();
@@ -585,7 +706,6 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 
     GemmStager<AMODE, C, ES> stager;
     stager.init(p, m0, n0, tid, smem, wave);
-    auto issue_piece = [&](int g, int kt, int slot) { stager.issue(g, kt, slot); };
     float* rstd_lds = (float*)(smem + C::SMEM);
     constexpr bool CAN_SCALE = GemmCanScale<EPI>::value;
     GemmRowScale<C> row_scale;
@@ -603,27 +723,49 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     GemmWOff<TA> w_off;
     w_off.init(p.w_packed, fr, fh);
     const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
+    // LO4: the ring simply continues over the fp4 k-tiles (global tile index tg = nt + u for fp4 tile u); the stager switches sources
+    // when the first fp4 tile is issued, the fragment offsets / MFMA when it is multiplied
+    const int nt_all = LO4 ? nt + p.K4 / 256 : nt;
+    GemmLo4<C> lo4;
+    if constexpr (LO4) lo4.init(p, m0, n0, tid, wave, wn, fr, smem);
+    // VMEM operations per k-tile and thread: G operand pieces (+ the scale pieces of an fp4 tile).  The counted wait of tile t uses the
+    // count of ITS phase: at the phase boundary the 16-bit count is the smaller one, i.e. the wait is at worst early-complete.
+    constexpr int GL = C::G + (LO4 ? GemmLo4<C>::SP : 0);
+    auto issue_tile_piece = [&](int g, int tg, int slot) {
+        if (LO4 && tg >= nt) {
+            if (g == 0) { if (tg == nt) stager.switch_lo4(p, m0, n0, tid); lo4.issue(tg - nt, slot); }
+            stager.issue(g, tg - nt, slot);
+        } else {
+            stager.issue(g, tg, slot);
+        }
+    };
 
     // ---- prologue: D tiles in flight -----------------------------------------------------------------------------
 #pragma unroll
     for (int d = 0; d < C::D; ++d)
-        if (d < nt) {
+        if (d < nt_all) {
 #pragma unroll
-            for (int g = 0; g < C::G; ++g) issue_piece(g, d, d);
+            for (int g = 0; g < C::G; ++g) issue_tile_piece(g, d, d);
         }
 
-    for (int t = 0; t < nt; ++t) {
+    auto k_tile = [&](auto lo_tag, int t) {
+        constexpr bool LO = decltype(lo_tag)::value;
         // tile t has landed once at most the D-1 younger tiles are outstanding (ring tail: everything)
-        if (C::D >= 2 && t + C::D - 1 < nt) wait_vmcnt_barrier<(C::D >= 2 ? C::G * (C::D - 1) : 0)>();
+        if (C::D >= 2 && t + C::D - 1 < nt_all) wait_vmcnt_barrier<(C::D >= 2 ? (LO ? GL : C::G) * (C::D - 1) : 0)>();
         else wait_vmcnt_barrier<0>();
         const int slot = t % C::STAGES;
         const char* a_t = smem + slot * C::STAGE_BYTES;
         const char* w_t = a_t + C::A_BYTES;
         const int t_issue = t + C::D;                                // k-tile whose loads are issued under this tile
-        const bool do_issue = t_issue < nt;
+        const bool do_issue = t_issue < nt_all;
         const int slot_issue = t_issue % C::STAGES;                  // == slot of tile t-1: free since the barrier
+        int sc_lo[C::MI], sc_hi[C::MI];
+        if constexpr (LO) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+            for (int i = 0; i < C::MI; ++i) lo4.read(slot, wm * C::WTM + i * 32 + fr, fh, sc_lo[i], sc_hi[i]);
+        }
+        static_for<KS>([&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
             Frag af[C::MI], wf[C::NI];
 #pragma unroll
             for (int i = 0; i < C::MI; ++i) af[i] = gemm_frag_load<TA>(a_t, wm * C::WTM + i * 32 + fr, ks, fh);
@@ -631,18 +773,29 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
             for (int i = 0; i < C::NI; ++i) wf[i] = gemm_wfrag_load<TA>(w_t, wn * C::WTN + i * 32, fr, ks, fh, w_off);
             if (do_issue) {
 #pragma unroll
-                for (int g = ks * C::G / KS; g < (ks + 1) * C::G / KS; ++g) issue_piece(g, t_issue, slot_issue);
+                for (int g = ks * C::G / KS; g < (ks + 1) * C::G / KS; ++g) issue_tile_piece(g, t_issue, slot_issue);
             }
 #pragma unroll
             for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < C::MI; ++mi) acc[ni][mi] = gemm_mma(wf[ni], af[mi], acc[ni][mi], p.scale_e8m0);
-        }
+                for (int mi = 0; mi < C::MI; ++mi) {
+                    if constexpr (LO)
+                        acc[ni][mi] = mfma32_fp4<0, (ks & 1) * 2>(frag_bits(wf[ni]), frag_bits(af[mi]), acc[ni][mi],
+                                                                 lo4.w_sc[ni], ks < 2 ? sc_lo[mi] : sc_hi[mi]);
+                    else
+                        acc[ni][mi] = gemm_mma(wf[ni], af[mi], acc[ni][mi], p.scale_e8m0);
+                }
+        });
+    };
+    for (int t = 0; t < nt; ++t) k_tile(std::false_type{}, t);
+    if constexpr (LO4) {
+        w_off.init(0, fr, fh);                                       // the fp4 weight image is row-major
+        for (int t = nt; t < nt_all; ++t) k_tile(std::true_type{}, t);
     }
 
     if (CAN_SCALE && p.rowsq_in) row_scale.finish(p, tid, rstd_lds);   // published by the barrier below
     raw_barrier();                                                 // every wave is done reading k-tiles: LDS is free
-    gemm_epilogue<T, EPI, ACT, C>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
+    gemm_epilogue<T, EPI, ACT, C, LO4>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
                                   smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds);
 }
 
@@ -667,9 +820,10 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
 // are short of, not L2 hit rate), of the successor workgroup's first k-tiles (+0.4 %), of the residual epilogue's rows (+0.3 %);
 // a strip-major tile order that lets all XCDs share one W strip (+0.4 %).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR, typename TA = T>
+template <typename T, int EPI, int ACT, int AMODE, typename C, int VAR, typename TA = T, bool LO4 = false>
 __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     static_assert(C::STAGES == 2 && C::NT == 512, "staggered schedule: 8 waves, 2-slot ring");
+    static_assert(!LO4 || (sizeof(TA) == 2 && AMODE == AMODE_PLAIN && VAR == 0), "the low-bit correction phase follows a 16-bit pass over a plain A");
     typedef typename GemmFrag<TA>::type Frag;
     // fp8: 2 k-steps of 64 per k-tile (8 MFMAs of 64 cycles each per MFMA segment); all DMA pieces of the next tile go out in
     // k-step 0's LOAD segment and are drained in k-step 1's: one MFMA segment of flight, as the 16-bit schedule has two of half the length
@@ -704,6 +858,8 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     GemmWOff<TA> w_off;
     w_off.init(p.w_packed, fr, fh);
     const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
+    GemmLo4<C> lo4;
+    if constexpr (LO4) lo4.init(p, m0, n0, tid, wave, wn, fr, smem);
 #pragma unroll
     for (int g = 0; g < C::G; ++g) issue_piece(g, 0, 0);
     constexpr bool TWO = (VAR == 0);                                // two-k-tile prologue
@@ -722,14 +878,18 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     const int rows_left = p.M - (m0 + wm * C::WTM);
     int nmi = rows_left >= C::WTM ? C::MI : (rows_left <= 0 ? 0 : (rows_left + 31) >> 5);
     if (n0 + wn * C::WTN >= p.N) nmi = 0;              // this wave's columns are all past N (masked on store anyway)
-    // ISSUE (a next k-tile exists) and FULL (no padding blocks) are compile-time: a runtime test per LDS-DMA piece or per
-    // MFMA would cut the MFMA segment into scheduling regions with a branch each
-    auto tile = [&](auto issue_tag, auto full_tag, int t) {
-        constexpr bool ISSUE = decltype(issue_tag)::value, FULL = decltype(full_tag)::value;
-        const char* a_t = smem + (t & 1) * C::STAGE_BYTES;
+    // ISSUE (0 = nothing, 1 = the operand pieces of the next k-tile, 2 = those + the block-scale pieces of an fp4 k-tile), FULL (no
+    // padding blocks) and LO (an fp4 k-tile of the correction phase) are compile-time: a runtime test per LDS-DMA piece or per MFMA
+    // would cut the MFMA segment into scheduling regions with a branch each.  `tg` = global k-tile index (slot tg & 1), `kt_next` =
+    // index of the next k-tile inside ITS phase.
+    auto tile = [&](auto issue_tag, auto full_tag, auto lo_tag, int tg, int kt_next) {
+        constexpr int ISSUE = decltype(issue_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value, LO = decltype(lo_tag)::value;
+        const char* a_t = smem + (tg & 1) * C::STAGE_BYTES;
         const char* w_t = a_t + C::A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        int sc_lo[C::MI], sc_hi[C::MI];
+        static_for<KS>([&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
             // ---- LOAD segment ---------------------------------------------------------------------------------
             Frag af[C::MI], wf[C::NI];
 #pragma unroll
@@ -738,9 +898,15 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < C::NI; ++i)
                 if (FULL || nmi > 0) wf[i] = gemm_wfrag_load<TA>(w_t, wn * C::WTN + i * 32, fr, ks, fh, w_off);
+            if constexpr (LO && ks == 0) {
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)
+                    if (FULL || i < nmi) lo4.read(tg & 1, wm * C::WTM + i * 32 + fr, fh, sc_lo[i], sc_hi[i]);
+            }
             if (ks < KS_ISSUE && ISSUE) {
 #pragma unroll
-                for (int g = ks * C::G / KS_ISSUE; g < (ks + 1) * C::G / KS_ISSUE; ++g) issue_piece(g, t + 1, (t + 1) & 1);
+                for (int g = ks * C::G / KS_ISSUE; g < (ks + 1) * C::G / KS_ISSUE; ++g) issue_piece(g, kt_next, (tg + 1) & 1);
+                if constexpr (LO4 && ISSUE == 2 && ks == 0) lo4.issue(kt_next, (tg + 1) & 1);
             }
             if (ks == KS - 1) wait_vmcnt_barrier<0>(); else raw_barrier();
             // ---- MFMA segment ---------------------------------------------------------------------------------
@@ -750,20 +916,42 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
             for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < C::MI; ++mi)
-                    if (FULL || mi < nmi) acc[ni][mi] = gemm_mma(wf[ni], af[mi], acc[ni][mi], p.scale_e8m0);
+                    if (FULL || mi < nmi) {
+                        if constexpr (LO)
+                            acc[ni][mi] = mfma32_fp4<0, (ks & 1) * 2>(frag_bits(wf[ni]), frag_bits(af[mi]), acc[ni][mi],
+                                                                     lo4.w_sc[ni], ks < 2 ? sc_lo[mi] : sc_hi[mi]);
+                        else
+                            acc[ni][mi] = gemm_mma(wf[ni], af[mi], acc[ni][mi], p.scale_e8m0);
+                    }
             setprio_lo();
             sched_fence();
             raw_barrier();
-        }
+        });
     };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
     auto run = [&](auto full_tag) {
-        if (TWO && nt > 1) {
-            tile(std::false_type{}, full_tag, 0);                  // k-tile 1 is already in flight; its pieces drain in k-step 3 as usual
-            for (int t = 1; t + 1 < nt; ++t) tile(std::true_type{}, full_tag, t);
-            tile(std::false_type{}, full_tag, nt - 1);
+        const std::false_type hi{};
+        if constexpr (LO4) {
+            // 16-bit tiles 0 .. nt-1 (nt >= 2, checked by the launcher), then fp4 tiles 0 .. n4-1 in the same ring: the last 16-bit tile
+            // issues fp4 tile 0 (its operand pieces were issued under tile nt-2 and drained there, so the stager may switch sources)
+            const int n4 = p.K4 / 256;
+            tile(I0{}, full_tag, hi, 0, 0);
+            for (int t = 1; t + 1 < nt; ++t) tile(I1{}, full_tag, hi, t, t + 1);
+            stager.switch_lo4(p, m0, n0, tid);
+            tile(I2{}, full_tag, hi, nt - 1, 0);
+            w_off.init(0, fr, fh);                                 // the fp4 weight image is row-major
+            const std::true_type lo{};
+            for (int u = 0; u + 1 < n4; ++u) tile(I2{}, full_tag, lo, nt + u, u + 1);
+            tile(I0{}, full_tag, lo, nt + n4 - 1, 0);
+        } else if (TWO && nt > 1) {
+            tile(I0{}, full_tag, hi, 0, 0);                        // k-tile 1 is already in flight; its pieces drain in k-step 3 as usual
+            for (int t = 1; t + 1 < nt; ++t) tile(I1{}, full_tag, hi, t, t + 1);
+            tile(I0{}, full_tag, hi, nt - 1, 0);
         } else {
-            for (int t = 0; t + 1 < nt; ++t) tile(std::true_type{}, full_tag, t);
-            tile(std::false_type{}, full_tag, nt - 1);
+            for (int t = 0; t + 1 < nt; ++t) tile(I1{}, full_tag, hi, t, t + 1);
+            tile(I0{}, full_tag, hi, nt - 1, 0);
         }
     };
     if (nmi == C::MI) run(std::true_type{}); else run(std::false_type{});
@@ -773,7 +961,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
         raw_barrier();
     }
     // past its last barrier a wave knows that every other wave has finished its last LOAD segment: LDS is free
-    gemm_epilogue<T, EPI, ACT, C>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
+    gemm_epilogue<T, EPI, ACT, C, LO4>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
                                   smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds);
 }
 

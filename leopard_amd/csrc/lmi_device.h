@@ -86,6 +86,10 @@ LMI_DEV void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, vo
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset,
                                              (int)soffset, 0, AUX);
 }
+// the 4-byte form (LDS destination = lds_wave_base + lane*4): the block scales of the low-bit correction phase
+LMI_DEV void glds4_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, (int)voffset, (int)soffset, 0, 0);
+}
 
 // D[32x32] += A[32x64] * B[64x32] on fp8 e4m3 operands at twice the 16-bit MFMA rate (v_mfma_scale_f32_32x32x64_f8f6f4; the
 // unscaled fp8 MFMA runs at the 16-bit rate).  Lane l supplies A[l&31][32*(l>>5) + j] and B[32*(l>>5) + j][l&31], j = 0..31
@@ -99,6 +103,27 @@ LMI_DEV uint8_t to_fp8(float x) {
     x = fminf(fmaxf(x, -448.0f), 448.0f);
     return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff);
 }
+// D[32x32] += A[32x64] * B[64x32] on fp4 e2m1 operands with MX block scales, at FOUR times the 16-bit MFMA rate (the low-bit correction
+// phase of gemm.h).  Lane l supplies A[l&31][32*(l>>5) + j] and B[32*(l>>5) + j][l&31], j = 0..31, as 16 bytes (element j in nibble j & 1 of
+// byte j >> 1, even element low; layout and scale semantics pinned by tools/ubench/mfma_fp4_layout.hip), and ONE E8M0 scale per operand for
+// its 32 elements — i.e. per (row, 32-k block): byte SEL_A of `scale_a` / byte SEL_B of `scale_b`.
+template <int SEL_A, int SEL_B>
+LMI_DEV f32x16 mfma32_fp4(u32x4 a, u32x4 b, f32x16 c, int scale_a, int scale_b) {
+    const v8i av = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0}, bv = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, SEL_A, scale_a, SEL_B, scale_b);
+}
+// max over the 4 lanes of a lane quad (lanes 4q .. 4q+3), DPP quad permutes: no LDS traffic
+LMI_DEV float quad_max(float v) {
+    int x = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));      // quad_perm [1,0,3,2]
+    x = __builtin_bit_cast(int, v);
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+}
+// lane 4q + i of a quad receives `v` of lane 4q + SRC
+template <int SRC> LMI_DEV unsigned quad_bcast(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, SRC * 0x55, 0xF, 0xF, false);
+}
+
 
 LMI_DEV void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 // this wave's LDS writes have completed (before a raw s_barrier that publishes them to the other waves)
@@ -257,6 +282,35 @@ inline f32x16 mfma32_fp8(v8i a, v8i b, f32x16 c, int scale_b) {
     hipemu::wave_sync();
     return c;
 }
+inline float emu_fp4_decode(unsigned code) {
+    static const float g[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+    return (code & 8) ? -g[code & 7] : g[code & 7];
+}
+template <int SEL_A, int SEL_B>
+inline f32x16 mfma32_fp4(u32x4 a, u32x4 b, f32x16 c, int scale_a, int scale_b) {
+    struct Slot { uint8_t a[16], b[16]; int sa, sb; };
+    Slot* s = (Slot*)hipemu::wave_buf();
+    const int l = lane_id();
+    __builtin_memcpy(s[l].a, &a, 16);
+    __builtin_memcpy(s[l].b, &b, 16);
+    s[l].sa = (scale_a >> (8 * SEL_A)) & 255;
+    s[l].sb = (scale_b >> (8 * SEL_B)) & 255;
+    hipemu::wave_sync();
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float tot = 0.f;
+        for (int kb = 0; kb < 2; ++kb) {
+            const Slot &sa = s[row + 32 * kb], &sb = s[col + 32 * kb];
+            float acc = 0.f;
+            for (int j = 0; j < 32; ++j)
+                acc += emu_fp4_decode((sa.a[j >> 1] >> (4 * (j & 1))) & 15) * emu_fp4_decode((sb.b[j >> 1] >> (4 * (j & 1))) & 15);
+            tot += acc * ldexpf(1.0f, sa.sa - 127) * ldexpf(1.0f, sb.sb - 127);
+        }
+        c[r] += tot;
+    }
+    hipemu::wave_sync();
+    return c;
+}
 inline void raw_barrier() { __syncthreads(); }
 inline void lds_write_drain() {}
 inline void wave_lds_fence() { hipemu::wave_sync(); }
@@ -311,6 +365,13 @@ inline void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, voi
     else __builtin_memset(dst, 0, 16);
 }
 
+inline void glds4_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
+    char* dst = (char*)lds_wave_base + lane_id() * 4;
+    const unsigned long off = (unsigned long)voffset + soffset;
+    if (off + 4 <= b.num_records) __builtin_memcpy(dst, b.base + off, 4);
+    else __builtin_memset(dst, 0, 4);
+}
+
 inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {
     struct Slot { uint16_t e[4]; };
     Slot* s = (Slot*)hipemu::wave_buf();
@@ -363,6 +424,11 @@ inline void swap_hi_lo(unsigned& a, unsigned& b) {
     const unsigned ta = (unsigned)emu_shfl_idx((int)a, lane_id() ^ 32), tb = (unsigned)emu_shfl_idx((int)b, lane_id() ^ 32);
     if (lane_id() < 32) b = ta; else a = tb;
 }
+inline float quad_max(float v) {
+    v = fmaxf(v, emu_shfl_idx(v, lane_id() ^ 1));
+    return fmaxf(v, emu_shfl_idx(v, lane_id() ^ 2));
+}
+template <int SRC> inline unsigned quad_bcast(unsigned v) { return (unsigned)emu_shfl_idx((int)v, (lane_id() & ~3) | SRC); }
 inline void lmi_trap() { __builtin_trap(); }
 inline bool wave_any(bool p) {
     int v = p ? 1 : 0;
@@ -420,6 +486,46 @@ template <int BIT, typename V> LMI_DEV V ld_epi(const V* p) {
 #endif
     return *p;
 }
+// ---- fp4 e2m1 (the low-bit correction operands) ------------------------------------------------------------------------------------------
+// |x| on the grid {0, .5, 1, 1.5, 2, 3, 4, 6} (codes 0..7), sign in bit 3; round to nearest, ties to the even code, saturating at 6.
+// Software on purpose: the same bits on the device and in the host emulator (the hardware conversion v_cvt_scalef32_pk_fp4_f32 is
+// compared with it by tools/ubench/mfma_fp4_layout.hip); a few VALU operations per element in epilogues that are HBM- or latency-bound.
+LMI_DEV unsigned to_fp4(float x) {
+    const unsigned s = (__builtin_bit_cast(unsigned, x) >> 28) & 8u;
+    const float a = fminf(__builtin_fabsf(x), 6.0f);
+    // units of the binade's grid step: < 2 -> halves, < 4 -> ones, else twos; rintf = round half to even, and an even count is an even code
+    const float q = a < 2.0f ? __builtin_rintf(a * 2.0f) : (a < 4.0f ? 2.0f + __builtin_rintf(a) : 4.0f + __builtin_rintf(a * 0.5f));
+    return s | (unsigned)(int)q;
+}
+// MX block scale of a block whose largest magnitude is `amax`: E8M0 byte of 2^(floor(log2 amax) - 2) (the block maximum lands in [4, 8):
+// values above 6 saturate), and the exact reciprocal of that power of two.  amax = 0 (or a denormal): byte 0 and inv 0 — every code is 0.
+LMI_DEV unsigned lo4_scale_byte(float amax, float& inv) {
+    const int eb = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u) - 2;
+    if (eb < 1) { inv = 0.f; return 0u; }
+    inv = __builtin_bit_cast(float, (unsigned)(254 - eb) << 23);
+    return (unsigned)eb;
+}
+// One lane's share of a low-bit residual image: y[0..7] are 8 consecutive fp32 values of a row, the 4 lanes of a lane quad hold one
+// 32-element block.  Returns the 8 codes of the lane (element e in nibble e) for the residuals y - float(T(y)) and, in every lane of the
+// quad, the block's E8M0 scale byte.  hi[e] = T(y[e]) is what the 16-bit pass multiplies.
+template <typename T>
+LMI_DEV unsigned lo4_encode8(const float (&y)[8], typename vec_of<T>::x8& hi, unsigned& scale_byte) {
+    float lo[8], amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (T)y[e];
+        lo[e] = y[e] - (float)hi[e];
+        amax = fmaxf(amax, __builtin_fabsf(lo[e]));
+    }
+    amax = quad_max(amax);
+    float inv;
+    scale_byte = lo4_scale_byte(amax, inv);
+    unsigned codes = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) codes |= to_fp4(lo[e] * inv) << (4 * e);
+    return codes;
+}
+
 LMI_DEV int imin(int a, int b) { return a < b ? a : b; }
 LMI_DEV int imax(int a, int b) { return a > b ? a : b; }
 template <typename T> LMI_DEV float to_f32(T v) { return (float)v; }

@@ -116,7 +116,7 @@ class LeopardEngine:
         # all-gather of the projected visual tokens: None = fp32 (bit-identical to one rank: the rows are merged into the fp32 residual stream,
         # which carries them unrounded through every layer); the 16-bit compute type halves the bytes (58 MB at C3) at one extra rounding
         self._comm_stream = None
-        self._workspaces: Dict[str, torch.Tensor] = {}   # caller-owned scratch per stage (lmi_llm_prefill_workspace_bytes / lmi_vit_workspace_bytes)
+        self._workspaces: Dict[tuple, torch.Tensor] = {}   # caller-owned scratch per (stage, launch stream) (lmi_llm_prefill_workspace_bytes / lmi_vit_workspace_bytes)
         self.graph_encode = False      # capture the vision encode per ViT-input count in a HIP graph (BASELINE config 5)
         self._encode_graphs: Dict[tuple, tuple] = {}   # (ViT-input count, stream) -> (graph, static in, static out)
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
@@ -126,6 +126,13 @@ class LeopardEngine:
         # 16-bit values (lmi_split_hi_lo) and multiplied against [W | W] — the GEMMs run at 2 K, the hand-over roundings that make up the
         # distance to the fp32 reference are gone (full-depth logits within north_star's 1e-3; ~1.8x the prefill time).  Prefill only.
         self.split_operands = False
+        # Low-bit correction mode (round 5): the same goal at + 25 % matrix time instead of + 100 %.  Every producer of a layer-
+        # linear A operand also hands over an MX fp4 image of the rounding residual x - T(x) (lmi_norm_lo4, lmi_split_lo4, the GELU / SwiGLU /
+        # folded-norm GEMM epilogues), every layer linear has an fp4 weight image (+ 0.5 B per parameter), and the GEMMs run a second k-loop
+        # phase of v_mfma_scale_f32_32x32x64_f8f6f4 on the two images into the accumulators of the 16-bit pass (lmi_gemm_lo4).  Prefill only;
+        # one rank.  ``precision`` = "fast" | "lo4" | "split" selects between the three schedules.
+        self.lo4 = False
+        self._lo4_w = None
         self.skinny_fold_norm = True   # batched decode: RMSNorms folded into the projections (lmi_gemm_skinny_ex producer / consumer); False: norm launches
         self.skinny_packed = True      # batched decode over nn.Linear-layout weights (TP, pack_llm_weights=False): stream a packed second copy
         self.fp8_fused = True          # fp8 schedule: attention writes the fp8 o_proj operand, q|k|v GEMM does RoPE + KV append (False: separate launches)
@@ -156,6 +163,21 @@ class LeopardEngine:
     @property
     def tp_size(self) -> int:
         return getattr(self.W, "tp_size", 1)
+
+    @property
+    def precision(self) -> str:
+        """"fast" (one rounding per operand hand-over: the benchmarked schedule up to round 4), "lo4" (+ the fp4 correction phase: meets
+        north_star's 1e-3 at full depth), "split" (hi + lo 16-bit operand pairs at 2 K: the most exact, ~1.9 x the time)."""
+        return "split" if self.split_operands else ("lo4" if self.lo4 else "fast")
+
+    @precision.setter
+    def precision(self, mode: str):
+        if mode not in ("fast", "lo4", "split"):
+            raise ValueError(f"precision must be 'fast', 'lo4' or 'split', not {mode!r}")
+        if mode != "fast" and self.tp_size > 1:
+            raise ValueError("the precision modes run on one rank (tensor-parallel engines keep the fast schedule)")
+        self.split_operands, self.lo4 = mode == "split", mode == "lo4"
+        self._encode_graphs.clear()                           # captured encodes replay the launches of the old schedule
 
     def _llm_heads(self) -> Tuple[int, int]:
         """(query heads, kv heads) this rank computes."""
@@ -258,13 +280,21 @@ class LeopardEngine:
 
     def _carve(self, which: str, total: int, offsets, specs):
         """Views into the engine's caller-owned workspace of stage ``which`` ("llm" / "vit"; SURVEY.md 8b: sized by the library's
-        lmi_*_workspace_bytes, owned by the caller): ONE uint8 allocation per stage, grown when a larger pass arrives and reused by every
-        later one, carved at the byte offsets the library returned.  specs: [(rows, cols, dtype)] in LMI_WS_* order."""
-        ws = self._workspaces.get(which)
+        lmi_*_workspace_bytes, owned by the caller): ONE uint8 allocation per stage AND LAUNCH STREAM, grown when a larger pass arrives and
+        reused by every later one on that stream, carved at the byte offsets the library returned.  specs: [(rows, cols, dtype)] in LMI_WS_*
+        order.  Per stream because passes on different HIP streams are not ordered against each other (bench.py --inflight > 1, a graph
+        capture beside eager work): they must not share scratch.  A workspace is allocated while its stream is current, so the caching
+        allocator's own stream bookkeeping covers its release."""
+        sid = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        key = (which, sid)
+        ws = self._workspaces.get(key)
         if ws is None or ws.numel() < total:
-            ws = self._workspaces[which] = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
-            if which == "vit":
-                self._encode_graphs.clear()                         # graphs captured over the old workspace point into freed memory
+            if ws is None and len(self._workspaces) >= 16:              # streams come and go (graph captures): bound the table
+                self._workspaces.pop(next(iter(self._workspaces)))
+            ws = self._workspaces[key] = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
+            if which == "vit":                                          # graphs captured on this stream point into the old workspace
+                for k in [k for k in self._encode_graphs if k[1] == sid]:
+                    self._encode_graphs.pop(k)
         out = []
         for off, (r, c, dt) in zip(offsets, specs):
             nbytes = r * c * torch.empty(0, dtype=dt).element_size()
@@ -324,6 +354,8 @@ class LeopardEngine:
             return self._vit_layers_fp8(x, n)
         if self.split_operands:
             return self._vit_layers_split(x, n)
+        if self.lo4:
+            return self._vit_layers_lo4(x, n)
         qkv_w = W.vit_layers[0].qkv_w.shape[0] if W.vit_layers else 3 * D
         total, offs = ops.vit_workspace(M, D, qkv_w, W.vit_ff, self.dtype)
         h, qkv, att, ff = self._carve("vit", total, offs, [(M, D, self.dtype), (M, qkv_w, self.dtype), (M, D, self.dtype), (M, W.vit_ff, self.dtype)])
@@ -344,8 +376,9 @@ class LeopardEngine:
             ops.gemm(ff, L.fc2_w, x, bias=L.fc2_b, epilogue=_lib.EPI_RESIDUAL)
             if self.trace:
                 self.trace(f"vit.{li}", x)
-        ops.layernorm(x, W.post_ln_w, W.post_ln_b, h, vc.layer_norm_eps)
-        return h
+        out = self._empty(M, D)                 # a result, not scratch: the caller may hold it across later passes that reuse the workspace
+        ops.layernorm(x, W.post_ln_w, W.post_ln_b, out, vc.layer_norm_eps)
+        return out
 
     def _vit_layers_fp8(self, x: torch.Tensor, n: int) -> torch.Tensor:
         """The SigLIP layers with fp8 linears (leopard_amd.fp8): LayerNorm -> fp8 operand in one launch, fc1's GELU epilogue
@@ -459,6 +492,85 @@ class LeopardEngine:
             if self.trace:
                 self.trace(f"llm.{i}", x)
 
+    # ---- low-bit correction mode --------------------------------------------------------------------------------------------------------
+    def _lo4_weights(self):
+        """fp4 images (+ one E8M0 scale per row) of the layer-linear weights, built on first use from the row-major order of each weight:
+        + 0.5 B per parameter (0.2 GB SigLIP + 3.5 GB Llama-3.1-8B)."""
+        lw = self._lo4_w
+        if lw is None:
+            from .weights import as_row_major
+            q = lambda w: self.ops.quantize_w4(as_row_major(w).contiguous())
+            W = self.W
+            lw = self._lo4_w = {
+                "vit": [(q(L.qkv_w), q(L.o_w), q(L.fc1_w), q(L.fc2_w)) for L in W.vit_layers],
+                "llm": [(q(L.qkv_w_rope if L.qkv_w_rope is not None else L.qkv_w), q(L.o_w), q(L.gu_w), q(L.down_w)) for L in W.llm_layers]}
+        return lw
+
+    def _lo4_act(self, rows: int, width: int):
+        from .ops import Lo4Act
+        return Lo4Act.empty(rows, width, self.dtype, self.device)
+
+    def _vit_layers_lo4(self, x: torch.Tensor, n: int) -> torch.Tensor:
+        """The SigLIP layers with the low-bit correction phase: the LayerNorms and fc1's GELU epilogue hand over T(y) + the fp4 image of
+        y - T(y) directly; the attention hands over fp32, split by lmi_split_lo4.  q / k / v and the attention arithmetic stay 16-bit."""
+        ops, W, vc = self.ops, self.W, self.cfg.vision_config
+        T, D, H, hd = vc.num_patches, vc.hidden_size, vc.num_attention_heads, vc.head_dim
+        M = n * T
+        h, att, ff = self._lo4_act(M, D), self._lo4_act(M, D), self._lo4_act(M, W.vit_ff)
+        a32 = self._empty(M, D, dtype=torch.float32)
+        qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0])
+        cu = self._vit_cu_cache[n]
+        scale = hd ** -0.5
+        for li, (L, (qkv4, o4, fc14, fc24)) in enumerate(zip(W.vit_layers, self._lo4_weights()["vit"])):
+            ops.norm_lo4(x, L.ln1_w, L.ln1_b, h, vc.layer_norm_eps)
+            ops.gemm_lo4(h, L.qkv_w, qkv4, qkv, bias=L.qkv_b)
+            ops.attention_f32out(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a32, cu, cu, T, H, H, hd, scale, False)
+            ops.split_lo4(a32, att)
+            ops.gemm_lo4(att, L.o_w, o4, x, bias=L.o_b, epilogue=_lib.EPI_RESIDUAL)
+            ops.norm_lo4(x, L.ln2_w, L.ln2_b, h, vc.layer_norm_eps)
+            ops.gemm_lo4(h, L.fc1_w, fc14, ff.hi, bias=L.fc1_b, act=_lib.ACT_GELU_TANH, out4=ff)
+            ops.gemm_lo4(ff, L.fc2_w, fc24, x, bias=L.fc2_b, epilogue=_lib.EPI_RESIDUAL)
+            if self.trace:
+                self.trace(f"vit.{li}", x)
+        out = self._empty(M, D)
+        ops.layernorm(x, W.post_ln_w, W.post_ln_b, out, vc.layer_norm_eps)
+        return out
+
+    def _llm_layers_lo4(self, x, cache, cu, cos, sin, max_len):
+        """The Llama / Mistral layers with the low-bit correction phase, on the FUSED schedule of the fast path: the RMSNorms ride in the GEMM
+        epilogues (the producers o_proj / down_proj also write the fp4 image of the residual of T(x gamma)), q|k|v + RoPE + KV append is one
+        launch, gate/up's SwiGLU epilogue writes down_proj's operand pair; only the attention output takes a launch of its own."""
+        ops, W, tc = self.ops, self.W, self.cfg.text_config
+        S, D = x.shape
+        (H, KV), hd = self._llm_heads(), tc.head_dim
+        qw, kw = H * hd, KV * hd
+        if not (hd == 128 and D % 256 == 0 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None):
+            raise RuntimeError("precision 'lo4' needs head_dim 128 and the rope-ordered q|k|v weights (the fused Llama / Mistral schedule)")
+        h, att, gu = self._lo4_act(S, D), self._lo4_act(S, qw), self._lo4_act(S, W.llm_ff)
+        a32 = self._empty(S, qw, dtype=torch.float32)
+        qkv = self._empty(S, qw + 2 * kw)
+        parts = (D + 63) // 64
+        sq_a, sq_b = self._empty(S, parts, dtype=torch.float32), self._empty(S, parts, dtype=torch.float32)
+        scale = hd ** -0.5
+        n_layers = len(W.llm_layers)
+        for i, (L, (qkv4, o4, gu4, down4)) in enumerate(zip(W.llm_layers, self._lo4_weights()["llm"])):
+            if i == 0:
+                ops.norm_lo4(x, L.in_norm, None, h, tc.rms_norm_eps)
+            ops.rmsnorm_rope_lo4(h, L.qkv_w_rope, qkv4, qkv, None if i == 0 else sq_b, tc.rms_norm_eps, cos, sin,
+                                 cache.k[i] if cache else None, cache.v[i] if cache else None, 0, H, KV, hd)
+            ops.attention_f32out(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], a32, cu, cu, max_len, H, KV, hd, scale, True,
+                                 window=tc.sliding_window or 0)
+            ops.split_lo4(a32, att)
+            ops.gemm_lo4(att, L.o_w, o4, x, epilogue=_lib.EPI_RESIDUAL, norm_out=h.hi, norm_gamma=L.post_norm, rowsq_out=sq_a, out4=h)
+            ops.gemm_lo4(h, L.gu_w, gu4, gu.hi, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq_a, norm_dim=D, norm_eps=tc.rms_norm_eps, out4=gu)
+            if i + 1 < n_layers:
+                ops.gemm_lo4(gu, L.down_w, down4, x, epilogue=_lib.EPI_RESIDUAL, norm_out=h.hi, norm_gamma=W.llm_layers[i + 1].in_norm,
+                             rowsq_out=sq_b, out4=h)
+            else:
+                ops.gemm_lo4(gu, L.down_w, down4, x, epilogue=_lib.EPI_RESIDUAL)
+            if self.trace:
+                self.trace(f"llm.{i}", x)
+
     def enable_fp8(self, calibration_samples, headroom: float = 2.0):
         """Switch the ViT / LLM layer linears to fp8 operands (BASELINE configs[4]): quantise the weights once, take the static
         activation scales from a 16-bit prefill of ``calibration_samples`` [(input_ids, tiles)].  ``engine.fp8 = None`` reverts."""
@@ -554,9 +666,11 @@ class LeopardEngine:
         max_len = max(int(l) for l in seq_lens)
         if self.trace:
             self.trace("llm.embed", x)
-        if self.fp8 is not None or (self.split_operands and self.tp_size == 1):
+        if self.fp8 is not None or ((self.split_operands or self.lo4) and self.tp_size == 1):
             if self.fp8 is not None:
                 self._llm_layers_fp8(x, cache, cu, cos, sin, max_len, seq_lens)
+            elif self.lo4:
+                self._llm_layers_lo4(x, cache, cu, cos, sin, max_len)
             else:
                 self._llm_layers_split(x, cache, cu, cos, sin, max_len)
             if cache is not None:
@@ -710,7 +824,7 @@ class LeopardEngine:
             if keep_parts:
                 vit = self.vision_tower(tiles)
                 visual_tokens = self.project(vit, n_tiles)
-                parts["vit"] = vit.clone()                       # (the tower's output is a view of the reused "vit" workspace)
+                parts["vit"] = vit
             else:
                 visual_tokens = self.encode_images(tiles)
         elif visual_tokens is not None:
@@ -1314,7 +1428,7 @@ class LeopardEngine:
         B = max(1, min(int(batch_size), self.MAX_DECODE_BATCH, len(samples)))
         eos = [int(e) for e in eos_token_id]
         if B == 1 or not self._batch_decode_supported() or len(eos) > self.MAX_EOS:
-            return [self.generate(ids, t, max_new_tokens, eos) for ids, t in samples]
+            return [self.generate(ids, t() if callable(t) else t, max_new_tokens, eos) for ids, t in samples]
         tpt = self.cfg.tokens_per_tile
         def merged_len(ids):
             return ids.shape[-1] + int((ids == self.cfg.image_token_index).sum()) * (tpt - 1)
@@ -1338,6 +1452,8 @@ class LeopardEngine:
             while pending:
                 i = pending.pop(0)
                 ids, tiles = samples[i]
+                if callable(tiles):                                   # lazy pixels: prepared when the sample is admitted, dropped after its prefill
+                    tiles = tiles()
                 S = merged_len(ids)
                 if scratch is None or scratch.capacity < S:
                     scratch = self._stream_cache = KVCache(self.cfg, (S + 1023) // 1024 * 1024, self.dtype, self.device)

@@ -125,6 +125,26 @@ def prepare_sample(record: dict, setting: str, open_image: Optional[Callable] = 
     return PreparedSample(prompt, question, vit_inputs, real, n_tok)
 
 
+def plan_record(record: dict, setting: str, tokenizer, open_image: Optional[Callable] = None):
+    """What a record needs BEFORE its pixels: (question for the result row, number of ViT inputs, prompt token ids).  Image files are opened
+    for their sizes only (PIL reads the header; nothing is decoded), the tile counts come from the integer plan (leopard_amd.tiler.plan_sample
+    == what cutting the tiles would give, EVAL:386-401), the prompt from build_prompt (EVAL:408-442)."""
+    from PIL import Image
+    from .tiler import plan_sample
+    sizes = []
+    for p in record["images_path"]:
+        im = open_image(p) if open_image else Image.open(p)
+        sizes.append(im.size)
+        if open_image is None:
+            im.close()
+    budget = SAMPLE_BUDGET - len(sizes)
+    real = [1] * len(sizes) if budget <= 0 else plan_sample(sizes).tiles_per_image                                  # sic (EVAL:400-401)
+    prompt, question, _ = build_prompt(record["question"], len(sizes), real, setting, record["ques_type"])
+    n_vit = len(sizes) if budget <= 0 else len(sizes) + sum(real)
+    enc = tokenizer([prompt], return_tensors="pt", truncation=True, max_length=MAX_PROMPT_TOKENS)["input_ids"]
+    return question, n_vit, enc
+
+
 def generate_kwargs(pad_token_id) -> dict:
     """EVAL:448-452."""
     return {"pad_token_id": pad_token_id, "eos_token_id": list(EOS_IDS), "max_new_tokens": MAX_NEW_TOKENS, "use_cache": True}
@@ -172,14 +192,19 @@ def run_inference(records: List[dict], model, tokenizer, setting: str = "direct"
 
     if batch_size > 1 and hasattr(model, "generate_stream"):
         # continuous batching: batch_size decode slots over ALL records — a slot freed by a finished record takes the next one at once
-        # (no record waits for the slowest member of a fixed group); the rows are the same and in record order
-        prepared = [prepare(rec) for rec in records]
+        # (no record waits for the slowest member of a fixed group); the rows are the same and in record order.  Only the PLAN of a
+        # record (image sizes -> tile counts -> prompt -> token ids: host integers and strings) is made up front; its pixels are decoded,
+        # tiled and moved to the device when a slot admits it and dropped after its prefill, so memory does not grow with the shard.
+        planned = [plan_record(rec, setting, tokenizer) for rec in records]
+
+        def pixels_of(rec):
+            return lambda: prepare(rec)[1]
         kw = generate_kwargs(tokenizer.pad_token_id)
-        outs = model.generate_stream([(enc.to(dev), pixel_values) for _, pixel_values, _, enc in prepared], batch_size=batch_size,
+        outs = model.generate_stream([(enc.to(dev), pixels_of(rec)) for rec, (_, _, enc) in zip(records, planned)], batch_size=batch_size,
                                      eos_token_id=kw["eos_token_id"], max_new_tokens=kw["max_new_tokens"], stats=stats)
-        for rec, (s, _, n_vit, enc), out in zip(records, prepared, outs):
+        for rec, (question, n_vit, enc), out in zip(records, planned, outs):
             response = tokenizer.batch_decode(out[:, enc.shape[1]:], skip_special_tokens=True)[0]
-            rows.append(result_row(rec, s.question, response, n_vit, scorer))
+            rows.append(result_row(rec, question, response, n_vit, scorer))
         return rows
     for b0 in range(0, len(records), max(1, batch_size)):
         group = records[b0:b0 + max(1, batch_size)]

@@ -22,6 +22,39 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+def lo4_k4(K: int) -> int:
+    """Width of the fp4 images of a K-wide operand: K rounded up to the 256-element k-tile of the correction phase."""
+    return (K + 255) // 256 * 256
+
+
+class Lo4Act:
+    """One A operand of a GEMM with the low-bit correction phase (include/leopard_amd.h ``lmi_lo4``): ``hi`` = T(x) [M, K], ``img`` = the
+    fp4 (e2m1) image of x - T(x) [M, K4 / 2] bytes, ``sc`` = its E8M0 block scales [M, K4 / 32].  The three are views into caller-owned
+    scratch; the producers (lmi_norm_lo4, lmi_split_lo4, the GEMM epilogues) write all of them, padding included."""
+    __slots__ = ("hi", "img", "sc", "K", "K4")
+
+    def __init__(self, hi: torch.Tensor, img: torch.Tensor, sc: torch.Tensor):
+        self.hi, self.img, self.sc = hi, img, sc
+        self.K = hi.shape[1]
+        self.K4 = lo4_k4(self.K)
+        assert img.dtype == torch.uint8 and sc.dtype == torch.uint8 and img.shape == (hi.shape[0], self.K4 // 2) and sc.shape[0] == hi.shape[0]
+        assert sc.shape[1] >= self.K4 // 32 and sc.stride(0) % 4 == 0 and img.stride(0) % 16 == 0
+
+    @staticmethod
+    def empty(M: int, K: int, dtype, device) -> "Lo4Act":
+        k4 = lo4_k4(K)
+        return Lo4Act(torch.empty(M, K, dtype=dtype, device=device), torch.empty(M, k4 // 2, dtype=torch.uint8, device=device),
+                      torch.empty(M, k4 // 32, dtype=torch.uint8, device=device))
+
+
+class Lo4Weight:
+    """fp4 image of a weight [N, K4 / 2] bytes (row-major, whatever the layout of the 16-bit copy) + one E8M0 scale per row [N]."""
+    __slots__ = ("img", "sc")
+
+    def __init__(self, img: torch.Tensor, sc: torch.Tensor):
+        self.img, self.sc = img, sc
+
+
 class Ops:
     def __init__(self, lib=None, emulated: bool = False):
         self.lib = lib if lib is not None else _lib.load()
@@ -347,6 +380,71 @@ class Ops:
         self._check(self.lib.lmi_gemm_fp8(_ptr(a8), _ptr(w8), _ptr(out), _ptr(bias), M, N, K, a8.stride(0), w8.stride(0), out.stride(0),
                                           epilogue, act, int(scale_exp), dt, float(out_scale), self._stream(out)))
         return out
+
+    # ---- low-bit correction phase (lmi_lo4) ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _lo4_desc(a: Optional[Lo4Act], w4: Optional[Lo4Weight], out4: Optional[Lo4Act]) -> "_lib.Lo4Desc":
+        d = _lib.Lo4Desc()
+        if a is not None:
+            d.a4, d.a4_scale, d.lda4, d.lds4, d.k4 = a.img.data_ptr(), a.sc.data_ptr(), a.img.stride(0), a.sc.stride(0), a.K4
+        if w4 is not None:
+            d.w4, d.w4_scale, d.ldw4 = w4.img.data_ptr(), w4.sc.data_ptr(), w4.img.stride(0)
+        if out4 is not None:
+            d.out4, d.out4_scale, d.ld_out4, d.ld_out4s = out4.img.data_ptr(), out4.sc.data_ptr(), out4.img.stride(0), out4.sc.stride(0)
+        return d
+
+    def quantize_w4(self, w: torch.Tensor) -> Lo4Weight:
+        """fp4 image + per-row E8M0 scales of a ROW-MAJOR 16-bit weight [N, K] (lmi_quantize_w4; once, at load)."""
+        assert not getattr(w, "_lmi_packed", False) and w.stride(1) == 1
+        N, K = w.shape
+        k4 = lo4_k4(K)
+        img = torch.empty(N, k4 // 2, dtype=torch.uint8, device=w.device)
+        sc = torch.empty(N, dtype=torch.uint8, device=w.device)
+        self._check(self.lib.lmi_quantize_w4(_ptr(w), _ptr(img), _ptr(sc), N, K, k4, w.stride(0), img.stride(0), _DT[w.dtype], self._stream(w)))
+        return Lo4Weight(img, sc)
+
+    def split_lo4(self, x_f32: torch.Tensor, act: Lo4Act) -> Lo4Act:
+        """act = (T(x), fp4 image of x - T(x), block scales) of the fp32 x [M, K] (lmi_split_lo4)."""
+        M, K = x_f32.shape
+        assert x_f32.dtype == torch.float32 and act.hi.shape == (M, K)
+        self._check(self.lib.lmi_split_lo4(_ptr(x_f32), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), M, K, act.K4, x_f32.stride(0), act.hi.stride(0),
+                                           act.img.stride(0), act.sc.stride(0), _DT[act.hi.dtype], self._stream(x_f32)))
+        return act
+
+    def norm_lo4(self, x, w, b, act: Lo4Act, eps) -> Lo4Act:
+        """LayerNorm (b given) / RMSNorm (b None) of the fp32 rows x, handed over as a Lo4Act (lmi_norm_lo4)."""
+        M, D = x.shape
+        assert act.hi.shape == (M, D)
+        self._check(self.lib.lmi_norm_lo4(_ptr(x), _ptr(w), _ptr(b), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), M, D, act.K4, x.stride(0),
+                                          act.hi.stride(0), act.img.stride(0), act.sc.stride(0), float(eps), _DT[act.hi.dtype], self._stream(x)))
+        return act
+
+    def gemm_lo4(self, a: Lo4Act, w, w4: Lo4Weight, out, bias=None, epilogue=EPI_STORE, act=ACT_NONE, rowsq_in=None, norm_dim=0, norm_eps=0.0,
+                 norm_out=None, norm_gamma=None, rowsq_out=None, out4: Optional[Lo4Act] = None):
+        """lmi_gemm_lo4: gemm_ex on a.hi x w plus the correction phase a.img x w4.img into the same accumulators.  ``out4``: the Lo4Act whose
+        ``hi`` is this launch's 16-bit result (``out`` for STORE / SWIGLU, ``norm_out`` for the RESIDUAL producer mode) receives the image of
+        its residual."""
+        N, K = w.shape
+        M = a.hi.shape[0]
+        parts = 0 if rowsq_in is None else rowsq_in.shape[1]
+        d = self._lo4_desc(a, w4, out4)
+        self._check(self.lib.lmi_gemm_lo4(_ptr(a.hi), _ptr(w), _ptr(out), _ptr(bias), M, N, K, a.hi.stride(0), self._ldw(w), out.stride(0), epilogue, act,
+                                          _ptr(rowsq_in), parts, int(norm_dim), float(norm_eps), _ptr(norm_out), _ptr(norm_gamma), _ptr(rowsq_out),
+                                          0 if norm_out is None else norm_out.stride(0), C.byref(d), _DT[w.dtype], self._stream(out)))
+        return out
+
+    def rmsnorm_rope_lo4(self, a: Lo4Act, w_qkv_rope, w4: Lo4Weight, qkv, rowsq_in, eps, cos, sin, k_cache, v_cache, cache_pos0, n_q_heads, n_kv_heads,
+                         head_dim):
+        """lmi_rmsnorm_rope_lo4: rmsnorm_rope with the correction phase."""
+        M, K = a.hi.shape[0], w_qkv_rope.shape[1]
+        parts = 0 if rowsq_in is None else rowsq_in.shape[1]
+        ldc = 0 if k_cache is None else k_cache.stride(0)
+        d = self._lo4_desc(a, w4, None)
+        self._check(self.lib.lmi_rmsnorm_rope_lo4(_ptr(a.hi), _ptr(w_qkv_rope), _ptr(qkv), _ptr(rowsq_in), parts, float(eps), _ptr(cos), _ptr(sin),
+                                                  _ptr(k_cache), _ptr(v_cache), ldc, int(cache_pos0), M, n_q_heads, n_kv_heads, head_dim, K,
+                                                  a.hi.stride(0), self._ldw(w_qkv_rope), qkv.stride(0), C.byref(d), _DT[w_qkv_rope.dtype],
+                                                  self._stream(qkv)))
+        return qkv
 
     def split_hi_lo(self, x_f32, out):
         """out [M, 2K] (16-bit) = [T(x) | T(x - T(x))] of the fp32 x [M, K] (lmi_split_hi_lo; split-operand precision mode)."""

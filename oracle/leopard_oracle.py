@@ -68,7 +68,49 @@ class _Emu:
                           # float8_e4m3fn with per-tensor power-of-two scales; everything else stays at ``dtype``
     fp8_attention = False # fp8 schedule with engine.fp8_attention (csrc/attention_fp8.h): the rotated q / k, v (per-tensor power-of-two
                           # scales) and the probabilities entering P.V of the LLM layers are e4m3 as well; row sums and accumulators fp32
+    lo_sites = frozenset()  # low-bit correction pass (round 5; csrc/gemm.h second k-loop phase, engine.precision = "lo4"): at these
+                          # hand-over sites the A operand is handed over as T(x) PLUS an MX block-scaled low-bit image of the rounding
+                          # residual x - T(x) (per-32-element E8M0 scale along the contraction axis), multiplied with a low-bit image of
+                          # the weight (one E8M0 scale per weight row) into the same fp32 accumulators
+    lo_fmt = "e2m1"       # element format of the residual and of the weight image: "e2m1" (fp4), "e2m3" / "e3m2" (fp6), "e4m3" (fp8)
+    lo_wblock = 0         # 0 = one scale per weight row (what the engine does); 32 = per-32 block scales on the weight image (study)
     _wcache: dict = {}
+
+
+class _Split:
+    """A operand handed over as a 16-bit value plus a low-bit image of its rounding residual (see _Emu.lo_sites)."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    def scaled(self, f):                 # per-row factor applied to the accumulator rows (folded RMSNorm)
+        return _Split(self.hi * f, self.lo * f)
+
+
+_LO_GRID = {"e2m1": (1, 2, 6.0), "e2m3": (3, 2, 7.5), "e3m2": (2, 4, 28.0), "e4m3": (3, 8, 448.0)}   # mantissa bits, emax, max normal
+
+
+def _lo_round(x: Tensor, fmt: str, block: int) -> Tensor:
+    """MX-style quantisation along the last axis: shared scale 2^(floor(log2(amax)) - emax) per ``block`` elements (block = 0: per row),
+    elements rounded to nearest even on the format's grid (subnormals included) and saturated at its largest normal."""
+    mbits, emax, vmax = _LO_GRID[fmt]
+    if block and x.shape[-1] % block:                # the kernels' images are zero-padded to whole blocks (SigLIP's 4304-wide fc1 output)
+        pad = block - x.shape[-1] % block
+        return _lo_round(F.pad(x, (0, pad)), fmt, block)[..., :x.shape[-1]]
+    shp = x.shape
+    b = x.reshape(*shp[:-1], shp[-1] // block, block) if block else x.unsqueeze(-2)
+    amax = b.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -120))) - emax
+    sc = torch.exp2(e)
+    y = (b / sc).clamp(-vmax, vmax)
+    # grid step of the binade of |y| (minimum normal exponent 0 for e2m1 / e2m3, i.e. subnormal step 2^-mbits)
+    emin = {"e2m1": 0, "e2m3": 0, "e3m2": -2, "e4m3": -6}[fmt]
+    ey = torch.floor(torch.log2(y.abs().clamp_min(2.0 ** emin))).clamp_min(emin)
+    step = torch.exp2(ey - mbits)
+    q = torch.round(y / step) * step          # torch.round: half to even
+    q = q.clamp(-vmax, vmax)
+    return (q * sc).reshape(shp)
 
 
 def _q(x: Tensor) -> Tensor:
@@ -97,7 +139,18 @@ def _qa(x: Tensor, site: str = "") -> Tensor:
     """Hand-over point that is the A operand of a ViT / LLM layer linear (norm outputs, attention output, GELU / SwiGLU output)."""
     if site and site in _Emu.exact_sites:
         return x
+    if site and site in _Emu.lo_sites and _Emu.dtype is not None and _Emu.operand_dtype is None:
+        hi = _q(x)
+        return _Split(hi, _lo_round(x - hi, _Emu.lo_fmt, 32))
     return _q(x) if _Emu.operand_dtype is None else _fp8_round(x)
+
+
+def _lin(h, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    """A ViT / LLM layer linear.  A plain operand: F.linear on the (possibly fp8-rounded) weight.  A _Split operand: the 16-bit pass on
+    the exact weight plus the low-bit pass — residual image x weight image — into the same sum."""
+    if isinstance(h, _Split):                        # (the weight image is rebuilt per call: a cache of every layer's would double the oracle's memory)
+        return F.linear(h.hi, w, b) + F.linear(h.lo, _lo_round(w, _Emu.lo_fmt, _Emu.lo_wblock))
+    return F.linear(h, _wq(w), b)
 
 
 def _wq(w: Tensor) -> Tensor:
@@ -116,14 +169,18 @@ def _tr(name: str, x: Tensor) -> None:
 
 
 class emulate_rounding:
-    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None, exact_sites=(), fp8_block: int = 0, fp8_attention: bool = False):
+    def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None, exact_sites=(), fp8_block: int = 0, fp8_attention: bool = False,
+                 lo_sites=(), lo_fmt: str = "e2m1", lo_wblock: int = 0):
         self.dtype, self.trace, self.operand_dtype, self.exact_sites = dtype, trace, operand_dtype, frozenset(exact_sites)
+        self.lo = (frozenset(lo_sites), lo_fmt, lo_wblock)
         self.fp8_block = fp8_block
         self.fp8_attention = bool(fp8_attention) and operand_dtype is not None
 
     def __enter__(self):
         self._old = (_Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused)
         self._old_sites, self._old_block, self._old_a8 = _Emu.exact_sites, _Emu.fp8_block, _Emu.fp8_attention
+        self._old_lo = (_Emu.lo_sites, _Emu.lo_fmt, _Emu.lo_wblock)
+        _Emu.lo_sites, _Emu.lo_fmt, _Emu.lo_wblock = self.lo
         _Emu.fp8_block = self.fp8_block
         _Emu.fp8_attention = self.fp8_attention
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype = self.dtype, self.trace, self.operand_dtype
@@ -135,6 +192,7 @@ class emulate_rounding:
     def __exit__(self, *exc):
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused = self._old
         _Emu.exact_sites, _Emu.fp8_block, _Emu.fp8_attention = self._old_sites, self._old_block, self._old_a8
+        _Emu.lo_sites, _Emu.lo_fmt, _Emu.lo_wblock = self._old_lo
         _Emu._wcache.clear()
         return False
 
@@ -282,17 +340,18 @@ def siglip_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, prefix: str = "vi
     H, hd = vc.num_attention_heads, vc.head_dim
     r = x
     h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], vc.layer_norm_eps), "norm")
-    q = _q(F.linear(h, _wq(W[p + "self_attn.q_proj.weight"]), W[p + "self_attn.q_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
-    k = _q(F.linear(h, _wq(W[p + "self_attn.k_proj.weight"]), W[p + "self_attn.k_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
-    v = _q(F.linear(h, _wq(W[p + "self_attn.v_proj.weight"]), W[p + "self_attn.v_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
+    q = _q(_lin(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
+    k = _q(_lin(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
+    v = _q(_lin(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"])).view(N, T, H, hd).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)      # full (non-causal) attention per tile
     a = _softmax_q(s)
-    o = _qa(torch.matmul(a, v) if "attn_out" in _Emu.exact_sites else _q(torch.matmul(a, v)), "attn_out").transpose(1, 2).reshape(N, T, D)
-    x = r + F.linear(o, _wq(W[p + "self_attn.out_proj.weight"]), W[p + "self_attn.out_proj.bias"])
+    o = torch.matmul(a, v).transpose(1, 2).reshape(N, T, D)
+    o = _qa(o if "attn_out" in _Emu.exact_sites | _Emu.lo_sites else _q(o), "attn_out")
+    x = r + _lin(o, W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"])
     r = x
     h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], vc.layer_norm_eps), "norm")
-    h = _qa(gelu_tanh(F.linear(h, _wq(W[p + "mlp.fc1.weight"]), W[p + "mlp.fc1.bias"])), "mlp_act")
-    return r + F.linear(h, _wq(W[p + "mlp.fc2.weight"]), W[p + "mlp.fc2.bias"])
+    h = _qa(gelu_tanh(_lin(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])), "mlp_act")
+    return r + _lin(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"])
 
 
 def siglip_vision_tower(pixel_values: Tensor, W: Dict[str, Tensor], cfg) -> Tensor:
@@ -421,8 +480,10 @@ def _rms_norm_q(x: Tensor, w: Tensor, eps: float, first: bool) -> Tensor:
     if "norm" in _Emu.exact_sites:
         return rms_norm(x, w, eps)
     if _Emu.dtype is None or not _Emu.fused or first:
-        return _qa(rms_norm(x, w, eps))
+        return _qa(rms_norm(x, w, eps), "norm" if "norm" in _Emu.lo_sites else "")
     v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+    if "norm" in _Emu.lo_sites:                      # the producer also emits the low-bit image of x * gamma - T(x * gamma)
+        return _qa(x * w, "norm").scaled(torch.rsqrt(v + eps))
     return _q(x * w) * torch.rsqrt(v + eps)          # producer epilogue rounds x * gamma; the consumer applies rstd in fp32
 
 
@@ -435,9 +496,9 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
     r = x
     pre = (lambda t: t) if _Emu.fused else _q          # unfused schedule: q / k are also rounded before the rotation
     h = _rms_norm_q(x, W[p + "input_layernorm.weight"], tc.rms_norm_eps, first=(i == 0))
-    q = pre(F.linear(h, _wq(W[p + "self_attn.q_proj.weight"]))).view(B, S, H, hd).transpose(1, 2)
-    k = pre(F.linear(h, _wq(W[p + "self_attn.k_proj.weight"]))).view(B, S, KV, hd).transpose(1, 2)
-    v = _q(F.linear(h, _wq(W[p + "self_attn.v_proj.weight"]))).view(B, S, KV, hd).transpose(1, 2)
+    q = pre(_lin(h, W[p + "self_attn.q_proj.weight"])).view(B, S, H, hd).transpose(1, 2)
+    k = pre(_lin(h, W[p + "self_attn.k_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
+    v = _q(_lin(h, W[p + "self_attn.v_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
     q = _q(q * cos + rotate_half(q) * sin)
     k = _q(k * cos + rotate_half(k) * sin)
     if kv_out is not None:
@@ -461,13 +522,13 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
         sc = sc.masked_fill(~causal, float("-inf"))
         o[:, :, s0:s1] = torch.matmul(_softmax_q(sc, fp8_p=a8), vv[:, :, :s1])
     o = o.transpose(1, 2).reshape(B, S, H * hd)
-    o = _qa(o if "attn_out" in _Emu.exact_sites else _q(o), "attn_out")
-    x = r + F.linear(o, _wq(W[p + "self_attn.o_proj.weight"]))
+    o = _qa(o if "attn_out" in _Emu.exact_sites | _Emu.lo_sites else _q(o), "attn_out")
+    x = r + _lin(o, W[p + "self_attn.o_proj.weight"])
     r = x
     h = _rms_norm_q(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps, first=False)
-    g = F.linear(h, _wq(W[p + "mlp.gate_proj.weight"]))
-    u = F.linear(h, _wq(W[p + "mlp.up_proj.weight"]))
-    return r + F.linear(_qa(F.silu(g) * u, "mlp_act"), _wq(W[p + "mlp.down_proj.weight"]))       # XFMR:136-139
+    g = _lin(h, W[p + "mlp.gate_proj.weight"])
+    u = _lin(h, W[p + "mlp.up_proj.weight"])
+    return r + _lin(_qa(F.silu(g) * u, "mlp_act"), W[p + "mlp.down_proj.weight"])       # XFMR:136-139
 
 
 def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tensor], cfg,

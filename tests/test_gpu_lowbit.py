@@ -1,0 +1,232 @@
+"""-m gpu: the LOW-BIT CORRECTION PHASE on the device (csrc/lowbit.h, the LO4 instantiations of csrc/gemm.h, through the C ABI).
+
+tests/test_emu_lowbit.py pins the LOGIC on the host emulator (images == the oracle's quantisation rule bit for bit; tile indexing; epilogues).
+Here the hardware half: what v_mfma_scale_f32_32x32x64_f8f6f4 does with the fp4 images and their E8M0 block scales (nibble order, lane ->
+(row, k-block) ownership of a scale byte, op_sel) — every LO4 GEMM is compared with a plain fp32 product over the DEQUANTISED images, at small
+shapes on every geometry and at the production shapes of the C3 step (7187 / 28392 rows), three launches each bit-identical (a DMA / read
+race would show) —, the producers against their host definitions, and the engine's lo4 mode at full depth in tests/test_gpu_parity.py."""
+import pytest
+import torch
+
+from leopard_amd import _lib
+from leopard_amd.ops import Lo4Act, Lo4Weight, lo4_k4
+from leopard_amd.weights import as_packed, interleave_gate_up, rope_permute_rows
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from leopard_amd.ops import Ops
+    o = Ops()
+    yield o
+    o.set_option("gemm.config", -1)
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def decode_img(img, sc, K, per_row=False):
+    """fp4 image [M, K4 / 2] bytes + E8M0 scales -> fp32 [M, K]: element k in nibble k & 1 of byte k >> 1 (the layout the kernels assume)."""
+    grid = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], device=img.device)
+    M, half = img.shape
+    b = img.to(torch.int64)
+    codes = torch.stack([b & 15, b >> 4], dim=-1).reshape(M, half * 2)
+    val = grid[codes & 7] * torch.where((codes & 8) != 0, -1.0, 1.0)
+    s = torch.exp2(sc.to(torch.float32) - 127.0)
+    s = s[:, None].expand(M, half * 2) if per_row else s[:, :half * 2 // 32].repeat_interleave(32, dim=1)
+    return (val * s)[:, :K]
+
+
+def host_lo_round(x, block):
+    """The oracle's MX e2m1 rule (oracle.leopard_oracle._lo_round) — imported: this file is test code."""
+    from oracle import leopard_oracle as O
+    return O._lo_round(x.float().cpu(), "e2m1", block)
+
+
+def eps(dtype):
+    return 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+
+
+def act_from(ops, x, dtype):
+    act = Lo4Act.empty(x.shape[0], x.shape[1], dtype, DEV)
+    ops.split_lo4(x.contiguous(), act)
+    return act
+
+
+def ref_acc(act, w_rowmajor, w4):
+    K = act.K
+    return act.hi.float() @ w_rowmajor.float().T + decode_img(act.img, act.sc, K) @ decode_img(w4.img, w4.sc, K, per_row=True).T
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_producers_match_the_host_rule(ops, dtype):
+    M, K = 333, 1152
+    x = rnd((M, K), torch.float32, 1, 3.0)
+    act = Lo4Act.empty(M, K, dtype, DEV)
+    act.img.fill_(0xAB); act.sc.fill_(0xCD)
+    ops.split_lo4(x, act)
+    assert torch.equal(act.hi, x.to(dtype))
+    lo = (x - act.hi.float())
+    assert torch.equal(decode_img(act.img, act.sc, K).cpu(), host_lo_round(lo, 32))
+    assert act.img[:, K // 2:].abs().max() == 0 and act.sc[:, K // 32:].abs().max() == 0
+    w = rnd((300, 4096), dtype, 2, 0.02)
+    w4 = ops.quantize_w4(w)
+    assert torch.equal(decode_img(w4.img, w4.sc, 4096, per_row=True).cpu(), host_lo_round(w, 0))
+    # norms: the 16-bit rows are those of the plain kernels, the image removes ~85 % of their rounding
+    for rms, D in ((False, 1152), (True, 4096)):
+        xs = rnd((777, D), torch.float32, 3, 2.0) + 0.3
+        g = torch.rand(D, generator=torch.Generator().manual_seed(4)).to(DEV) + 0.5
+        b = None if rms else rnd((D,), torch.float32, 5, 0.2)
+        a = Lo4Act.empty(777, D, dtype, DEV)
+        ops.norm_lo4(xs, g, b, a, 1e-5)
+        plain = torch.empty(777, D, dtype=dtype, device=DEV)
+        (ops.rmsnorm(xs, g, plain, 1e-5) if rms else ops.layernorm(xs, g, b, plain, 1e-5))
+        assert torch.equal(a.hi, plain)
+        y = (xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-5) * g) if rms else torch.nn.functional.layer_norm(xs, (D,), g, b, 1e-5)
+        before = (y - a.hi.float()).pow(2).mean().sqrt().item()
+        after = (y - a.hi.float() - decode_img(a.img, a.sc, D)).pow(2).mean().sqrt().item()
+        assert after < 0.25 * before, (rms, before, after)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [-1, 0, 2, 5, 8, 10])
+def test_gemm_lo4_small_every_geometry(ops, dtype, cfg):
+    M, N, K = 300, 256, 320
+    x, w = rnd((M, K), torch.float32, 10, 2.0), rnd((N, K), dtype, 11, 0.1)
+    bias = rnd((N,), torch.float32, 12)
+    act, w4 = act_from(ops, x, dtype), ops.quantize_w4(w)
+    ref = ref_acc(act, w, w4) + bias
+    ops.set_option("gemm.config", cfg)
+    try:
+        outs = []
+        for _ in range(3):
+            o = torch.empty(M, N, dtype=torch.float32, device=DEV)
+            ops.gemm_lo4(act, w, w4, o, bias=bias, epilogue=_lib.EPI_STORE_F32)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert (outs[0] - ref).abs().max() <= 2e-4 * ref.abs().max(), ((outs[0] - ref).abs().max().item(), ref.abs().max().item())
+        exact = x @ w.float().T + bias
+        plain = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        ops.gemm(act.hi, w, plain, bias=bias, epilogue=_lib.EPI_STORE_F32)
+        assert (outs[0] - exact).pow(2).mean().sqrt().item() < 0.3 * (plain - exact).pow(2).mean().sqrt().item()
+        # GELU + the image of its own output
+        out4 = Lo4Act.empty(M, N, dtype, DEV)
+        ops.gemm_lo4(act, w, w4, out4.hi, bias=bias, act=_lib.ACT_GELU_TANH, out4=out4)
+        y = torch.nn.functional.gelu(ref, approximate="tanh")
+        assert ((out4.hi.float() - y).abs() / (1 + y.abs())).max().item() <= 2 * eps(dtype)
+        before = (y - out4.hi.float()).pow(2).mean().sqrt().item()
+        after = (y - out4.hi.float() - decode_img(out4.img, out4.sc, N)).pow(2).mean().sqrt().item()
+        assert after < 0.3 * before, (before, after)
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
+PROD = [  # (name, M, N, K, epilogue) — the lo4 schedule's GEMMs at the C3 sizes
+    ("siglip qkv", 28392, 3456, 1152, "store_bias"),
+    ("siglip out_proj", 28392, 1152, 1152, "resid_bias"),
+    ("siglip fc1", 28392, 4352, 1152, "gelu_out4"),
+    ("siglip fc2", 28392, 1152, 4352, "resid_bias"),
+    ("llama o_proj", 7187, 4096, 4096, "producer"),
+    ("llama gate/up", 7187, 28672, 4096, "swiglu_out4"),
+    ("llama down", 7187, 4096, 14336, "producer"),
+]
+
+
+@pytest.mark.parametrize("name,M,N,K,kind", PROD, ids=[p[0].replace(" ", "_").replace("/", "_") for p in PROD])
+def test_gemm_lo4_production_shapes(ops, name, M, N, K, kind):
+    """fp16, the automatic geometry, packed 16-bit weights where the engine packs them; sampled rows (every tile edge) against fp32."""
+    dtype = torch.float16
+    x = rnd((M, K), torch.float32, 20, 1.5)
+    w = rnd((N, K), dtype, 21, 0.03)
+    act, w4 = act_from(ops, x, dtype), ops.quantize_w4(w)
+    w_run = as_packed(w) if name.startswith("llama") else w
+    rows = torch.unique(torch.cat([torch.arange(0, M, 997), torch.tensor([0, 1, 255, 256, 257, M - 257, M - 256, M - 2, M - 1])]).clamp(0, M - 1)).to(DEV)
+    sub = Lo4Act(act.hi[rows].contiguous(), act.img[rows].contiguous(), act.sc[rows].contiguous())
+    acc = ref_acc(sub, w, w4)
+    bias = rnd((N,), torch.float32, 22, 0.5) if "bias" in kind or "gelu" in kind else None
+
+    def run():
+        if kind == "store_bias":
+            o = torch.empty(M, N, dtype=dtype, device=DEV)
+            ops.gemm_lo4(act, w_run, w4, o, bias=bias)
+            return (o,)
+        if kind == "resid_bias":
+            xs = torch.ones(M, N, dtype=torch.float32, device=DEV)
+            ops.gemm_lo4(act, w_run, w4, xs, bias=bias, epilogue=_lib.EPI_RESIDUAL)
+            return (xs,)
+        if kind == "gelu_out4":
+            o4 = Lo4Act.empty(M, N, dtype, DEV)
+            ops.gemm_lo4(act, w_run, w4, o4.hi, bias=bias, act=_lib.ACT_GELU_TANH, out4=o4)
+            return (o4.hi, o4.img, o4.sc)
+        if kind == "producer":
+            xs = torch.ones(M, N, dtype=torch.float32, device=DEV)
+            h = Lo4Act.empty(M, N, dtype, DEV)
+            sq = torch.empty(M, N // 64, dtype=torch.float32, device=DEV)
+            ops.gemm_lo4(act, w_run, w4, xs, epilogue=_lib.EPI_RESIDUAL, norm_out=h.hi, norm_gamma=gamma, rowsq_out=sq, out4=h)
+            return (xs, h.hi, h.img, h.sc, sq)
+        o4 = Lo4Act.empty(M, N // 2, dtype, DEV)
+        ops.gemm_lo4(act, w_run, w4, o4.hi, epilogue=_lib.EPI_SWIGLU, out4=o4)
+        return (o4.hi, o4.img, o4.sc)
+
+    gamma = (torch.rand(N, generator=torch.Generator().manual_seed(23)) + 0.5).to(DEV)
+    a, b, c = run(), run(), run()
+    for t0, t1, t2 in zip(a, b, c):
+        assert torch.equal(t0, t1) and torch.equal(t0, t2), name
+    scale = acc.abs().max().item()
+    if kind == "store_bias":
+        y = acc + bias
+        assert ((a[0][rows].float() - y).abs() / (1 + y.abs())).max().item() <= 2 * eps(dtype)
+    elif kind == "resid_bias":
+        assert (a[0][rows] - (1.0 + acc + bias)).abs().max().item() <= 3e-4 * scale
+    elif kind == "gelu_out4":
+        y = torch.nn.functional.gelu(acc + bias, approximate="tanh")
+        assert ((a[0][rows].float() - y).abs() / (1 + y.abs())).max().item() <= 2 * eps(dtype)
+        before = (y - a[0][rows].float()).pow(2).mean().sqrt().item()
+        after = (y - a[0][rows].float() - decode_img(a[1][rows], a[2][rows], N)).pow(2).mean().sqrt().item()
+        assert after < 0.3 * before, (before, after)
+    elif kind == "producer":
+        xs = a[0][rows]
+        assert (xs - (1.0 + acc)).abs().max().item() <= 3e-4 * scale
+        assert torch.equal(a[1][rows], (xs * gamma).to(dtype))
+        assert torch.equal(decode_img(a[2][rows], a[3][rows], N).cpu(), host_lo_round(xs * gamma - a[1][rows].float(), 32))
+    else:
+        g = acc.view(-1, N // 64, 2, 32)
+        y = (torch.nn.functional.silu(g[:, :, 0]) * g[:, :, 1]).reshape(-1, N // 2)
+        assert ((a[0][rows].float() - y).abs() / (1 + y.abs())).max().item() <= 3 * eps(dtype)
+        before = (y - a[0][rows].float()).pow(2).mean().sqrt().item()
+        after = (y - a[0][rows].float() - decode_img(a[1][rows], a[2][rows], N // 2)).pow(2).mean().sqrt().item()
+        assert after < 0.3 * before, (before, after)
+
+
+def test_rmsnorm_rope_lo4_at_the_llama_shape(ops):
+    dtype = torch.float16
+    S, nq, nkv, D, K = 7187, 32, 8, 128, 4096
+    xa = rnd((S, K), torch.float32, 30, 1.5)
+    wq, wk, wv = rnd((nq * D, K), dtype, 31, 0.03), rnd((nkv * D, K), dtype, 32, 0.03), rnd((nkv * D, K), dtype, 33, 0.03)
+    w_nat = torch.cat([wq, wk, wv], 0)
+    w_rope = torch.cat([rope_permute_rows(torch.cat([wq, wk], 0)), wv], 0).contiguous()
+    act = act_from(ops, xa, dtype)
+    w4_rope, w4_nat = ops.quantize_w4(w_rope), ops.quantize_w4(w_nat)
+    pos = torch.arange(S).float()
+    inv = 1.0 / (5e5 ** (torch.arange(0, D, 2).float() / D))
+    cos, sin = (pos[:, None] * inv[None]).cos().contiguous().to(DEV), (pos[:, None] * inv[None]).sin().contiguous().to(DEV)
+    sq = (torch.rand(S, K // 64, generator=torch.Generator().manual_seed(34)) * 64 + 32).to(DEV)
+    rstd = torch.rsqrt(sq.sum(-1, keepdim=True) / K + 1e-5)
+    qkv = torch.empty(S, (nq + 2 * nkv) * D, dtype=dtype, device=DEV)
+    kc, vc = torch.zeros(S, nkv * D, dtype=dtype, device=DEV), torch.zeros(S, nkv * D, dtype=dtype, device=DEV)
+    ops.rmsnorm_rope_lo4(act, as_packed(w_rope), w4_rope, qkv, sq, 1e-5, cos, sin, kc, vc, 0, nq, nkv, D)
+    rows = torch.cat([torch.arange(0, S, 499), torch.tensor([255, 256, S - 1])]).to(DEV)
+    sub = Lo4Act(act.hi[rows].contiguous(), act.img[rows].contiguous(), act.sc[rows].contiguous())
+    acc = (ref_acc(sub, w_nat, w4_nat) * rstd[rows]).view(len(rows), nq + 2 * nkv, D)
+    h = D // 2
+    c, s = torch.cat([cos[rows], cos[rows]], -1)[:, None, :], torch.cat([sin[rows], sin[rows]], -1)[:, None, :]
+    qk = acc[:, :nq + nkv]
+    rot = torch.cat((-qk[..., h:], qk[..., :h]), dim=-1)
+    ref = torch.cat([qk * c + rot * s, acc[:, nq + nkv:]], dim=1).reshape(len(rows), -1)
+    assert ((qkv[rows].float() - ref).abs() / (1 + ref.abs())).max().item() <= 2 * eps(dtype)
+    assert torch.equal(kc, qkv[:, nq * D:(nq + nkv) * D]) and torch.equal(vc, qkv[:, (nq + nkv) * D:])

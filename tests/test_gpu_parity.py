@@ -178,13 +178,13 @@ def rel_rms(a, b):
     return ((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt()).item()
 
 
-def run_full_depth(ops, fx, dtype, split=False):
+def run_full_depth(ops, fx, dtype, split=False, precision=None):
     from leopard_amd.engine import LeopardEngine
     from leopard_amd.weights import EngineWeights, SynthSource
     cfg = full_config()
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, torch.device(DEV), dtype), dtype)
     eng = LeopardEngine(cfg, W, ops=ops, device=torch.device(DEV))
-    eng.split_operands = split
+    eng.precision = precision or ("split" if split else "fast")
     probes = {}
     eng.trace = lambda name, x: probes.__setitem__(name, fx.probe_of(name, x.detach()).float().cpu())
     res = eng.prefill(fx.ids.to(DEV), torch.from_numpy(fx.u8).to(DEV))
@@ -248,6 +248,40 @@ def test_full_depth_split_operands_meets_1e_3(ops, full_depth_oracle, case):
     a, n, r = err_stats(got, fx.ref)
     print(f"[{case} full depth fp16, split operands] vs fp32 oracle: max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}")
     assert n <= 1.0e-3 and int(got.argmax()) == int(fx.ref.argmax())
+
+
+@pytest.mark.parametrize("case", ["c1", "c2", "c3"])
+def test_full_depth_lo4_meets_1e_3(ops, full_depth_oracle, case):
+    """north_star's figure on the schedule the bench line is quoted on (round 5): engine.precision = "lo4" — the fast schedule + the fp4 image of
+    every layer-linear operand's rounding residual multiplied into the same accumulators (+ 25 % matrix time, not + 100 %).  Last-position
+    logits of C1, C2 and C3 at FULL depth within 1e-3 of the fp32 reference, normalised by the logit scale (the absolute figure is printed beside
+    it); predicted by the oracle that emulates exactly this arithmetic: C1 6.1e-4 (profiles/r05_lowbit_correction_study_c1.txt)."""
+    fx = full_depth_oracle[case]
+    got, probes = run_full_depth(ops, fx, torch.float16, precision="lo4")
+    a, n, r = err_stats(got, fx.ref)
+    last = fx.names[-1]
+    print(f"[{case} full depth fp16, lo4 correction] vs fp32 oracle: max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}  max|logit| {fx.ref.abs().max():.3f}  "
+          f"residual stream after {last} (probe rows) rel-rms {rel_rms(probes[last], fx.probe[last]):.3e}  argmax equal = {int(got.argmax()) == int(fx.ref.argmax())}")
+    assert n <= 1.0e-3 and int(got.argmax()) == int(fx.ref.argmax())
+    # and it is the fast schedule's error that was removed: the fp32 residual stream after the last layer is >= 2 x closer than the 16-bit budget
+    pred16 = fx.pred.get("fp16", {}).get(last)
+    if pred16:
+        assert rel_rms(probes[last], fx.probe[last]) <= 0.6 * pred16
+
+
+@pytest.mark.parametrize("case", ["c2"])
+def test_full_depth_bf16_precision_modes(ops, full_depth_oracle, case):
+    """BASELINE configs[1] names bf16.  With 8 significand bits the attention's own operands (q, k, v, P: untouched by either precision mode) cost
+    ~1.6e-3 at this depth, so NO bf16 schedule meets 1e-3; the modes still do what they are for — lo4 removes most of the layer-linear hand-over
+    roundings, split all of them — and the figures are printed for DESIGN.md 2.1.  The 1e-3 line of configs[1] is the fp16 engine in lo4 mode."""
+    fx = full_depth_oracle[case]
+    base, _ = run_full_depth(ops, fx, torch.bfloat16)
+    lo4, _ = run_full_depth(ops, fx, torch.bfloat16, precision="lo4")
+    split, _ = run_full_depth(ops, fx, torch.bfloat16, precision="split")
+    nb, nl, ns = err_stats(base, fx.ref)[1], err_stats(lo4, fx.ref)[1], err_stats(split, fx.ref)[1]
+    print(f"[{case} full depth bf16] normalised-max vs fp32 oracle: fast {nb:.3e}  lo4 {nl:.3e}  split {ns:.3e}")
+    assert nl < 0.6 * nb and ns < 0.6 * nb
+    assert int(lo4.argmax()) == int(fx.ref.argmax()) and int(split.argmax()) == int(fx.ref.argmax())
 
 
 # ---- fp8 linears (BASELINE configs[4]; leopard_amd.fp8): the error budget of e4m3 operands, predicted and measured --------------------
