@@ -107,6 +107,23 @@ class GemmTimer:
                 return r
             return call
         ops.gemm_ex, ops.rmsnorm_rope = timed(ops.gemm_ex), timed(ops.rmsnorm_rope)
+        # precision "lo4": the same family with the fp4 correction phase (a = Lo4Act: 16-bit rows + fp4 image + block scales).  FLOPs booked
+        # are the ALGORITHMIC 2 M N K of the linear — the correction phase's extra matrix work is overhead, not useful work
+        self._inner_lo4, self._inner_rope_lo4 = ops.gemm_lo4, ops.rmsnorm_rope_lo4
+
+        def timed_lo4(fn):
+            def call(a, w, w4, out, *args, **kw):
+                M = a.hi.shape[0]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
+                r = fn(a, w, w4, out, *args, **kw)
+                e1.record(torch.cuda.current_stream())
+                timer.records.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1, (M, w.shape[0], w.shape[1])))
+                timer.bytes += ((M + w.shape[0]) * w.shape[1] * w.element_size() + out.numel() * out.element_size()
+                                + a.img.numel() + a.sc.numel() + w4.img.numel())
+                return r
+            return call
+        ops.gemm_lo4, ops.rmsnorm_rope_lo4 = timed_lo4(ops.gemm_lo4), timed_lo4(ops.rmsnorm_rope_lo4)
         # --dtype fp8: the fp8 GEMMs are their own family (own records, priced against the fp8 peak)
         self._inner_fp8 = ops.gemm_fp8
         self.fp8_records, self.fp8_bytes = [], 0
@@ -124,6 +141,7 @@ class GemmTimer:
 
     def unwrap(self, ops, inner):
         ops.gemm, ops.gemm_ex, ops.rmsnorm_rope, ops.gemm_fp8 = inner, self._inner_ex, self._inner_rope, self._inner_fp8
+        ops.gemm_lo4, ops.rmsnorm_rope_lo4 = self._inner_lo4, self._inner_rope_lo4
 
     def use_fp8_family(self):
         """Make the fp8 launches the family summary() / dominant() describe; returns (flops, ms, n) of the 16-bit launches left."""
@@ -132,16 +150,17 @@ class GemmTimer:
         return rest
 
     def times(self):
-        """Elapsed ms of every record.  The passes launch the same sequence: a launch's time is the MINIMUM over the passes (an event pair also
-        spans any moment the host fell behind the device between the two records — one such stall would otherwise be booked as GEMM time)."""
+        """Elapsed ms of every record.  The passes launch the same sequence: a launch's time is the MEDIAN over the passes (an event pair also
+        spans any moment the host fell behind the device between the two records; the median of three drops one such stall without booking
+        every launch at its best case)."""
         torch.cuda.synchronize()
         t = [r[1].elapsed_time(r[2]) for r in self.records]
         p = getattr(self, "passes", 1)
         if p > 1 and len(t) % p == 0 and len(t) > 0:
             n = len(t) // p
             if all(self.records[i][3] == self.records[i + k * n][3] for k in range(1, p) for i in range(n)):
-                best = [min(t[i + k * n] for k in range(p)) for i in range(n)]
-                t = best * p
+                mid = [sorted(t[i + k * n] for k in range(p))[(p - 1) // 2] for i in range(n)]
+                t = mid * p
         return t
 
     def summary(self):
@@ -769,7 +788,7 @@ def main():
             with torch.cuda.stream(ctxs[0].stream):
                 ctxs[0].cache.length = 0
                 eng.prefill(ctxs[0].ids, ctxs[0].tiles, cache=ctxs[0].cache)
-        passes = min(args.steps, 2)
+        passes = min(args.steps, 3)
         rl = roofline_from_timer(ops, once, passes, args.dtype == "fp8")
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes over this very command (tools/collect_traffic.sh ->
         # tools/hbm_traffic.py).  The committed summary is stamped with the hash of the kernel sources it was measured on and is

@@ -260,8 +260,8 @@ int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* 
  * an MX fp4 image (e2m1; one E8M0 power-of-two scale per 32 consecutive k), the weight has an fp4 image with one E8M0 scale per row, and
  * after its 16-bit k-loop the GEMM runs K4 / 256 more k-tiles of v_mfma_scale_f32_32x32x64_f8f6f4 on the two images INTO THE SAME
  * ACCUMULATORS: + 25 % matrix-pipe time instead of + 100 % for the hi + lo 16-bit pair, ~80 % of the rounding removed.
- * Images: row-major, element k of a row in nibble k & 1 of byte k >> 1; K4 = K rounded up to a multiple of 256 elements, zero codes and
- * zero scale bytes in the padding; lda4 / ldw4 / ld_out4 in BYTES; a4_scale [M, lds4] with lds4 >= K4 / 32; w4_scale [N].
+ * Images: row-major, element k of a row in nibble k & 1 of byte k >> 1; K4 = K rounded up to a multiple of 256 elements (or wider, when
+ * the two images share a padded k order: lmi_attn_varlen_fwd_lo4), zero codes and zero scale bytes in the padding; lda4 / ldw4 / ld_out4 in BYTES; a4_scale [M, lds4] with lds4 >= K4 / 32; w4_scale [N].
  * lmi_lo4: inputs (a4, a4_scale, w4, w4_scale: all four) consumed by this launch, outputs (out4, out4_scale: both or neither) = the image of
  * the residual of this launch's own 16-bit result — `out` for LMI_EPI_STORE (+ activation) and LMI_EPI_SWIGLU, `norm_out` for the
  * RESIDUAL producer mode — for the next GEMM. */
@@ -278,6 +278,13 @@ int lmi_gemm_lo4(const void* A, const void* W, void* out, const float* bias, int
 int lmi_rmsnorm_rope_lo4(const void* A, const void* Wqkv, void* qkv, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_table,
                          const float* sin_table, void* k_cache, void* v_cache, int ld_cache, int cache_pos0, int M, int n_q_heads, int n_kv_heads,
                          int head_dim, int K, int lda, int ldw, int ldo, const lmi_lo4* lo, int dtype, void* stream);
+/* lmi_attn_varlen_fwd that also writes the residual image of its 16-bit output rows (LDS-DMA kernel; head_dim 72 / 96 / 128).  The image
+ * has its own k order so that no 32-element block straddles two heads: head h occupies blocks [h * NB, (h + 1) * NB), NB = ceil(head_dim / 32)
+ * (head_dim 128: the natural order; 72 / 96: every head padded to 96 with zero codes), i.e. k4 = n_heads * NB * 32 rounded up to 256 by the
+ * caller's buffer; the consuming projection's weight image must use the same order.  out4 [total_q, ld_out4 bytes], out4_scale [total_q, ld_out4s]. */
+int lmi_attn_varlen_fwd_lo4(const void* q, const void* k, const void* v, void* out, void* out4, void* out4_scale, int ld_out4, int ld_out4s,
+                            const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                            int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int dtype, void* stream);
 /* fp32 activation [M, K] (K % 32 == 0) -> hi = T(x) [M, ldh] + the fp4 image of x - T(x) [M, ld4 bytes] + its block scales [M, lds]
  * (attention outputs: lmi_attn_varlen_fwd_f32 hands over fp32). */
 int lmi_split_lo4(const float* x, void* hi, void* lo4, void* scales, int M, int K, int K4, int ldx, int ldh, int ld4, int lds, int dtype, void* stream);

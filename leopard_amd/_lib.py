@@ -64,6 +64,7 @@ SIGNATURES = {
     "lmi_split_hi_lo": [_P, _P, _I, _I, _I, _I, _I, _P],
     "lmi_gemm_lo4": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _P, _P, _I, C.POINTER(Lo4Desc), _I, _P],
     "lmi_rmsnorm_rope_lo4": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(Lo4Desc), _I, _P],
+    "lmi_attn_varlen_fwd_lo4": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "lmi_split_lo4": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_norm_lo4": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "lmi_quantize_w4": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -42,20 +42,41 @@ class LlavaCausalLMOutputWithPast:
                 if v is not None][i]
 
 
+def resolve_precision(requested_dtype, compute_dtype, precision: Optional[str] = None, tp_size: int = 1) -> str:
+    """Schedule of the prefill (LeopardEngine.precision).  ``LEOPARD_AMD_PRECISION`` = fast | lo4 | split overrides everything; an explicit
+    ``precision`` argument comes next; otherwise a caller that asks for ``torch_dtype=torch.float32`` — the reference script does, EVAL:373 —
+    gets the mode that meets the stated tolerance against fp32 arithmetic (lo4: fp16 operands + the fp4 correction phase, full-depth logits
+    within 1e-3), and a caller that asks for a 16-bit type gets the fast schedule of that type.  Tensor-parallel engines run the fast schedule."""
+    env = os.environ.get("LEOPARD_AMD_PRECISION", "").lower()
+    mode = env or precision or ("lo4" if requested_dtype in (None, torch.float32) and compute_dtype == torch.float16 else "fast")
+    if mode not in ("fast", "lo4", "split"):
+        raise ValueError(f"precision must be fast, lo4 or split, not {mode!r}")
+    return "fast" if tp_size > 1 else mode
+
+
 class LeopardForConditionalGeneration:
-    def __init__(self, config: LeopardConfig, source_factory, compute_dtype=torch.float16, ops: Optional[Ops] = None):
+    def __init__(self, config: LeopardConfig, source_factory, compute_dtype=torch.float16, ops: Optional[Ops] = None,
+                 torch_dtype=torch.float32, precision: Optional[str] = None, tp_rank: int = 0, tp_size: int = 1):
         self.config = config
         self._source_factory = source_factory            # (device, dtype) -> parameter source with .get(name)
         self.compute_dtype = compute_dtype
+        self.requested_dtype = torch_dtype
+        self.precision = resolve_precision(torch_dtype, compute_dtype, precision, tp_size)
+        self.tp_rank, self.tp_size = int(tp_rank), int(tp_size)
         self._ops = ops
         self._engine: Optional[LeopardEngine] = None
         self.device = torch.device("cpu")
 
     # ---- loading ---------------------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype=torch.float32, compute_dtype=torch.float16, ops: Optional[Ops] = None):
+    def from_pretrained(cls, path: str, torch_dtype=torch.float32, compute_dtype=torch.float16, ops: Optional[Ops] = None,
+                        precision: Optional[str] = None, tp_rank: int = 0, tp_size: int = 1):
+        """``precision``: see resolve_precision.  ``tp_size`` > 1 (SURVEY.md 8 f1 "optional TP pre-sharding on load"): this process holds
+        tensor-parallel shard ``tp_rank`` of the LLM — the checkpoint's tensors are sliced while they stream to the device
+        (EngineWeights.build) — and needs an initialised process group of that size (leopard_amd.dist.init) by the time ``.to(device)`` runs."""
         cfg = load_config(path)
-        return cls(cfg, lambda dev, dt: CheckpointSource(path, dev, dt), compute_dtype, ops)
+        return cls(cfg, lambda dev, dt: CheckpointSource(path, dev, dt), compute_dtype, ops, torch_dtype=torch_dtype, precision=precision,
+                   tp_rank=tp_rank, tp_size=tp_size)
 
     def eval(self):
         return self
@@ -64,11 +85,12 @@ class LeopardForConditionalGeneration:
         device = torch.device(device)
         if self._engine is None or device != self.device:
             ops = self._ops if self._ops is not None else Ops()
-            W = EngineWeights.build(self.config, self._source_factory(device, self.compute_dtype), self.compute_dtype)
+            W = EngineWeights.build(self.config, self._source_factory(device, self.compute_dtype), self.compute_dtype, tp_rank=self.tp_rank,
+                                    tp_size=self.tp_size)
             self._engine = LeopardEngine(self.config, W, ops=ops, device=device)
-            # LEOPARD_AMD_PRECISION=split: the split-operand precision mode for the prefill (full-depth logits within 1e-3 of the fp32
-            # arithmetic the reference script asks for with torch_dtype=torch.float32, at ~1.8x the prefill time); default: the fast schedule
-            self._engine.split_operands = os.environ.get("LEOPARD_AMD_PRECISION", "").lower() == "split"
+            if self.precision == "lo4" and not self._engine.lo4_supported():
+                self.precision = "split"                 # a model shape the lo4 schedule does not cover: the 2 K mode meets the same figure
+            self._engine.precision = self.precision
             self.device = device
         return self
 
@@ -138,7 +160,8 @@ class LeopardForConditionalGeneration:
         """Continuous batching over a list of requests: ``batch_size`` decode slots kept busy (LeopardEngine.generate_stream); the outputs
         come back in request order, each what ``generate`` returns for that request."""
         eos = eos_token_id if isinstance(eos_token_id, (list, tuple)) else ([] if eos_token_id is None else [eos_token_id])
-        samples = [(ids.to(self.device), self._as_tiles(pix)) for ids, pix in requests]
+        # a callable in place of the pixels is called when a slot admits the request (leopard_amd.harness: bounded memory over a shard)
+        samples = [(ids.to(self.device), (lambda f=pix: self._as_tiles(f())) if callable(pix) else self._as_tiles(pix)) for ids, pix in requests]
         return self.engine.generate_stream(samples, batch_size=batch_size, max_new_tokens=max_new_tokens, eos_token_id=eos, stats=stats)
 
 

@@ -50,6 +50,13 @@ struct AttnArgs {
     void* out_fp8;            // LDS-DMA kernel, optional: instead of `out`, write e4m3(O * out_fp8_scale) bytes [total_q, ...] (row stride ldo8) —
     float out_fp8_scale;      // the o_proj operand of the fp8 schedule straight from the attention epilogue (no conversion launch)
     int ldo8;
+    // LDS-DMA kernel, optional (beside `out`): the MX fp4 image of the rounding residuals O - T(O) and its block scales, for the low-bit
+    // correction phase of the projection that consumes `out` (gemm.h LO4).  The image has its OWN k order: head h occupies the 32-element
+    // blocks [h * NDB, (h + 1) * NDB) — head_dim 128: the natural order; 72 / 96: every head padded to 96 (zero codes), so that no block
+    // straddles two heads (= two workgroups); the projection's weight image is laid out the same way (leopard_amd.engine).
+    uint8_t* out4;            // [total_q, ld_out4 bytes]: head h, block db at byte (h * NDB + db) * 16
+    uint8_t* out4_scale;      // [total_q, ld_out4s]: byte h * NDB + db
+    int ld_out4, ld_out4s;
     int gqa_pack;             // LDS-DMA kernel, decode: a workgroup's 4 waves take the 4 query heads of ONE kv head (32 query rows per block)
     int check_k_extent;       // 1 = the launcher could not bound a sequence's K / V extent (< 4 GiB): the kernel checks (and traps)
 };
@@ -609,6 +616,40 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
                 if (my_q < len_q && d < D) *(u32x2*)(o8 + d) = u32x2{a, b};
             }
         return;
+    }
+    if (p.out4) {
+        // (workgroup-uniform) residual image of the rows about to be rounded.  Block db of this head = the 16 values of this lane + the 16 of
+        // its half-wave partner: block maximum by one lane exchange; this lane's codes are two dwords (quads qd = 0, 1 and 2, 3: 16 bits per
+        // quad); after trading one dword the low lane owns bytes 0..7 of the block (d 0..15) and the high lane bytes 8..15 — the same trade
+        // as the 16-bit rows below.
+        const long row4 = q_beg + imin(my_q, len_q - 1);
+        uint8_t* o4 = p.out4 + row4 * p.ld_out4 + head * (NDB * 16);
+        uint8_t* s4 = p.out4_scale + row4 * p.ld_out4s + head * NDB;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            float lo[16], amax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = db * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                const float y = o_acc[db][r] * inv;
+                lo[r] = d < D ? y - (float)(T)y : 0.f;
+                amax = fmaxf(amax, __builtin_fabsf(lo[r]));
+            }
+            amax = xhalf_max(amax);
+            float scale, sinv;
+            const unsigned sb = lo4_scale_byte(amax, scale, sinv);
+            const float g0[8] = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+            const float g1[8] = {lo[8], lo[9], lo[10], lo[11], lo[12], lo[13], lo[14], lo[15]};
+            unsigned a = fp4_pack8(g0, scale, sinv), b = fp4_pack8(g1, scale, sinv);
+            swap_hi_lo(a, b);                                      // low lane: b = partner's first dword; high lane: a = partner's second
+            const unsigned own = fh ? b : a, other = fh ? a : b;
+            const unsigned w0 = fh ? ((other & 0xffffu) | (own << 16)) : ((own & 0xffffu) | (other << 16));
+            const unsigned w1 = fh ? ((other >> 16) | (own & 0xffff0000u)) : ((own >> 16) | (other & 0xffff0000u));
+            if (my_q < len_q) {
+                *(u32x2*)(o4 + db * 16 + fh * 8) = u32x2{w0, w1};
+                if (fh == 0) s4[db] = (uint8_t)sb;
+            }
+        }
     }
     T* o_row = (T*)p.out + (long)(q_beg + imin(my_q, len_q - 1)) * p.ldo + head * D;
 #pragma unroll

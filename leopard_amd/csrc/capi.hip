@@ -338,7 +338,7 @@ int launch_attn_r64(const AttnArgs& a, int n_seq, int max_q, void* stream) {
 template <typename T, int D>
 bool attn_r64_applies(const AttnArgs& a, int max_q, int use_tr) {
     if (D != 128 || !use_tr || !g_attn_dma.load() || !g_attn_rows64.load() || max_q < g_attn_rows64_min.load()) return false;
-    if (!a.out || a.out_fp8 || a.out_f32 || a.n_splits > 1 || a.k_len || a.gqa_pack || a.check_k_extent) return false;   // self-attention, 16-bit output only
+    if (!a.out || a.out_fp8 || a.out_f32 || a.out4 || a.n_splits > 1 || a.k_len || a.gqa_pack || a.check_k_extent) return false;   // self-attention, 16-bit output only
     // the ring requests tiles up to two past the end (range-checked to zeros): their 32-bit offsets must not wrap
     return ((long)(max_q + 4 * ATT_BKV) * a.ldk + D) * 2 < (1L << 32) && ((long)(max_q + 4 * ATT_BKV) * a.ldv + D) * 2 < (1L << 32);
 }
@@ -812,11 +812,11 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     a.a4_bytes = a.w4_bytes = a.a4s_bytes = 0;
     a.out4 = nullptr; a.out4_scale = nullptr; a.ld_out4 = a.ld_out4s = 0;
     if (lo) {                                                       // low-bit correction phase (lmi_gemm_lo4 / lmi_rmsnorm_rope_lo4)
-        const int k4 = (K + 255) / 256 * 256;
-        if (!lo->a4 || !lo->a4_scale || !lo->w4 || !lo->w4_scale || lo->k4 != k4 || K < 128 || a_mode != LMI_A_PLAIN || (lo->lda4 & 15) ||
+        const int k4 = lo->k4;          // K rounded up to 256, or wider: the images may carry their own (padded) k order — see lmi_attn_varlen_fwd_lo4
+        if (!lo->a4 || !lo->a4_scale || !lo->w4 || !lo->w4_scale || k4 < K || (k4 & 255) || K < 128 || a_mode != LMI_A_PLAIN || (lo->lda4 & 15) ||
             (lo->ldw4 & 15) || lo->lda4 < k4 / 2 || lo->ldw4 < k4 / 2 || (lo->lds4 & 3) || lo->lds4 < k4 / 32 || !aligned16(lo->a4) || !aligned16(lo->w4) ||
             ((uintptr_t)lo->a4_scale & 3))
-            return fail(LMI_EINVAL, "%s: lo4 needs all four images, k4 == K rounded up to 256 (%d), K >= 128, a plain A, 16-byte aligned images with "
+            return fail(LMI_EINVAL, "%s: lo4 needs all four images, k4 %% 256 == 0 and >= K (%d), K >= 128, a plain A, 16-byte aligned images with "
                         "lda4 / ldw4 %% 16 == 0 and >= k4 / 2, lds4 %% 4 == 0 and >= k4 / 32", who, k4);
         if ((lo->out4 != nullptr) != (lo->out4_scale != nullptr) ||
             (lo->out4 && (((uintptr_t)lo->out4 & 3) || (lo->ld_out4 & 3) || lo->ld_out4s <= 0 ||
@@ -952,7 +952,7 @@ int lmi_norm_lo4(const float* x, const float* w, const float* b, void* out, void
 }
 
 int lmi_quantize_w4(const void* W, void* w4, void* scales, int N, int K, int K4, int ldw, int ld4, int dtype, void* stream) {
-    if (!W || !w4 || !scales || N <= 0 || K <= 0 || (K & 7) || K4 != (K + 255) / 256 * 256 || (ldw & 7) || ldw < K || (ld4 & 15) || ld4 < K4 / 2 ||
+    if (!W || !w4 || !scales || N <= 0 || K <= 0 || (K & 7) || K4 < K || (K4 & 255) || (ldw & 7) || ldw < K || (ld4 & 15) || ld4 < K4 / 2 ||
         !aligned16(W) || !aligned16(w4))
         return fail(LMI_EINVAL, "lmi_quantize_w4: bad argument (N=%d K=%d K4=%d; K %% 8 == 0, K4 = K rounded up to 256, ld4 %% 16 == 0 and >= K4 / 2)", N, K, K4);
     const int grid = (N + 3) / 4;
@@ -1039,8 +1039,16 @@ int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int
 
 static int attn_varlen_entry(const char* who, const void* q, const void* k, const void* v, void* out, float* out_f32, int ldo32, void* out_fp8, int ldo8, float out_fp8_scale,
                              const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
-                             int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream) {
+                             int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream,
+                             void* out4 = nullptr, void* out4_scale = nullptr, int ld_out4 = 0, int ld_out4s = 0) {
     if (!q || !k || !v || (!out && !out_fp8 && !out_f32) || !cu_seqlens_q || !cu_seqlens_k) return fail(LMI_EINVAL, "%s: null pointer", who);
+    if (out4) {
+        const int ndb = (head_dim + 31) / 32;
+        if (!out || !out4_scale || !use_tr || !g_attn_dma.load() || ((uintptr_t)out4 & 7) || (ld_out4 & 7) || ld_out4 < n_heads * ndb * 16 ||
+            ld_out4s < n_heads * ndb)
+            return fail(LMI_EINVAL, "%s: the residual image needs the 16-bit output, the LDS-DMA kernel, an 8-byte aligned image with ld_out4 %% 8 == 0 and "
+                        ">= n_heads * ceil(head_dim / 32) * 16 bytes, ld_out4s >= n_heads * ceil(head_dim / 32)", who);
+    }
     if (n_seq < 0 || max_seqlen_q < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads))
         return fail(LMI_EINVAL, "%s: bad head counts (%d, %d)", who, n_heads, n_kv_heads);
     if (head_dim != 128 && head_dim != 96 && head_dim != 72)
@@ -1056,6 +1064,7 @@ static int attn_varlen_entry(const char* who, const void* q, const void* k, cons
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = nullptr;
     a.out_fp8 = out_fp8; a.ldo8 = ldo8; a.out_fp8_scale = out_fp8_scale; a.out_f32 = out_f32; a.ldo32 = ldo32;
+    a.out4 = (uint8_t*)out4; a.out4_scale = (uint8_t*)out4_scale; a.ld_out4 = ld_out4; a.ld_out4s = ld_out4s;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
     a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr; a.gqa_pack = 0;
     a.check_k_extent = 1;
@@ -1142,6 +1151,14 @@ int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* 
                              n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, 0, scale, causal, window, 1, dtype, stream);
 }
 
+int lmi_attn_varlen_fwd_lo4(const void* q, const void* k, const void* v, void* out, void* out4, void* out4_scale, int ld_out4, int ld_out4s,
+                            const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                            int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int dtype, void* stream) {
+    if (!out || !out4 || !out4_scale) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd_lo4: null pointer");
+    return attn_varlen_entry("lmi_attn_varlen_fwd_lo4", q, k, v, out, nullptr, 0, nullptr, 0, 0.f, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads,
+                             n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, causal, window, 1, dtype, stream, out4, out4_scale, ld_out4, ld_out4s);
+}
+
 int lmi_split_hi_lo(const float* x, void* out, int M, int K, int ldx, int ldo, int dtype, void* stream) {
     if (!x || !out || M < 0 || K <= 0 || (K & 7) || (ldx & 3) || (ldo & 7) || ldo < 2 * K || !aligned16(x) || !aligned16(out))
         return fail(LMI_EINVAL, "lmi_split_hi_lo: bad argument (M=%d K=%d ldx=%d ldo=%d; K %% 8 == 0, ldo >= 2K)", M, K, ldx, ldo);
@@ -1217,6 +1234,7 @@ static int attn_decode_entry(const char* who, const void* q, const void* k, cons
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = k_len;
     a.out_fp8 = nullptr; a.ldo8 = 0; a.out_fp8_scale = 0.f; a.out_f32 = nullptr; a.ldo32 = 0;
+    a.out4 = nullptr; a.out4_scale = nullptr; a.ld_out4 = a.ld_out4s = 0;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
     if (((long)max_seqlen_k * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_k * ldv + head_dim) * 2 >= (1L << 32))
         return fail(LMI_EINVAL, "%s: one sequence's K / V rows span >= 4 GiB (max_seqlen_k %d, ldk %d, ldv %d)", who, max_seqlen_k, ldk, ldv);

@@ -112,6 +112,17 @@ LMI_DEV f32x16 mfma32_fp4(u32x4 a, u32x4 b, f32x16 c, int scale_a, int scale_b) 
     const v8i av = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0}, bv = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, SEL_A, scale_a, SEL_B, scale_b);
 }
+// 8 fp32 values / scale -> 8 e2m1 codes in one dword (element e in nibble e): v_cvt_scalef32_pk_fp4_f32, two elements per instruction.
+// Round to nearest even, saturating at 6 — bit for bit the software rule to_fp4() below (every tie and the saturation range checked on
+// the device: tools/ubench/mfma_fp4_layout.hip, profiles/r05_mfma_fp4_layout.txt), which the host emulator build uses.
+LMI_DEV unsigned fp4_pack8(const float (&v)[8], float scale, float) {
+    unsigned r = 0;
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[0], v[1], scale, 0);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[2], v[3], scale, 1);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[4], v[5], scale, 2);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[6], v[7], scale, 3);
+    return r;
+}
 // max over the 4 lanes of a lane quad (lanes 4q .. 4q+3), DPP quad permutes: no LDS traffic
 LMI_DEV float quad_max(float v) {
     int x = __builtin_bit_cast(int, v);
@@ -498,13 +509,21 @@ LMI_DEV unsigned to_fp4(float x) {
     return s | (unsigned)(int)q;
 }
 // MX block scale of a block whose largest magnitude is `amax`: E8M0 byte of 2^(floor(log2 amax) - 2) (the block maximum lands in [4, 8):
-// values above 6 saturate), and the exact reciprocal of that power of two.  amax = 0 (or a denormal): byte 0 and inv 0 — every code is 0.
-LMI_DEV unsigned lo4_scale_byte(float amax, float& inv) {
+// values above 6 saturate), that power of two and its exact reciprocal.  amax = 0 (or a denormal): byte 0, scale 1, inv 0 — every code is 0.
+LMI_DEV unsigned lo4_scale_byte(float amax, float& scale, float& inv) {
     const int eb = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u) - 2;
-    if (eb < 1) { inv = 0.f; return 0u; }
+    if (eb < 1) { scale = 1.0f; inv = 0.f; return 0u; }
+    scale = __builtin_bit_cast(float, (unsigned)eb << 23);
     inv = __builtin_bit_cast(float, (unsigned)(254 - eb) << 23);
     return (unsigned)eb;
 }
+#ifdef LMI_EMU
+inline unsigned fp4_pack8(const float (&v)[8], float, float inv) {
+    unsigned r = 0;
+    for (int e = 0; e < 8; ++e) r |= to_fp4(v[e] * inv) << (4 * e);
+    return r;
+}
+#endif
 // One lane's share of a low-bit residual image: y[0..7] are 8 consecutive fp32 values of a row, the 4 lanes of a lane quad hold one
 // 32-element block.  Returns the 8 codes of the lane (element e in nibble e) for the residuals y - float(T(y)) and, in every lane of the
 // quad, the block's E8M0 scale byte.  hi[e] = T(y[e]) is what the 16-bit pass multiplies.
@@ -518,12 +537,9 @@ LMI_DEV unsigned lo4_encode8(const float (&y)[8], typename vec_of<T>::x8& hi, un
         amax = fmaxf(amax, __builtin_fabsf(lo[e]));
     }
     amax = quad_max(amax);
-    float inv;
-    scale_byte = lo4_scale_byte(amax, inv);
-    unsigned codes = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) codes |= to_fp4(lo[e] * inv) << (4 * e);
-    return codes;
+    float scale, inv;
+    scale_byte = lo4_scale_byte(amax, scale, inv);
+    return fp4_pack8(lo, scale, inv);
 }
 
 LMI_DEV int imin(int a, int b) { return a < b ? a : b; }

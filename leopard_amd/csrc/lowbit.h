@@ -61,14 +61,16 @@ __global__ void __launch_bounds__(256) quantize_w4_kernel(const T* W, uint8_t* w
         for (int e = 0; e < 8; ++e) amax = fmaxf(amax, __builtin_fabsf((float)v[e]));
     }
     amax = wave_max(amax);
-    float inv;
-    const unsigned sb = lo4_scale_byte(amax, inv);
+    float scale, inv;
+    const unsigned sb = lo4_scale_byte(amax, scale, inv);
     for (int c = lane; c < cpr; c += 64) {
         unsigned codes = 0;
         if (c < creal) {
             const T8 v = *(const T8*)(wr + c * 8);
+            float f[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) codes |= to_fp4((float)v[e] * inv) << (4 * e);
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+            codes = fp4_pack8(f, scale, inv);
         }
         *(unsigned*)(w4 + (long)row * ld4 + c * 4) = codes;
     }

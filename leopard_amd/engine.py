@@ -170,12 +170,21 @@ class LeopardEngine:
         north_star's 1e-3 at full depth), "split" (hi + lo 16-bit operand pairs at 2 K: the most exact, ~1.9 x the time)."""
         return "split" if self.split_operands else ("lo4" if self.lo4 else "fast")
 
+    def lo4_supported(self) -> bool:
+        """The lo4 schedule rides on the fused Llama / Mistral layer (head_dim 128, rope-ordered q|k|v rows, hidden % 256 == 0) and on
+        32-element blocks along every contraction axis (hidden sizes and FFN widths % 32 == 0); one rank, 16-bit compute type."""
+        tc, vc, W = self.cfg.text_config, self.cfg.vision_config, self.W
+        return bool(self.tp_size == 1 and self.dtype in (torch.float16, torch.bfloat16) and tc.head_dim == 128 and tc.hidden_size % 256 == 0
+                    and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None and tc.intermediate_size % 32 == 0 and vc.hidden_size % 32 == 0)
+
     @precision.setter
     def precision(self, mode: str):
         if mode not in ("fast", "lo4", "split"):
             raise ValueError(f"precision must be 'fast', 'lo4' or 'split', not {mode!r}")
         if mode != "fast" and self.tp_size > 1:
             raise ValueError("the precision modes run on one rank (tensor-parallel engines keep the fast schedule)")
+        if mode == "lo4" and not self.lo4_supported():
+            raise ValueError("precision 'lo4' needs the fused Llama / Mistral layer shape (head_dim 128, hidden % 256 == 0): use 'split'")
         self.split_operands, self.lo4 = mode == "split", mode == "lo4"
         self._encode_graphs.clear()                           # captured encodes replay the launches of the old schedule
 
@@ -499,33 +508,34 @@ class LeopardEngine:
         lw = self._lo4_w
         if lw is None:
             from .weights import as_row_major
-            q = lambda w: self.ops.quantize_w4(as_row_major(w).contiguous())
-            W = self.W
+            q = lambda w, head_pad=None: self.ops.quantize_w4(as_row_major(w).contiguous(), head_pad=head_pad)
+            W, vc = self.W, self.cfg.vision_config
+            vhp = (vc.num_attention_heads, vc.head_dim)          # out_proj's image in the per-head padded k order of the attention's residual image
             lw = self._lo4_w = {
-                "vit": [(q(L.qkv_w), q(L.o_w), q(L.fc1_w), q(L.fc2_w)) for L in W.vit_layers],
+                "vit": [(q(L.qkv_w), q(L.o_w, vhp), q(L.fc1_w), q(L.fc2_w)) for L in W.vit_layers],
                 "llm": [(q(L.qkv_w_rope if L.qkv_w_rope is not None else L.qkv_w), q(L.o_w), q(L.gu_w), q(L.down_w)) for L in W.llm_layers]}
         return lw
 
-    def _lo4_act(self, rows: int, width: int):
-        from .ops import Lo4Act
-        return Lo4Act.empty(rows, width, self.dtype, self.device)
+    def _lo4_act(self, rows: int, width: int, heads: Optional[tuple] = None):
+        """Operand pair buffers; ``heads`` = (n_heads, head_dim): an attention output (image in the per-head padded k order)."""
+        from .ops import Lo4Act, lo4_head_k4
+        return Lo4Act.empty(rows, width, self.dtype, self.device, k4=lo4_head_k4(*heads) if heads else None)
 
     def _vit_layers_lo4(self, x: torch.Tensor, n: int) -> torch.Tensor:
         """The SigLIP layers with the low-bit correction phase: the LayerNorms and fc1's GELU epilogue hand over T(y) + the fp4 image of
-        y - T(y) directly; the attention hands over fp32, split by lmi_split_lo4.  q / k / v and the attention arithmetic stay 16-bit."""
+        y - T(y) directly, and so does the attention kernel (lmi_attn_varlen_fwd_lo4: every head padded to 96 slots in the image, out_proj's
+        weight image laid out to match).  q / k / v and the attention arithmetic stay 16-bit."""
         ops, W, vc = self.ops, self.W, self.cfg.vision_config
         T, D, H, hd = vc.num_patches, vc.hidden_size, vc.num_attention_heads, vc.head_dim
         M = n * T
-        h, att, ff = self._lo4_act(M, D), self._lo4_act(M, D), self._lo4_act(M, W.vit_ff)
-        a32 = self._empty(M, D, dtype=torch.float32)
+        h, att, ff = self._lo4_act(M, D), self._lo4_act(M, D, heads=(H, hd)), self._lo4_act(M, W.vit_ff)
         qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0])
         cu = self._vit_cu_cache[n]
         scale = hd ** -0.5
         for li, (L, (qkv4, o4, fc14, fc24)) in enumerate(zip(W.vit_layers, self._lo4_weights()["vit"])):
             ops.norm_lo4(x, L.ln1_w, L.ln1_b, h, vc.layer_norm_eps)
             ops.gemm_lo4(h, L.qkv_w, qkv4, qkv, bias=L.qkv_b)
-            ops.attention_f32out(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a32, cu, cu, T, H, H, hd, scale, False)
-            ops.split_lo4(a32, att)
+            ops.attention_lo4(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, cu, cu, T, H, H, hd, scale, False)
             ops.gemm_lo4(att, L.o_w, o4, x, bias=L.o_b, epilogue=_lib.EPI_RESIDUAL)
             ops.norm_lo4(x, L.ln2_w, L.ln2_b, h, vc.layer_norm_eps)
             ops.gemm_lo4(h, L.fc1_w, fc14, ff.hi, bias=L.fc1_b, act=_lib.ACT_GELU_TANH, out4=ff)
@@ -539,15 +549,14 @@ class LeopardEngine:
     def _llm_layers_lo4(self, x, cache, cu, cos, sin, max_len):
         """The Llama / Mistral layers with the low-bit correction phase, on the FUSED schedule of the fast path: the RMSNorms ride in the GEMM
         epilogues (the producers o_proj / down_proj also write the fp4 image of the residual of T(x gamma)), q|k|v + RoPE + KV append is one
-        launch, gate/up's SwiGLU epilogue writes down_proj's operand pair; only the attention output takes a launch of its own."""
+        launch, gate/up's SwiGLU epilogue writes down_proj's operand pair, the attention kernel o_proj's: no launch is added to the fast schedule."""
         ops, W, tc = self.ops, self.W, self.cfg.text_config
         S, D = x.shape
         (H, KV), hd = self._llm_heads(), tc.head_dim
         qw, kw = H * hd, KV * hd
         if not (hd == 128 and D % 256 == 0 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None):
             raise RuntimeError("precision 'lo4' needs head_dim 128 and the rope-ordered q|k|v weights (the fused Llama / Mistral schedule)")
-        h, att, gu = self._lo4_act(S, D), self._lo4_act(S, qw), self._lo4_act(S, W.llm_ff)
-        a32 = self._empty(S, qw, dtype=torch.float32)
+        h, att, gu = self._lo4_act(S, D), self._lo4_act(S, qw, heads=(H, hd)), self._lo4_act(S, W.llm_ff)
         qkv = self._empty(S, qw + 2 * kw)
         parts = (D + 63) // 64
         sq_a, sq_b = self._empty(S, parts, dtype=torch.float32), self._empty(S, parts, dtype=torch.float32)
@@ -558,9 +567,8 @@ class LeopardEngine:
                 ops.norm_lo4(x, L.in_norm, None, h, tc.rms_norm_eps)
             ops.rmsnorm_rope_lo4(h, L.qkv_w_rope, qkv4, qkv, None if i == 0 else sq_b, tc.rms_norm_eps, cos, sin,
                                  cache.k[i] if cache else None, cache.v[i] if cache else None, 0, H, KV, hd)
-            ops.attention_f32out(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], a32, cu, cu, max_len, H, KV, hd, scale, True,
-                                 window=tc.sliding_window or 0)
-            ops.split_lo4(a32, att)
+            ops.attention_lo4(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], att, cu, cu, max_len, H, KV, hd, scale, True,
+                              window=tc.sliding_window or 0)
             ops.gemm_lo4(att, L.o_w, o4, x, epilogue=_lib.EPI_RESIDUAL, norm_out=h.hi, norm_gamma=L.post_norm, rowsq_out=sq_a, out4=h)
             ops.gemm_lo4(h, L.gu_w, gu4, gu.hi, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq_a, norm_dim=D, norm_eps=tc.rms_norm_eps, out4=gu)
             if i + 1 < n_layers:

@@ -27,6 +27,11 @@ def lo4_k4(K: int) -> int:
     return (K + 255) // 256 * 256
 
 
+def lo4_head_k4(n_heads: int, head_dim: int) -> int:
+    """Width of the per-head padded k order of an attention output's residual image (lmi_attn_varlen_fwd_lo4)."""
+    return lo4_k4(n_heads * ((head_dim + 31) // 32) * 32)
+
+
 class Lo4Act:
     """One A operand of a GEMM with the low-bit correction phase (include/leopard_amd.h ``lmi_lo4``): ``hi`` = T(x) [M, K], ``img`` = the
     fp4 (e2m1) image of x - T(x) [M, K4 / 2] bytes, ``sc`` = its E8M0 block scales [M, K4 / 32].  The three are views into caller-owned
@@ -36,15 +41,16 @@ class Lo4Act:
     def __init__(self, hi: torch.Tensor, img: torch.Tensor, sc: torch.Tensor):
         self.hi, self.img, self.sc = hi, img, sc
         self.K = hi.shape[1]
-        self.K4 = lo4_k4(self.K)
-        assert img.dtype == torch.uint8 and sc.dtype == torch.uint8 and img.shape == (hi.shape[0], self.K4 // 2) and sc.shape[0] == hi.shape[0]
+        self.K4 = img.shape[1] * 2          # lo4_k4(K), or wider when the image carries a padded k order (attention outputs, head_dim 72 / 96)
+        assert img.dtype == torch.uint8 and sc.dtype == torch.uint8 and self.K4 % 256 == 0 and self.K4 >= self.K and sc.shape[0] == hi.shape[0] == img.shape[0]
         assert sc.shape[1] >= self.K4 // 32 and sc.stride(0) % 4 == 0 and img.stride(0) % 16 == 0
 
     @staticmethod
-    def empty(M: int, K: int, dtype, device) -> "Lo4Act":
-        k4 = lo4_k4(K)
-        return Lo4Act(torch.empty(M, K, dtype=dtype, device=device), torch.empty(M, k4 // 2, dtype=torch.uint8, device=device),
-                      torch.empty(M, k4 // 32, dtype=torch.uint8, device=device))
+    def empty(M: int, K: int, dtype, device, k4: Optional[int] = None) -> "Lo4Act":
+        alloc = torch.zeros if k4 else torch.empty      # a padded k order: the producer writes its own blocks only, the padding stays zero
+        k4 = k4 or lo4_k4(K)
+        return Lo4Act(torch.empty(M, K, dtype=dtype, device=device), alloc(M, k4 // 2, dtype=torch.uint8, device=device),
+                      alloc(M, k4 // 32, dtype=torch.uint8, device=device))
 
 
 class Lo4Weight:
@@ -393,15 +399,33 @@ class Ops:
             d.out4, d.out4_scale, d.ld_out4, d.ld_out4s = out4.img.data_ptr(), out4.sc.data_ptr(), out4.img.stride(0), out4.sc.stride(0)
         return d
 
-    def quantize_w4(self, w: torch.Tensor) -> Lo4Weight:
-        """fp4 image + per-row E8M0 scales of a ROW-MAJOR 16-bit weight [N, K] (lmi_quantize_w4; once, at load)."""
+    def quantize_w4(self, w: torch.Tensor, head_pad: Optional[tuple] = None) -> Lo4Weight:
+        """fp4 image + per-row E8M0 scales of a ROW-MAJOR 16-bit weight [N, K] (lmi_quantize_w4; once, at load).  ``head_pad`` = (n_heads,
+        head_dim): the image in the per-head padded k order of an attention output's residual image (lmi_attn_varlen_fwd_lo4)."""
         assert not getattr(w, "_lmi_packed", False) and w.stride(1) == 1
+        if head_pad is not None and head_pad[1] % 32:
+            H, hd = head_pad
+            nb = (hd + 31) // 32 * 32
+            wp = torch.zeros(w.shape[0], lo4_head_k4(H, hd), dtype=w.dtype, device=w.device)
+            wp[:, :H * nb].view(w.shape[0], H, nb)[:, :, :hd] = w.view(w.shape[0], H, hd)
+            w = wp
         N, K = w.shape
         k4 = lo4_k4(K)
         img = torch.empty(N, k4 // 2, dtype=torch.uint8, device=w.device)
         sc = torch.empty(N, dtype=torch.uint8, device=w.device)
         self._check(self.lib.lmi_quantize_w4(_ptr(w), _ptr(img), _ptr(sc), N, K, k4, w.stride(0), img.stride(0), _DT[w.dtype], self._stream(w)))
         return Lo4Weight(img, sc)
+
+    def attention_lo4(self, q, k, v, act: Lo4Act, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, scale, causal, window=0):
+        """lmi_attn_varlen_fwd_lo4: act.hi = the 16-bit attention output rows, act.img / act.sc = the image of their rounding residual in the
+        per-head padded k order (act must have k4 = lo4_head_k4(n_heads, head_dim))."""
+        n_seq = cu_q.numel() - 1
+        assert act.K4 == lo4_head_k4(n_heads, head_dim)
+        self._check(self.lib.lmi_attn_varlen_fwd_lo4(_ptr(q), _ptr(k), _ptr(v), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), act.img.stride(0), act.sc.stride(0),
+                                                     _ptr(cu_q), _ptr(cu_k), n_seq, int(max_seqlen_q), n_heads, n_kv_heads, head_dim, q.stride(0), k.stride(0),
+                                                     v.stride(0), act.hi.stride(0), float(scale), int(bool(causal)), int(window), _DT[q.dtype],
+                                                     self._stream(act.hi)))
+        return act
 
     def split_lo4(self, x_f32: torch.Tensor, act: Lo4Act) -> Lo4Act:
         """act = (T(x), fp4 image of x - T(x), block scales) of the fp32 x [M, K] (lmi_split_lo4)."""

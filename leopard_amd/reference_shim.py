@@ -29,9 +29,10 @@ Two ways to use it, neither edits ``evaluations/``:
 Precision: EVAL:373 asks for ``torch_dtype=torch.float32``; the engine computes in a 16-bit MFMA operand type with fp32
 accumulation and fp32 residual streams (``LEOPARD_AMD_COMPUTE_DTYPE`` = f16 (default) | bf16).  That narrowing is NOT silent: every
 ``from_pretrained`` emits a ``UserWarning`` when the requested and the compute type differ and records both in
-``leopard_amd_run_info.json`` in the working directory — next to the shard files ``results_*`` the script writes — so that a result
-row can always be traced to the arithmetic that produced it.  ``LEOPARD_AMD_PRECISION=split`` selects the split-operand precision
-mode for the prefill (every layer-linear operand as a hi + lo pair of 16-bit values: full-depth logits within 1e-3 of fp32, ~1.8x the time).
+``leopard_amd_run_info.json`` in the checkpoint directory — next to the shard files ``*_shard_details.jsonl`` the script writes there
+(EVAL:496-497; ``LEOPARD_AMD_RUN_INFO_DIR`` overrides) — so that a result row can always be traced to the arithmetic that produced it.
+A float32 request is served by the ``lo4`` schedule (fp16 operands + the fp4 correction phase: full-depth logits within 1e-3 of fp32, ~1.2x the
+fast schedule's prefill time); ``LEOPARD_AMD_PRECISION`` = fast | lo4 | split overrides (split: hi + lo 16-bit operand pairs, ~1.9x).
 
 Smoke-run knobs (GPU-less containers / CI only; the product path needs none of them):
     LEOPARD_AMD_LIB             alternative C-ABI library (the CPU kernel-logic emulator build); implies host tensors
@@ -70,23 +71,35 @@ def _compute_dtype(default):
     return torch.bfloat16 if name.startswith("b") else torch.float16
 
 
-def _record_run_info(model_class: str, checkpoint: str, requested, compute) -> None:
-    """Side file of the result rows: what arithmetic the script's ``torch_dtype`` request was actually served with."""
+_PRECISION_TEXT = {"fast": "fast (one rounding per MFMA-operand hand-over)",
+                   "lo4": "lo4 (16-bit operands + the fp4 image of every layer-linear operand's rounding residual, same accumulators)",
+                   "split": "split operands (hi + lo 16-bit pairs, GEMMs at 2 K)"}
+
+
+def _record_run_info(model_class: str, checkpoint: str, requested, compute, precision: str = "fast") -> None:
+    """Side file of the result rows: what arithmetic the script's ``torch_dtype`` request was actually served with.  Written where the
+    script writes its result shards — the checkpoint directory (EVAL:496-497) — or ``LEOPARD_AMD_RUN_INFO_DIR``; a location that cannot be
+    written falls back to the working directory, then to the warning alone."""
     import json
     import warnings
     req, cmp_ = str(requested).replace("torch.", ""), str(compute).replace("torch.", "")
     if requested is not None and requested != compute:
         warnings.warn(f"{model_class}.from_pretrained: torch_dtype={req} was requested; leopard_amd computes with {cmp_} MFMA operands "
-                      f"(fp32 accumulation, fp32 residual streams) — recorded in leopard_amd_run_info.json", UserWarning, stacklevel=3)
+                      f"(fp32 accumulation, fp32 residual streams), precision mode {precision} — recorded in leopard_amd_run_info.json",
+                      UserWarning, stacklevel=3)
     info = {"model_class": model_class, "checkpoint": str(checkpoint), "requested_torch_dtype": req, "compute_dtype": cmp_,
             "accumulate_dtype": "float32", "residual_stream_dtype": "float32",
-            "precision_mode": "split operands (hi + lo 16-bit pairs, GEMMs at 2 K)" if os.environ.get("LEOPARD_AMD_PRECISION", "").lower() == "split" else "fast", "library": os.environ.get("LEOPARD_AMD_LIB") or "libleopard_amd.so",
+            "precision_mode": _PRECISION_TEXT.get(precision, precision), "library": os.environ.get("LEOPARD_AMD_LIB") or "libleopard_amd.so",
             "fallback_scorers": sorted(_FALLBACK_SCORERS)}
-    try:
-        with open("leopard_amd_run_info.json", "w") as f:
-            json.dump(info, f, indent=1)
-    except OSError:                                   # read-only working directory: the warning above still went out
-        pass
+    for d in (os.environ.get("LEOPARD_AMD_RUN_INFO_DIR"), str(checkpoint) if os.path.isdir(str(checkpoint)) else None, "."):
+        if not d:
+            continue
+        try:
+            with open(os.path.join(d, "leopard_amd_run_info.json"), "w") as f:
+                json.dump(info, f, indent=1)
+            return
+        except OSError:                               # read-only location: try the next one; the warning above went out either way
+            continue
 
 
 _FALLBACK_SCORERS = set()
@@ -118,18 +131,19 @@ def _llava_class():
         _pending = None
 
         def __init__(self, config):
-            path, compute_dtype, ops = type(self)._pending or (None, torch.float16, None)
+            path, compute_dtype, ops, req, precision = type(self)._pending or (None, torch.float16, None, torch.float32, None)
             if path is None:
                 raise RuntimeError("construct through from_pretrained(checkpoint_dir) — the engine streams the checkpoint's tensors")
-            super().__init__(config, lambda dev, dt: CheckpointSource(path, dev, dt), compute_dtype, ops)
+            super().__init__(config, lambda dev, dt: CheckpointSource(path, dev, dt), compute_dtype, ops, torch_dtype=req, precision=precision)
 
         @classmethod
-        def from_pretrained(cls, path, torch_dtype=torch.float32, compute_dtype=None, ops=None, **unused):
+        def from_pretrained(cls, path, torch_dtype=torch.float32, compute_dtype=None, ops=None, precision=None, **unused):
+            from .compat import resolve_precision
             cfg = load_config(path)
             if compute_dtype is None:                     # a 16-bit request is honoured as is; fp32 (EVAL:373) is served in 16 bits, loudly
                 compute_dtype = _compute_dtype(torch_dtype if torch_dtype in (torch.float16, torch.bfloat16) else torch.float16)
-            _record_run_info("LlavaForConditionalGeneration", path, torch_dtype, compute_dtype)
-            cls._pending = (path, compute_dtype, ops if ops is not None else _ops_from_env())
+            _record_run_info("LlavaForConditionalGeneration", path, torch_dtype, compute_dtype, resolve_precision(torch_dtype, compute_dtype, precision))
+            cls._pending = (path, compute_dtype, ops if ops is not None else _ops_from_env(), torch_dtype, precision)
             try:
                 return cls(cfg)
             finally:

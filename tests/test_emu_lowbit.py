@@ -319,3 +319,44 @@ def test_engine_lo4_mode_lands_on_the_oracle_prediction():
     assert torch.equal(eng.prefill(ids, tiles, all_logits=True).logits_all, base)
     with pytest.raises(ValueError):
         eng.precision = "fp64"
+
+
+@pytest.mark.parametrize("hd,H,KV,causal", [(128, 2, 1, True), (72, 8, 8, False)])
+def test_attention_lo4_image_is_the_oracle_rule_in_the_padded_head_order(ops, hd, H, KV, causal):
+    """lmi_attn_varlen_fwd_lo4: the 16-bit rows are those of lmi_attn_varlen_fwd bit for bit; the image, read back through the per-head padded
+    k order (head h -> blocks [h NB, (h + 1) NB)), is the oracle's MX e2m1 rule applied to (fp32 output - its 16-bit rounding) of every head
+    zero-padded to NB * 32; a GEMM whose weight image is built with the same head_pad consumes it."""
+    from leopard_amd.ops import lo4_head_k4
+    dtype = torch.float16
+    lens = [70, 45]
+    S = sum(lens)
+    cu = torch.tensor([0, 70, 115], dtype=torch.int32)
+    qkv = rnd((S, (H + 2 * KV) * hd), dtype, 60)
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + KV) * hd], qkv[:, (H + KV) * hd:]
+    plain = torch.empty(S, H * hd, dtype=dtype)
+    ops.attention(q, k, v, plain, cu, cu, max(lens), H, KV, hd, hd ** -0.5, causal)
+    o32 = torch.empty(S, H * hd, dtype=torch.float32)
+    ops.attention_f32out(q, k, v, o32, cu, cu, max(lens), H, KV, hd, hd ** -0.5, causal)
+    act = Lo4Act.empty(S, H * hd, dtype, "cpu", k4=lo4_head_k4(H, hd))
+    ops.attention_lo4(q, k, v, act, cu, cu, max(lens), H, KV, hd, hd ** -0.5, causal)
+    assert torch.equal(act.hi, plain)
+    nb = (hd + 31) // 32 * 32
+    lo = torch.zeros(S, H, nb)
+    lo[:, :, :hd] = (o32 - plain.float()).view(S, H, hd)
+    want = O._lo_round(lo.view(S, H * nb), "e2m1", 32)
+    got = decode_img(act.img, act.sc, H * nb)
+    assert torch.equal(got, want)
+    if H * nb < act.K4:
+        assert act.img[:, H * nb // 2:].abs().max() == 0 and act.sc[:, H * nb // 32:].abs().max() == 0
+    # the consuming projection: weight image in the same padded order
+    N = 128
+    w = rnd((N, H * hd), dtype, 61, 0.1)
+    w4 = ops.quantize_w4(w, head_pad=(H, hd))
+    out = torch.empty(S, N, dtype=torch.float32)
+    ops.gemm_lo4(act, w, w4, out, epilogue=_lib.EPI_STORE_F32)
+    wq = O._lo_round(w.float(), "e2m1", 0)
+    ref = plain.float() @ w.float().T + want.view(S, H, nb)[:, :, :hd].reshape(S, H * hd) @ wq.T
+    assert (out - ref).abs().max() <= 1e-4 * ref.abs().max()
+    exact = o32 @ w.float().T
+    base = plain.float() @ w.float().T
+    assert (out - exact).pow(2).mean().sqrt() < 0.35 * (base - exact).pow(2).mean().sqrt()

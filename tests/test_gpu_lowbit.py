@@ -192,8 +192,13 @@ def test_gemm_lo4_production_shapes(ops, name, M, N, K, kind):
     elif kind == "producer":
         xs = a[0][rows]
         assert (xs - (1.0 + acc)).abs().max().item() <= 3e-4 * scale
-        assert torch.equal(a[1][rows], (xs * gamma).to(dtype))
-        assert torch.equal(decode_img(a[2][rows], a[3][rows], N).cpu(), host_lo_round(xs * gamma - a[1][rows].float(), 32))
+        hx = xs * gamma
+        hi = a[1][rows].float()
+        assert ((hi - hx).abs() <= eps(dtype) * hx.abs() + 2.0 ** -24).all()               # one rounding of x * gamma (the device may fuse the product into the conversion)
+        got, want = decode_img(a[2][rows], a[3][rows], N).cpu(), host_lo_round(hx - hi, 32)
+        assert (got != want).float().mean().item() < 2e-3                                    # the same rule; a fused multiply-subtract moves a few ties
+        before, after = (hx - hi).pow(2).mean().sqrt().item(), (hx - hi - got.to(DEV)).pow(2).mean().sqrt().item()
+        assert after < 0.25 * before, (before, after)
     else:
         g = acc.view(-1, N // 64, 2, 32)
         y = (torch.nn.functional.silu(g[:, :, 0]) * g[:, :, 1]).reshape(-1, N // 2)
@@ -230,3 +235,37 @@ def test_rmsnorm_rope_lo4_at_the_llama_shape(ops):
     ref = torch.cat([qk * c + rot * s, acc[:, nq + nkv:]], dim=1).reshape(len(rows), -1)
     assert ((qkv[rows].float() - ref).abs() / (1 + ref.abs())).max().item() <= 2 * eps(dtype)
     assert torch.equal(kc, qkv[:, nq * D:(nq + nkv) * D]) and torch.equal(vc, qkv[:, (nq + nkv) * D:])
+
+
+@pytest.mark.parametrize("name,lens,H,KV,hd,causal", [("llama", [7187], 32, 8, 128, True), ("siglip", [676] * 42, 16, 16, 72, False)])
+def test_attention_lo4_at_the_production_shapes(ops, name, lens, H, KV, hd, causal):
+    """lmi_attn_varlen_fwd_lo4 at the C3 shapes: the 16-bit rows == lmi_attn_varlen_fwd bit for bit, the image == the host rule on
+    (fp32 output - 16-bit rows) in the per-head padded order (up to a few ties moved by fused multiply-subtracts), three launches bit-identical."""
+    from leopard_amd.ops import lo4_head_k4
+    dtype = torch.float16
+    S = sum(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    qkv = rnd((S, (H + 2 * KV) * hd), dtype, 70)
+    q, k, v = qkv[:, :H * hd], qkv[:, H * hd:(H + KV) * hd], qkv[:, (H + KV) * hd:]
+    plain = torch.empty(S, H * hd, dtype=dtype, device=DEV)
+    ops.attention(q, k, v, plain, cu, cu, max(lens), H, KV, hd, hd ** -0.5, causal)
+    o32 = torch.empty(S, H * hd, dtype=torch.float32, device=DEV)
+    ops.attention_f32out(q, k, v, o32, cu, cu, max(lens), H, KV, hd, hd ** -0.5, causal)
+    acts = []
+    for _ in range(3):
+        act = Lo4Act.empty(S, H * hd, dtype, DEV, k4=lo4_head_k4(H, hd))
+        ops.attention_lo4(q, k, v, act, cu, cu, max(lens), H, KV, hd, hd ** -0.5, causal)
+        acts.append(act)
+    assert all(torch.equal(acts[0].hi, a.hi) and torch.equal(acts[0].img, a.img) and torch.equal(acts[0].sc, a.sc) for a in acts[1:])
+    act = acts[0]
+    assert torch.equal(act.hi, plain)
+    nb = (hd + 31) // 32 * 32
+    rows = torch.arange(0, S, 37, device=DEV)
+    lo = torch.zeros(len(rows), H, nb, device=DEV)
+    lo[:, :, :hd] = (o32[rows] - plain[rows].float()).view(len(rows), H, hd)
+    want = host_lo_round(lo.view(len(rows), H * nb), 32)
+    got = decode_img(act.img[rows], act.sc[rows], H * nb).cpu()
+    assert (got != want).float().mean().item() < 2e-3
+    assert ((lo.view(len(rows), -1).cpu() - got).pow(2).mean().sqrt() / lo.pow(2).mean().sqrt().cpu()).item() < 0.25
+    if H * nb < act.K4:
+        assert act.img[:, H * nb // 2:].abs().max() == 0
