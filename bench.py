@@ -40,6 +40,7 @@ from leopard_amd.synth import synth_image_u8, synth_prompt_ids  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_FP8_TFLOPS = 5000.0 # dense fp8 peak (same guide); only the --dtype fp8 line is priced against it
+MFMA_PEAK_FP4_TFLOPS = 10000.0  # dense fp4 / fp6 peak (same guide): the correction phase of the lo4 schedule
 HBM_PEAK_GBS = 8000.0
 
 
@@ -55,6 +56,12 @@ def algorithmic_flops(cfg, n_tiles: int, S: int) -> dict:
     head = 2 * t.hidden_size * t.vocab_size
     return {"vit": n_tiles * vit_tile, "projector": n_tiles * proj_tile, "llm_linear": lin, "llm_attention": attn,
             "lm_head_last": head, "total": n_tiles * (vit_tile + proj_tile) + lin + attn + head}
+
+
+def vit_attention_flops(cfg) -> int:
+    """QK^T + PV of one ViT input through all SigLIP layers (part of algorithmic_flops()["vit"]; not a layer linear: no correction phase)."""
+    v = cfg.vision_config
+    return v.num_hidden_layers * 4 * v.num_patches * v.num_patches * v.hidden_size
 
 
 def make_sample(cfg, n_images: int, width: int, height: int, seed: int):
@@ -438,6 +445,8 @@ def bench_c5(args, dev, dtype, rank, world, D):
                 eng.graph_encode = keep
         out["roofline"] = roofline_from_timer(ops, eager_pass, 1, args.dtype == "fp8")
         out["roofline"]["traffic_source"] = "not collected for this workload"
+    if rank == 0 and world == 1 and args.no_cpu_baseline and args.cpu_tflops > 0:
+        out["cpu_baseline"] = extrapolated_cpu_baseline(args.cpu_tflops, n_samples * n_img, fl)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tflops, t = cpu_baseline_sample(cfg)
         out["cpu_baseline"] = {"value": round(n_samples * n_img / (fl / 1e12 / tflops), 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -510,6 +519,8 @@ def bench_idefics2(args, dev, dtype, rank, world, D):
     if rank == 0 and not tp and not args.no_roofline:
         out["roofline"] = roofline_from_timer(ops, step, 1, False)
         out["roofline"]["traffic_source"] = "not collected for this workload"
+    if rank == 0 and world == 1 and args.no_cpu_baseline and args.cpu_tflops > 0:
+        out["cpu_baseline"] = extrapolated_cpu_baseline(args.cpu_tflops, n_img, total)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tflops, t = cpu_baseline_idefics2()
         out["cpu_baseline"] = {"value": round(n_img / (total / 1e12 / tflops), 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -565,13 +576,59 @@ def measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler):
             "prefill_mfma_frac_of_n_gpus": round(fl["total"] / 1e12 / (elapsed / args.steps) / (MFMA_PEAK_TFLOPS * world), 4)}
 
 
-DEFAULT_PRECISION = "fast"
+DEFAULT_PRECISION = "lo4"     # the schedule whose full-depth logits are within north_star's 1e-3 of the fp32 reference
 PRECISION_NOTE = {
     "fast": "fast: one rounding of every activation to the 16-bit compute type per MFMA-operand hand-over",
     "lo4": "lo4: fast + the MX fp4 image of every layer-linear operand's rounding residual multiplied with an fp4 weight image into the same "
            "accumulators (v_mfma_scale_f32_32x32x64_f8f6f4, + 25 % matrix time; algorithmic FLOPs below are the model's, not the extra MFMA work)",
     "split": "split operands: every A operand of every ViT / LLM layer linear handed over as hi + lo 16-bit values, GEMMs at 2 K "
              "(algorithmic FLOPs below are the model's, not the doubled MFMA work)"}
+
+
+def extrapolated_cpu_baseline(cpu_tflops: float, units: float, total_flops: float) -> dict:
+    """cpu_baseline of an other_configs child run: the host TFLOP/s the PARENT run measured on its bounded CPU-oracle sample (fp32 PyTorch
+    restatement of the reference path; cpu_baseline_sample), scaled to this workload by algorithmic FLOPs."""
+    return {"value": round(units / (total_flops / 1e12 / cpu_tflops), 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"CPU oracle bounded sample of the parent bench run ({cpu_tflops:.3f} TFLOP/s on {torch.get_num_threads()} host threads), scaled to this "
+                      f"workload ({total_flops / 1e12:.1f} TFLOP per step) by algorithmic FLOPs"}
+
+
+OTHER_CONFIGS = [   # (key, BASELINE.json configuration, extra argv) — short runs appended to the default line (VERDICT r04 item 3)
+    ("c1_f16_lo4", "configs[0]: 1 x 336x336 + 32-token prompt (the reference's CPU-runnable case)", ["--images", "1", "--width", "336", "--height", "336", "--steps", "10", "--warmup", "3"]),
+    ("c2_f16_lo4", "configs[1] shape (1 x 1344x896), fp16 + lo4: the parity-qualified line", ["--images", "1", "--steps", "10", "--warmup", "3"]),
+    ("c2_bf16_fast", "configs[1] as worded (1 x 1344x896, bf16)", ["--images", "1", "--dtype", "bf16", "--steps", "10", "--warmup", "3"]),
+    ("c3_f16_split", "configs[2] sample, split-operand precision mode (hi + lo 16-bit pairs at 2 K)", ["--precision", "split", "--steps", "3", "--warmup", "1"]),
+    ("c4_idefics2", "configs[3]: Leopard-Idefics2, 4 x 1344x896 (one rank; TP in the N > 1 runs)", ["--workload", "idefics2-c4", "--steps", "10", "--warmup", "3"]),
+    ("configs4_fp8_graph", "configs[4]: batch 8 x 8 images, fp8 MFMA ViT + LLM prefill, HIP-graph-captured encode",
+     ["--workload", "llava-c5", "--dtype", "fp8", "--graph-encode", "--steps", "3", "--warmup", "2"]),
+]
+
+
+def run_other_configs(cpu_tflops: float, timeout_s: float = 240.0) -> dict:
+    """The other BASELINE configurations, each as a short child run of this script on the same GPU (own process: own library options, own
+    allocator; a failure costs its entry, not the headline).  Every entry keeps the child's own line fields that matter here."""
+    import subprocess
+    keep = ("value", "unit", "ms_per_step", "steps", "dtype", "precision_mode", "prefill_mfma_frac", "matrix_pipe_frac", "parity", "cpu_baseline",
+            "graph_encode", "dtype_detail")
+    res = {}
+    for key, what, argv in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-other-configs", "--no-fast-line", "--no-cpu-baseline", "--cpu-tflops", f"{cpu_tflops:.4f}"] + argv
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                res[key] = {"config": what, "error": (p.stderr or "no output")[-300:]}
+                continue
+            d = json.loads(line[-1])
+            e = {"config": what, "workload": d.get("config", {}).get("workload"), **{k: d[k] for k in keep if k in d}}
+            if "roofline" in d:
+                e["roofline"] = {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_incl_correction_phase") if k in d["roofline"]}
+            e["wall_s"] = round(time.perf_counter() - t0, 1)
+            res[key] = e
+        except subprocess.TimeoutExpired:
+            res[key] = {"config": what, "error": f"no result within {timeout_s:.0f} s"}
+    return res
 
 
 def main():
@@ -603,6 +660,9 @@ def main():
     ap.add_argument("--precision", default=None, choices=["fast", "lo4", "split"],
                     help="schedule of the 16-bit engines (DESIGN.md 2.1): fast = one rounding per operand hand-over; lo4 = + the fp4 correction "
                          "phase (logits within north_star's 1e-3 at full depth); split = hi + lo 16-bit operand pairs at 2 K")
+    ap.add_argument("--no-fast-line", action="store_true", help="lo4 headline: skip the additional measurement of the fast schedule on the same sample")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configurations appended to the default line")
+    ap.add_argument("--cpu-tflops", type=float, default=0.0, help="(internal) host TFLOP/s measured by the parent run: the cpu_baseline of an other_configs child")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-tp", action="store_true", help="N > 1: skip the additional one-sample-on-all-ranks (strong scaling) measurement")
@@ -720,16 +780,18 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev)
-    assert res.seq_len == S and torch.isfinite(res.logits_last).all()
+    def timed(n_warm, n_steps):
+        for _ in range(n_warm):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            r = step()
+        barrier()
+        el = D.max_over_ranks(time.perf_counter() - t0, dev)
+        assert r.seq_len == S and torch.isfinite(r.logits_last).all()
+        return el, r
+    elapsed, res = timed(args.warmup, args.steps)
     ms_per_step = elapsed / args.steps * 1e3
     # the same step from ready-made tiles (what round 1 timed): the tiler's share of the headline
     n_ex = max(2, min(args.steps, 5))
@@ -804,9 +866,40 @@ def main():
         if args.dtype == "fp8":
             traffic, traffic_note = None, "the committed PMC summary describes the f16 step; not collected for the fp8 line"
         rl["traffic"], rl["traffic_source"] = traffic, traffic_note
+        if args.precision == "lo4":
+            # matrix-pipe time of the launches at the peak of each phase's operand type: the 16-bit pass at 2.5 PF + the fp4 phase (the same
+            # M x N x K again: 2 M N K4 FLOP) at 10 PF — what MFMA-busy counters see; `frac` above prices only the ALGORITHMIC FLOPs
+            rl["frac_incl_correction_phase"] = round(rl["frac"] * (1.0 + MFMA_PEAK_TFLOPS / MFMA_PEAK_FP4_TFLOPS), 4)
+            rl["correction_phase_note"] = ("every launch of the family also runs K4 / 256 k-tiles of v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 images "
+                                           "(4 x the 16-bit rate, dense peak 10 PF): + 25 % matrix-pipe time that `frac` books as overhead")
         out["roofline"] = rl
+    if args.precision == "lo4":
+        lo_fl = fl["total"] - fl["llm_attention"] - fl["lm_head_last"] - n_tiles * vit_attention_flops(cfg) - fl["projector"]
+        out["matrix_pipe_frac"] = round((args.inflight * (fl["total"] / MFMA_PEAK_TFLOPS + lo_fl / MFMA_PEAK_FP4_TFLOPS) / 1e12) / (elapsed / args.steps), 4)
+        out["matrix_pipe_frac_note"] = ("algorithmic FLOPs at the 2.5 PF 16-bit peak + the correction phase's FLOPs (every ViT / LLM layer linear once more, "
+                                        f"{lo_fl / 1e12:.1f} TFLOP) at the 10 PF fp4 peak, over the step time; prefill_mfma_frac counts the algorithmic FLOPs only")
+    if args.precision == "lo4" and not args.no_fast_line and args.dtype != "fp8":
+        # the SAME sample on the fast schedule (one rounding per operand hand-over, no correction phase): the throughput ceiling of the
+        # 16-bit path and what it costs in parity — both modes in one line
+        eng.precision = "fast"
+        f_elapsed, f_res = timed(max(1, min(args.warmup, 2)), args.steps)
+        fast = {"precision_mode": PRECISION_NOTE["fast"], "value": round(world * args.inflight * args.images * args.steps / f_elapsed, 3), "unit": "images/s",
+                "ms_per_step": round(f_elapsed / args.steps * 1e3, 3), "steps": args.steps,
+                "prefill_mfma_frac": round(args.inflight * fl["total"] / 1e12 / (f_elapsed / args.steps) / MFMA_PEAK_TFLOPS, 4),
+                "lo4_over_fast_time": round(elapsed / f_elapsed, 4)}
+        if rank == 0:
+            fast["parity"] = fixture_parity(args, ctxs[0], f_res if args.inflight == 1 else None)
+            if not args.no_roofline:
+                frl = roofline_from_timer(ops, once, min(args.steps, 3), False)
+                fast["roofline"] = {k: frl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "dominant", "launches_per_step", "avg_launch_ms", "gemm_ms_per_step")}
+        out["fast_schedule"] = fast
+        eng.precision = args.precision
+    cpu_tflops = args.cpu_tflops
+    if rank == 0 and world == 1 and args.no_cpu_baseline and args.cpu_tflops > 0:
+        out["cpu_baseline"] = extrapolated_cpu_baseline(args.cpu_tflops, args.images, fl["total"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tflops, t = cpu_baseline_sample(cfg)                   # doubles as the warm-up of the timed C1 runs
+        cpu_tflops = tflops
         del eng, W, ctxs
         torch.cuda.empty_cache()
         c1_s, c1_tf, c1_S = cpu_baseline_c1(cfg, ops, dev)
@@ -845,6 +938,15 @@ def main():
             out["tp"] = {"error": repr(e)[:500]}
         done.set()
         timer.cancel()
+    default_line = (args.workload == "llava-c3" and (args.images, args.width, args.height) == (6, 1344, 896) and args.dtype == "f16" and args.inflight == 1)
+    if rank == 0 and world == 1 and default_line and not args.no_other_configs:
+        if "eng" in dir():
+            del eng, W
+            ctxs.clear()
+        torch.cuda.empty_cache()
+        if cpu_tflops <= 0:
+            cpu_tflops = cpu_baseline_sample(cfg)[0]
+        out["other_configs"] = run_other_configs(cpu_tflops)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
