@@ -108,7 +108,11 @@ class LeopardEngine:
             if self.comm is None or self.comm.world != weights.tp_size:
                 raise RuntimeError(f"tensor-parallel weights (tp_size {weights.tp_size}) need an initialised process group of that size")
         self.tp_chunks = 2             # row chunks per layer under TP: chunk c's collectives overlap chunk c+1's GEMMs
-        self.tp_comm_dtype = None      # dtype of the reduce-scattered partial products: None = the compute type, torch.float32 = exact sums
+        # dtype of the reduce-scattered partial products.  torch.float32 (default since round 5) = exact partial sums: at C2 full depth two ranks
+        # with fp32 sums sit at 1.18e-3 of the logit scale against the fp32 reference — the one-rank fast schedule's 1.14e-3 — while the
+        # 16-bit exchange (None = the compute type: half the reduce-scatter bytes) adds a rounding per partial product and half layer, 1.74e-3
+        # (tests/test_gpu_dist.py, profiles/r05_tp_parity.txt).  LMI_TP_COMM_DTYPE=16 selects the 16-bit exchange.
+        self.tp_comm_dtype = None if os.environ.get("LMI_TP_COMM_DTYPE", "32") == "16" else torch.float32
         # TP decode: capture the step (with its RCCL all-reduces) in a HIP graph when the communicator is RcclComm.  OFF by default: capture and
         # replay of a multi-rank RCCL step has only ever run on a one-rank communicator (tests/test_gpu_dist.py) — LMI_TP_DECODE_GRAPH=1 /
         # this flag opt in, and a failed capture falls back to the eager step (``_decode_run``)

@@ -176,6 +176,21 @@ class Idefics2Engine(LeopardEngine):
         cu = self._pinned_to_device(torch.tensor(cu_list, dtype=torch.int32))
         h = self._empty(M, D)
         qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0])
+        if self.lo4:
+            # precision "lo4" (LeopardEngine._vit_layers_lo4): every layer-linear operand of the NaViT tower travels with the fp4 image of its
+            # rounding residual; the connector (modality projection + 3 perceiver layers) keeps the fast schedule, the Mistral layers take
+            # LeopardEngine._llm_layers_lo4
+            h4, att4, ff4 = self._lo4_act(M, D), self._lo4_act(M, D, heads=(H, hd)), self._lo4_act(M, W.vit_ff)
+            for L, (qkv4, o4, fc14, fc24) in zip(W.vit_layers, self._lo4_weights()["vit"]):
+                ops.norm_lo4(x, L.ln1_w, L.ln1_b, h4, vc.layer_norm_eps)
+                ops.gemm_lo4(h4, L.qkv_w, qkv4, qkv, bias=L.qkv_b)
+                ops.attention_lo4(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att4, cu, cu, max(counts), H, H, hd, hd ** -0.5, False)
+                ops.gemm_lo4(att4, L.o_w, o4, x, bias=L.o_b, epilogue=_lib.EPI_RESIDUAL)
+                ops.norm_lo4(x, L.ln2_w, L.ln2_b, h4, vc.layer_norm_eps)
+                ops.gemm_lo4(h4, L.fc1_w, fc14, ff4.hi, bias=L.fc1_b, act=_lib.ACT_GELU_TANH, out4=ff4)
+                ops.gemm_lo4(ff4, L.fc2_w, fc24, x, bias=L.fc2_b, epilogue=_lib.EPI_RESIDUAL)
+            ops.layernorm(x, W.post_ln_w, W.post_ln_b, h, vc.layer_norm_eps)
+            return h, counts
         att = self._empty(M, D)
         ff = self._empty(M, W.vit_ff)
         for L in W.vit_layers:

@@ -157,11 +157,15 @@ class Idefics2ForConditionalGeneration:
         # idefics_vlm_model.py:608, language_model_llama3.py:654, and the transformers 4.4x releases Leopard-Idefics2 ran with);
         # "all" = transformers 5.x, kept for the golden fixture pinned to that version
         self.patch_validity = "any"
+        self.precision = "fast"
         self._engine: Optional[Idefics2Engine] = None
         self.device = torch.device("cpu")
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype=torch.float16, ops: Optional[Ops] = None, patch_validity: str = "any", **unused):
+    def from_pretrained(cls, path: str, torch_dtype=torch.float16, ops: Optional[Ops] = None, patch_validity: str = "any",
+                        precision: Optional[str] = None, **unused):
+        """``precision`` / ``LEOPARD_AMD_PRECISION``: see leopard_amd.compat.resolve_precision.  The reference loads this model in fp16
+        (idefics2_multiimg.py:27-28), so the default for its request is the fast fp16 schedule; a float32 request selects lo4."""
         cfg = load_idefics2_config(path)
         eos, bad = (2, 32002), None
         gpath = os.path.join(path, "generation_config.json")
@@ -175,6 +179,8 @@ class Idefics2ForConditionalGeneration:
         dtype = torch_dtype if torch_dtype in (torch.float16, torch.bfloat16) else torch.float16
         m = cls(cfg, lambda dev, dt: CheckpointSource(path, dev, dt), dtype, ops, eos, bad)
         m.patch_validity = patch_validity
+        from .compat import resolve_precision
+        m.precision = resolve_precision(torch_dtype, dtype, precision)
         return m
 
     def eval(self):
@@ -186,6 +192,10 @@ class Idefics2ForConditionalGeneration:
             ops = self._ops if self._ops is not None else Ops()
             W = Idefics2Weights.build(self.config, self._source_factory(device, self.compute_dtype), self.compute_dtype)
             self._engine = Idefics2Engine(self.config, W, ops=ops, device=device)
+            if self.precision == "lo4" and not self._engine.lo4_supported():
+                self.precision = "fast"                 # (the split mode is a LeopardEngine schedule; the Idefics2 tower has fast and lo4)
+            if self.precision in ("fast", "lo4"):
+                self._engine.precision = self.precision
             vocab = self.config.text_config.vocab_size
             bad = [b for b in self.bad_words_ids if 0 <= b < vocab]
             self._engine.suppress_tokens = torch.tensor(bad, dtype=torch.int64, device=device) if bad else None

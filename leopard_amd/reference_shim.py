@@ -171,7 +171,7 @@ def _idefics2_classes():
             kw.setdefault("ops", _ops_from_env())
             req = kw.get("torch_dtype", torch.float16)
             m = super().from_pretrained(path, **kw)
-            _record_run_info("AutoModelForVision2Seq", path, req, m.compute_dtype)
+            _record_run_info("AutoModelForVision2Seq", path, req, m.compute_dtype, getattr(m, "precision", "fast"))
             return m
 
         def to(self, device):

@@ -147,3 +147,86 @@ def test_rccl_c_abi_single_rank_communicator():
     assert res["ranks"] == 1 and res["backend"].startswith("rccl")
     assert res["graph"], "lmi_allreduce / lmi_allgather inside a captured HIP graph did not replay correctly"
     assert res["torch.float16"] and res["torch.bfloat16"] and res["torch.float32"] and res["sent"] == 0
+
+
+def _worker_c2_full_depth(rank, world, port, out, ckpt_dir):
+    """BASELINE config C2 (1 x 1344x896 -> 7 ViT inputs, S = 1242) at FULL depth through the two-rank path, both exchange dtypes; and a
+    checkpoint -> tensor-parallel shard -> device load through compat.from_pretrained(tp_rank=, tp_size=)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from leopard_amd import compat
+    from leopard_amd import dist as D
+    from leopard_amd.config import full_config
+    from leopard_amd.engine import LeopardEngine
+    from leopard_amd.ops import Ops
+    from leopard_amd.weights import EngineWeights, SynthSource
+    from tests.test_gpu_parity import sample_inputs
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    D.init(backend="gloo")
+    ops, cfg, dtype = Ops(), full_config(), torch.float16
+    src = SynthSource(cfg, ops, dev, dtype)
+    eng = LeopardEngine(cfg, EngineWeights.build(cfg, src, dtype, tp_rank=rank, tp_size=world), ops=ops, device=dev)
+    u8, ids, _ = sample_inputs(cfg, 1, 1344, 896)
+    tiles = torch.from_numpy(u8).to(dev)
+    res = {}
+    for name, cdt in (("16-bit reduce-scatter", None), ("fp32 reduce-scatter", torch.float32)):
+        eng.tp_chunks, eng.tp_comm_dtype = 2, cdt
+        vis = D.encode_images_sharded(eng, tiles)
+        res[name] = eng.prefill(ids, None, visual_tokens=vis).logits_last.float().cpu()
+    del eng
+    torch.cuda.empty_cache()
+    # checkpoint -> TP shard -> device (SURVEY.md 8 f1 "optional TP pre-sharding on load")
+    m = compat.from_pretrained(ckpt_dir, torch_dtype=torch.float16, tp_rank=rank, tp_size=world).eval().to(dev)
+    S = m.config.vision_config.image_size
+    px = torch.from_numpy(np.random.default_rng(4).integers(0, 256, (3, S, S, 3), dtype=np.uint8)).to(dev)
+    tok = torch.tensor([[7, 500, 11, 500, 500, 12, 13]]).to(dev)
+    lg_tp = m.engine.prefill(tok, px).logits_last.float().cpu()
+    shard_rows = m.engine.W.llm_layers[0].o_w.shape[1]
+    lg_one = None
+    if rank == 0:
+        one = compat.from_pretrained(ckpt_dir, torch_dtype=torch.float16).eval().to(dev)
+        lg_one = one.engine.prefill(tok, px).logits_last.float().cpu()
+        assert one.engine.W.llm_layers[0].o_w.shape[1] == 2 * shard_rows
+    torch.cuda.synchronize()
+    out.put((rank, {k: v.tolist() for k, v in res.items()}, lg_tp.tolist(), None if lg_one is None else lg_one.tolist(), m.precision))
+    D.barrier()
+
+
+def test_tensor_parallel_c2_full_depth_vs_oracle_fixture_and_tp_checkpoint_load(tmp_path):
+    """what tensor parallelism does to PARITY, measured against the committed fp32 oracle fixture of C2 at full depth
+    (tests/golden/c2_full_depth.npz), for both dtypes of the reduce-scattered partial products; and f1's TP pre-sharding on load."""
+    from leopard_amd.checkpoint import save_synthetic_checkpoint
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    ck = str(tmp_path / "ckpt")
+    small = LeopardConfig(          # the kernel shape rules at tiny depth, with 4 q / 2 kv heads so that two ranks get whole heads
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=256, num_hidden_layers=2, num_attention_heads=16, image_size=56, patch_size=14),
+        text_config=TextConfig(hidden_size=512, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
+                               vocab_size=512, rope_scaling=RopeScaling()),
+        image_token_index=500)
+    save_synthetic_checkpoint(ck, small, shard_bytes=8 << 20)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_full_depth.npz"))
+    ref = torch.from_numpy(z["logits_fp32"])
+    mp.set_start_method("spawn", force=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c2_full_depth, args=(r, 2, port, q, ck)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=1500) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, v0, tp0, one, prec), (_, v1, tp1, _, _) = res
+    assert v0 == v1 and tp0 == tp1 and prec == "fast"          # every rank holds the same logits; TP engines run the fast schedule
+    scale = ref.abs().max().item()
+    errs = {k: (torch.tensor(v) - ref).abs().max().item() / scale for k, v in v0.items()}
+    print("[tp2 C2 full depth fp16] max|logit diff| / max|logit| vs the fp32 oracle fixture:", {k: f"{e:.3e}" for k, e in errs.items()},
+          "(one rank, fast schedule: 1.14e-3; one rank, lo4: 3.3e-4)")
+    for k, v in v0.items():
+        assert int(torch.tensor(v).argmax()) == int(ref.argmax()), k
+    # the 16-bit exchange adds one rounding per partial product and half layer; the fp32 exchange must stay on the one-rank fast budget
+    assert errs["fp32 reduce-scatter"] <= 1.6e-3 and errs["16-bit reduce-scatter"] <= 2.5e-3
+    d = (torch.tensor(tp0) - torch.tensor(one)).abs().max().item() / torch.tensor(one).abs().max().item()
+    print(f"[tp2 checkpoint load] TP-sharded from_pretrained vs one rank: {d:.3e} of the logit scale")
+    assert d <= 2.5e-3
