@@ -327,7 +327,9 @@ FP8_DETAIL = ("fp8 e4m3fn operands (static power-of-two scales, fp32 accumulate)
               "layers and the qkv / o / gate-up / down linears of the 32 Llama layers; f16 attention, patch embed, projector; fp32 "
               "residual stream, norms and head")
 FP8_ATTN_DETAIL = ("; Llama attention arithmetic on the fp8 pipe as well: e4m3 q / k / v (static scales) and e4m3 P, QK^T and PV on "
-                   "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 softmax statistics and accumulators (--fp8-attention 0: the f16 attention)")
+                   "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 softmax statistics and accumulators — an OPT-IN of the fp8 schedule that this bench switches on "
+                   "(engine.fp8_attention / LMI_FP8_ATTENTION=1; the library default and --fp8-attention 0 keep the f16 attention arithmetic: "
+                   "81.3 vs 76.5 ms per C3 step, profiles/r04_bench_c3_fp8_f16_attention.json)")
 
 
 def fp8_detail(args):

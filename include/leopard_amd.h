@@ -291,6 +291,9 @@ int lmi_split_lo4(const float* x, void* hi, void* lo4, void* scales, int M, int 
 /* LayerNorm (b != null) / RMSNorm (b == null) writing T(y) and the fp4 image of y - T(y) in one launch (D % 32 == 0, D <= 4096). */
 int lmi_norm_lo4(const float* x, const float* w, const float* b, void* out, void* out4, void* scales, int M, int D, int K4, int ldx, int ldo,
                  int ld4, int lds, float eps, int dtype, void* stream);
+/* lmi_add_rmsnorm (tensor parallel: residual add of the reduce-scattered partial products + RMSNorm on the rank's rows) writing the Lo4 pair. */
+int lmi_add_rmsnorm_lo4(float* x, const void* delta, int delta_dtype, const float* w, void* out, void* out4, void* scales, int M, int D, int K4,
+                        int ldx, int ldd, int ldo, int ld4, int lds, float eps, int dtype, void* stream);
 /* Weight image, once at load: W T [N, K] row-major (ldw elements) -> fp4 [N, ld4 bytes] + one E8M0 scale per row [N]. */
 int lmi_quantize_w4(const void* W, void* w4, void* scales, int N, int K, int K4, int ldw, int ld4, int dtype, void* stream);
 

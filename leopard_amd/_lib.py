@@ -67,6 +67,7 @@ SIGNATURES = {
     "lmi_attn_varlen_fwd_lo4": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "lmi_split_lo4": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_norm_lo4": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "lmi_add_rmsnorm_lo4": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "lmi_quantize_w4": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lmi_attn_varlen_fwd_f32": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "lmi_rope_qkv_skinny": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P, _P, _P, _I, C.c_int64, _P, _I, _P],

@@ -46,12 +46,12 @@ def resolve_precision(requested_dtype, compute_dtype, precision: Optional[str] =
     """Schedule of the prefill (LeopardEngine.precision).  ``LEOPARD_AMD_PRECISION`` = fast | lo4 | split overrides everything; an explicit
     ``precision`` argument comes next; otherwise a caller that asks for ``torch_dtype=torch.float32`` — the reference script does, EVAL:373 —
     gets the mode that meets the stated tolerance against fp32 arithmetic (lo4: fp16 operands + the fp4 correction phase, full-depth logits
-    within 1e-3), and a caller that asks for a 16-bit type gets the fast schedule of that type.  Tensor-parallel engines run the fast schedule."""
+    within 1e-3), and a caller that asks for a 16-bit type gets the fast schedule of that type.  Tensor-parallel engines run fast or lo4."""
     env = os.environ.get("LEOPARD_AMD_PRECISION", "").lower()
     mode = env or precision or ("lo4" if requested_dtype in (None, torch.float32) and compute_dtype == torch.float16 else "fast")
     if mode not in ("fast", "lo4", "split"):
         raise ValueError(f"precision must be fast, lo4 or split, not {mode!r}")
-    return "fast" if tp_size > 1 else mode
+    return "fast" if (tp_size > 1 and mode == "split") else mode
 
 
 class LeopardForConditionalGeneration:

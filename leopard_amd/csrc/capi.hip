@@ -852,6 +852,28 @@ int lmi_add_rmsnorm(float* x, const void* delta, int delta_dtype, const float* w
                                   : add_rmsnorm_impl<bf16_t, bf16_t>(x, delta, w, out, M, D, ldx, ldd, ldo, eps, stream);
 }
 
+int lmi_add_rmsnorm_lo4(float* x, const void* delta, int delta_dtype, const float* w, void* out, void* out4, void* scales, int M, int D, int K4,
+                        int ldx, int ldd, int ldo, int ld4, int lds, float eps, int dtype, void* stream) {
+    if (!x || !delta || !w || !out || !out4 || !scales || M < 0 || D <= 0 || (D & 31) || D > 4096 || K4 != (D + 255) / 256 * 256 || (ldx & 3) || (ldd & 7) ||
+        (ldo & 7) || (ld4 & 3) || ld4 < K4 / 2 || lds < K4 / 32 || !aligned16(x) || !aligned16(delta) || !aligned16(out) || !aligned16(w) || ((uintptr_t)out4 & 3))
+        return fail(LMI_EINVAL, "lmi_add_rmsnorm_lo4: bad argument (M=%d D=%d K4=%d; D %% 32 == 0, D <= 4096, K4 = D rounded up to 256)", M, D, K4);
+    if (dtype != LMI_F16 && dtype != LMI_BF16) return fail(LMI_EINVAL, "lmi_add_rmsnorm_lo4: dtype must be LMI_F16 or LMI_BF16");
+    if (delta_dtype != LMI_F32 && delta_dtype != dtype) return fail(LMI_EINVAL, "lmi_add_rmsnorm_lo4: delta_dtype must be LMI_F32 or dtype");
+    if (M == 0) return LMI_OK;
+    NormLo4 lo;
+    lo.out4 = (uint8_t*)out4; lo.scales = (uint8_t*)scales; lo.ld4 = ld4; lo.lds = lds; lo.K4 = K4;
+    const int grid = (M + 3) / 4;
+#define LMI_ADDNORM4(T_, DT_)                                                                                                                     \
+    do {                                                                                                                                          \
+        if (D <= 1536) LMI_LAUNCH((add_rmsnorm_kernel<T_, DT_, 3, true>), dim3(grid), dim3(256), 0, stream, x, (const DT_*)delta, w, (T_*)out, M, D, ldx, ldd, ldo, eps, lo); \
+        else LMI_LAUNCH((add_rmsnorm_kernel<T_, DT_, 8, true>), dim3(grid), dim3(256), 0, stream, x, (const DT_*)delta, w, (T_*)out, M, D, ldx, ldd, ldo, eps, lo);          \
+    } while (0)
+    if (dtype == LMI_F16) { if (delta_dtype == LMI_F32) LMI_ADDNORM4(f16_t, float); else LMI_ADDNORM4(f16_t, f16_t); }
+    else { if (delta_dtype == LMI_F32) LMI_ADDNORM4(bf16_t, float); else LMI_ADDNORM4(bf16_t, bf16_t); }
+#undef LMI_ADDNORM4
+    return check_launch("lmi_add_rmsnorm_lo4");
+}
+
 int lmi_gemm(const void* A, const void* W, void* out, const float* bias, const float* addmat, const int* add_rows,
              const int* row_map,
              int M, int N, int K, int lda, int ldw, int ldo, int add_period, int epilogue, int act, int a_mode,

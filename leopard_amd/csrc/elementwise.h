@@ -309,9 +309,9 @@ __global__ void __launch_bounds__(256) norm_rows_kernel(const float* x, const fl
 // products of o_proj / down_proj, 16-bit or fp32), x written back, then out[row] = w * (x * rstd) as norm_kernel<RMS> does.
 // out == nullptr: the add only.  One wave per row, row in registers.
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename DT, int MAXV>
+template <typename T, typename DT, int MAXV, bool LO4 = false>
 __global__ void __launch_bounds__(256) add_rmsnorm_kernel(float* x, const DT* delta, const float* w, T* out, int M, int D, int ldx,
-                                                          int ldd, int ldo, float eps) {
+                                                          int ldd, int ldo, float eps, NormLo4 lo = NormLo4()) {
     typedef typename vec_of<T>::x8 T8;
     typedef typename vec_of<DT>::x8 D8;
     const int lane = threadIdx.x & 63;
@@ -350,9 +350,31 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(float* x, const DT* de
             for (int h = 0; h < 2; ++h) {
                 const f32x4 ww = *(const f32x4*)(w + c * 8 + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[4 * h + e] = (T)(ww[e] * (v[i][h][e] * rstd));
+                for (int e = 0; e < 4; ++e) {
+                    const float y = ww[e] * (v[i][h][e] * rstd);
+                    o[4 * h + e] = (T)y;
+                    if constexpr (LO4) v[i][h][e] = y;               // kept for the residual image below
+                }
             }
-            *(T8*)(orow + c * 8) = o;
+            if constexpr (!LO4) *(T8*)(orow + c * 8) = o;
+        }
+    }
+    if constexpr (LO4) {                                             // as norm_kernel: every lane of the wave takes part in the quad exchange
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = i * 64 + lane;
+            if (i * 64 >= (lo.K4 >> 3)) break;
+            float yv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) yv[e] = c < nvec ? v[i][e >> 2][e & 3] : 0.f;
+            T8 o;
+            unsigned sb;
+            const unsigned codes = lo4_encode8<T>(yv, o, sb);
+            if (c < nvec) *(T8*)(orow + c * 8) = o;
+            if (c < (lo.K4 >> 3)) {
+                *(unsigned*)(lo.out4 + (long)row * lo.ld4 + c * 4) = codes;
+                if ((lane & 3) == 0) lo.scales[(long)row * lo.lds + (c >> 2)] = (uint8_t)sb;
+            }
         }
     }
 }
@@ -468,9 +490,11 @@ __global__ void __launch_bounds__(1024) decode_advance_kernel(DecodeAdvanceArgs 
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     auto take = [&](float v, int i) {
-        for (int j = 0; j < a.n_suppress; ++j)
-            if (a.suppress[j] == i) v = -INFINITY;
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        if (v > bv || (v == bv && i < bi)) {                         // only a candidate for the running best is looked up in the suppress list
+            for (int j = 0; j < a.n_suppress; ++j)
+                if (a.suppress[j] == i) return;                      // (the logits row itself is left as computed: suppressed ids are skipped, not overwritten)
+            bv = v; bi = i;
+        }
     };
     // 16 bytes per lane, four loads in flight per thread: the row is 0.5 MB and ONE workgroup scans it — the scan is load latency, not bandwidth
     const int v4 = ((((size_t)row) & 15) == 0) ? (a.vocab >> 2) : 0;

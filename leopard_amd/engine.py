@@ -176,17 +176,19 @@ class LeopardEngine:
 
     def lo4_supported(self) -> bool:
         """The lo4 schedule rides on the fused Llama / Mistral layer (head_dim 128, rope-ordered q|k|v rows, hidden % 256 == 0) and on
-        32-element blocks along every contraction axis (hidden sizes and FFN widths % 32 == 0); one rank, 16-bit compute type."""
+        32-element blocks along every contraction axis (hidden sizes and FFN widths % 32 == 0); 16-bit compute type.  Tensor-parallel
+        engines run it too (round 5): the sequence-parallel norms hand over Lo4 pairs and the all-gathers move the images with the rows."""
         tc, vc, W = self.cfg.text_config, self.cfg.vision_config, self.W
-        return bool(self.tp_size == 1 and self.dtype in (torch.float16, torch.bfloat16) and tc.head_dim == 128 and tc.hidden_size % 256 == 0
-                    and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None and tc.intermediate_size % 32 == 0 and vc.hidden_size % 32 == 0)
+        return bool(self.dtype in (torch.float16, torch.bfloat16) and tc.head_dim == 128 and tc.hidden_size % 256 == 0
+                    and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None and (tc.intermediate_size // self.tp_size) % 32 == 0
+                    and tc.intermediate_size // self.tp_size >= 128 and vc.hidden_size % 32 == 0)
 
     @precision.setter
     def precision(self, mode: str):
         if mode not in ("fast", "lo4", "split"):
             raise ValueError(f"precision must be 'fast', 'lo4' or 'split', not {mode!r}")
-        if mode != "fast" and self.tp_size > 1:
-            raise ValueError("the precision modes run on one rank (tensor-parallel engines keep the fast schedule)")
+        if mode == "split" and self.tp_size > 1:
+            raise ValueError("the split-operand mode runs on one rank (tensor-parallel engines: 'fast' or 'lo4')")
         if mode == "lo4" and not self.lo4_supported():
             raise ValueError("precision 'lo4' needs the fused Llama / Mistral layer shape (head_dim 128, hidden % 256 == 0): use 'split'")
         self.split_operands, self.lo4 = mode == "split", mode == "lo4"
@@ -207,8 +209,8 @@ class LeopardEngine:
         L0 = self.W.llm_layers[0] if self.W.llm_layers else None
         marked = L0 is not None and is_packed(L0.o_w)
         want = getattr(self.W, "_llm_packed", None)
-        if want is not None and L0 is not None and any(is_packed(getattr(L0, n)) != want for n in ("qkv_w_rope", "o_w", "gu_w", "down_w")
-                                                       if getattr(L0, n) is not None):
+        if want is not None and any(is_packed(getattr(L, n)) != want for L in self.W.llm_layers for n in ("qkv_w_rope", "o_w", "gu_w", "down_w")
+                                    if getattr(L, n) is not None):                # every layer, every linear (128 attribute reads per pass)
             raise RuntimeError("LLM layer weights were replaced by copies that lost their layout mark (weights.mark_packed); "
                                "call engine.pack_llm_weights() / unpack_llm_weights() instead of copying packed tensors")
         return marked
@@ -948,13 +950,27 @@ class LeopardEngine:
                 ms.wait_event(e)
         pos = torch.arange(NC * Sc)
         cos, sin = self.rope_tables(pos)
-        h_loc = [self._empty(Sl, D_) for _ in range(NC)]
-        h_full = [self._empty(Sc, D_) for _ in range(NC)]
+        lo4 = self.lo4
+        if lo4:
+            # precision "lo4" under tensor parallelism: the rank's normalised rows are Lo4 pairs (16-bit rows + fp4 image of their rounding
+            # residual + block scales; image and scales in ONE buffer so that one more all-gather moves both: + 27 % all-gather bytes), the
+            # column-parallel GEMMs run the correction phase on the gathered pair against the image of THIS rank's weight shard, the
+            # attention and the SwiGLU epilogue hand their images to the row-parallel GEMMs.  The partial products are exchanged as before.
+            from .ops import lo4_packed_act
+            if not (hd == 128 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None):
+                raise RuntimeError("precision 'lo4' needs head_dim 128 and the rope-ordered q|k|v weights")
+            L4 = self._lo4_weights()["llm"]
+            h_loc = [lo4_packed_act(Sl, D_, T, dev) for _ in range(NC)]
+            h_full = [lo4_packed_act(Sc, D_, T, dev) for _ in range(NC)]
+            att, gu = self._lo4_act(Sc, qw, heads=(H, hd)), self._lo4_act(Sc, W.llm_ff)
+        else:
+            h_loc = [self._empty(Sl, D_) for _ in range(NC)]
+            h_full = [self._empty(Sc, D_) for _ in range(NC)]
+            att = self._empty(Sc, qw)
+            gu = self._empty(Sc, W.llm_ff)
         part = [self._empty(Sc, D_, dtype=cdt) for _ in range(NC)]
         red = [self._empty(Sl, D_, dtype=cdt) for _ in range(NC)]
         qkv = self._empty(Sc, qw + 2 * kw)
-        att = self._empty(Sc, qw)
-        gu = self._empty(Sc, W.llm_ff)
         cu_q = torch.tensor([0, Sc], dtype=torch.int32, device=dev)
         cu_k = [torch.tensor([0, (c + 1) * Sc], dtype=torch.int32, device=dev) for c in range(NC)]
         scale = hd ** -0.5
@@ -962,49 +978,75 @@ class LeopardEngine:
         fused_rope = self.fuse_norm_rope and hd == 128 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None
         n_layers = len(W.llm_layers)
         ev = [None] * NC
+
+        def gather(c):
+            """all-gather of chunk c's normalised rows (and, under lo4, of their residual images) on the comm stream."""
+            to_comm()
+            if lo4:
+                comm.all_gather(h_full[c].hi, h_loc[c].hi, cs)
+                comm.all_gather(h_full[c].buf.view(torch.float16), h_loc[c].buf.view(torch.float16), cs)
+            else:
+                comm.all_gather(h_full[c], h_loc[c], cs)
+            ev[c] = done()
+
+        def add_norm(c, delta, w):
+            if w is None:
+                ops.add_rmsnorm(xs[c], delta, None, None, tc.rms_norm_eps)
+            elif lo4:
+                ops.add_rmsnorm_lo4(xs[c], delta, w, h_loc[c], tc.rms_norm_eps)
+            else:
+                ops.add_rmsnorm(xs[c], delta, w, h_loc[c], tc.rms_norm_eps)
         for li, L in enumerate(W.llm_layers):
+            w4 = L4[li] if lo4 else None
             # ---- attention half ----------------------------------------------------------------------------------------
             for c in range(NC):
                 if li == 0:
-                    ops.rmsnorm(xs[c], L.in_norm, h_loc[c], tc.rms_norm_eps)
-                to_comm()
-                comm.all_gather(h_full[c], h_loc[c], cs)
-                ev[c] = done()
+                    if lo4:
+                        ops.norm_lo4(xs[c], L.in_norm, None, h_loc[c], tc.rms_norm_eps)
+                    else:
+                        ops.rmsnorm(xs[c], L.in_norm, h_loc[c], tc.rms_norm_eps)
+                gather(c)
             for c in range(NC):
                 wait(ev[c])
                 kc, vc = cache.k[li], cache.v[li]
-                if fused_rope:
-                    ops.rmsnorm_rope(h_full[c], L.qkv_w_rope, qkv, None, tc.rms_norm_eps, cos[c * Sc:(c + 1) * Sc], sin[c * Sc:(c + 1) * Sc],
-                                     kc, vc, c * Sc, H, KV, hd)
+                if lo4:
+                    ops.rmsnorm_rope_lo4(h_full[c], L.qkv_w_rope, w4[0], qkv, None, tc.rms_norm_eps, cos[c * Sc:(c + 1) * Sc],
+                                         sin[c * Sc:(c + 1) * Sc], kc, vc, c * Sc, H, KV, hd)
+                    ops.attention_lo4(qkv[:, :qw], kc[:(c + 1) * Sc], vc[:(c + 1) * Sc], att, cu_q, cu_k[c], Sc, H, KV, hd, scale, True,
+                                      window=tc.sliding_window or 0)
+                    ops.gemm_lo4(att, L.o_w, w4[1], part[c], epilogue=epi_part)
                 else:
-                    ops.gemm(h_full[c], L.qkv_w, qkv)
-                    ops.rope_qk(qkv, H, KV, hd, cos[c * Sc:(c + 1) * Sc], sin[c * Sc:(c + 1) * Sc], kc, vc, c * Sc)
-                ops.attention(qkv[:, :qw], kc[:(c + 1) * Sc], vc[:(c + 1) * Sc], att, cu_q, cu_k[c], Sc, H, KV, hd, scale, True,
-                              self.use_tr, window=tc.sliding_window or 0)
-                ops.gemm(att, L.o_w, part[c], epilogue=epi_part)
+                    if fused_rope:
+                        ops.rmsnorm_rope(h_full[c], L.qkv_w_rope, qkv, None, tc.rms_norm_eps, cos[c * Sc:(c + 1) * Sc], sin[c * Sc:(c + 1) * Sc],
+                                         kc, vc, c * Sc, H, KV, hd)
+                    else:
+                        ops.gemm(h_full[c], L.qkv_w, qkv)
+                        ops.rope_qk(qkv, H, KV, hd, cos[c * Sc:(c + 1) * Sc], sin[c * Sc:(c + 1) * Sc], kc, vc, c * Sc)
+                    ops.attention(qkv[:, :qw], kc[:(c + 1) * Sc], vc[:(c + 1) * Sc], att, cu_q, cu_k[c], Sc, H, KV, hd, scale, True,
+                                  self.use_tr, window=tc.sliding_window or 0)
+                    ops.gemm(att, L.o_w, part[c], epilogue=epi_part)
                 to_comm()
                 comm.reduce_scatter(red[c], part[c], cs)
                 ev[c] = done()
             # ---- MLP half ----------------------------------------------------------------------------------------------
             for c in range(NC):
                 wait(ev[c])
-                ops.add_rmsnorm(xs[c], red[c], L.post_norm, h_loc[c], tc.rms_norm_eps)
-                to_comm()
-                comm.all_gather(h_full[c], h_loc[c], cs)
-                ev[c] = done()
+                add_norm(c, red[c], L.post_norm)
+                gather(c)
             for c in range(NC):
                 wait(ev[c])
-                ops.gemm(h_full[c], L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
-                ops.gemm(gu, L.down_w, part[c], epilogue=epi_part)
+                if lo4:
+                    ops.gemm_lo4(h_full[c], L.gu_w, w4[2], gu.hi, epilogue=_lib.EPI_SWIGLU, out4=gu)
+                    ops.gemm_lo4(gu, L.down_w, w4[3], part[c], epilogue=epi_part)
+                else:
+                    ops.gemm(h_full[c], L.gu_w, gu, epilogue=_lib.EPI_SWIGLU)
+                    ops.gemm(gu, L.down_w, part[c], epilogue=epi_part)
                 to_comm()
                 comm.reduce_scatter(red[c], part[c], cs)
                 ev[c] = done()
             for c in range(NC):
                 wait(ev[c])
-                if li + 1 < n_layers:
-                    ops.add_rmsnorm(xs[c], red[c], W.llm_layers[li + 1].in_norm, h_loc[c], tc.rms_norm_eps)
-                else:
-                    ops.add_rmsnorm(xs[c], red[c], None, None, tc.rms_norm_eps)
+                add_norm(c, red[c], W.llm_layers[li + 1].in_norm if li + 1 < n_layers else None)
             if self.trace:
                 self.trace(f"llm.{li}", xs)
         if on_gpu:

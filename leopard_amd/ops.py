@@ -36,10 +36,10 @@ class Lo4Act:
     """One A operand of a GEMM with the low-bit correction phase (include/leopard_amd.h ``lmi_lo4``): ``hi`` = T(x) [M, K], ``img`` = the
     fp4 (e2m1) image of x - T(x) [M, K4 / 2] bytes, ``sc`` = its E8M0 block scales [M, K4 / 32].  The three are views into caller-owned
     scratch; the producers (lmi_norm_lo4, lmi_split_lo4, the GEMM epilogues) write all of them, padding included."""
-    __slots__ = ("hi", "img", "sc", "K", "K4")
+    __slots__ = ("hi", "img", "sc", "K", "K4", "buf")
 
     def __init__(self, hi: torch.Tensor, img: torch.Tensor, sc: torch.Tensor):
-        self.hi, self.img, self.sc = hi, img, sc
+        self.hi, self.img, self.sc, self.buf = hi, img, sc, None
         self.K = hi.shape[1]
         self.K4 = img.shape[1] * 2          # lo4_k4(K), or wider when the image carries a padded k order (attention outputs, head_dim 72 / 96)
         assert img.dtype == torch.uint8 and sc.dtype == torch.uint8 and self.K4 % 256 == 0 and self.K4 >= self.K and sc.shape[0] == hi.shape[0] == img.shape[0]
@@ -47,10 +47,23 @@ class Lo4Act:
 
     @staticmethod
     def empty(M: int, K: int, dtype, device, k4: Optional[int] = None) -> "Lo4Act":
-        alloc = torch.zeros if k4 else torch.empty      # a padded k order: the producer writes its own blocks only, the padding stays zero
+        # a padded k order, or K not a multiple of 256: the attention kernel and the GEMM epilogues write their own blocks only — the padding
+        # must read as zero codes / zero scales (the norm and split kernels write theirs)
+        alloc = torch.zeros if (k4 or lo4_k4(K) != K) else torch.empty
         k4 = k4 or lo4_k4(K)
         return Lo4Act(torch.empty(M, K, dtype=dtype, device=device), alloc(M, k4 // 2, dtype=torch.uint8, device=device),
                       alloc(M, k4 // 32, dtype=torch.uint8, device=device))
+
+
+def lo4_packed_act(M: int, K: int, dtype, device) -> Lo4Act:
+    """A Lo4Act whose image and scales are column ranges of ONE row-major uint8 buffer ``buf`` [M, K4 / 2 + K4 / 32 (+ pad to 16)]: a
+    tensor-parallel all-gather then moves both with one collective (rows are gathered rank-major, so row blocks stay row blocks)."""
+    k4 = lo4_k4(K)
+    rb = (k4 // 2 + k4 // 32 + 15) // 16 * 16
+    buf = (torch.zeros if k4 != K else torch.empty)(M, rb, dtype=torch.uint8, device=device)
+    act = Lo4Act(torch.empty(M, K, dtype=dtype, device=device), buf[:, :k4 // 2], buf[:, k4 // 2:k4 // 2 + k4 // 32])
+    act.buf = buf
+    return act
 
 
 class Lo4Weight:
@@ -441,6 +454,15 @@ class Ops:
         assert act.hi.shape == (M, D)
         self._check(self.lib.lmi_norm_lo4(_ptr(x), _ptr(w), _ptr(b), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), M, D, act.K4, x.stride(0),
                                           act.hi.stride(0), act.img.stride(0), act.sc.stride(0), float(eps), _DT[act.hi.dtype], self._stream(x)))
+        return act
+
+    def add_rmsnorm_lo4(self, x, delta, w, act: Lo4Act, eps) -> Lo4Act:
+        """x (fp32, in place) += delta; act = the Lo4 pair of rmsnorm(x) * w (lmi_add_rmsnorm_lo4: the tensor-parallel layer's norm)."""
+        M, D = x.shape
+        assert act.hi.shape == (M, D)
+        self._check(self.lib.lmi_add_rmsnorm_lo4(_ptr(x), _ptr(delta), _DT[delta.dtype], _ptr(w), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), M, D, act.K4,
+                                                 x.stride(0), delta.stride(0), act.hi.stride(0), act.img.stride(0), act.sc.stride(0), float(eps),
+                                                 _DT[act.hi.dtype], self._stream(x)))
         return act
 
     def gemm_lo4(self, a: Lo4Act, w, w4: Lo4Weight, out, bias=None, epilogue=EPI_STORE, act=ACT_NONE, rowsq_in=None, norm_dim=0, norm_eps=0.0,

@@ -268,3 +268,71 @@ def test_c_abi_communicator_failure_is_agreed_on_by_all_ranks():
         assert kind == "TorchComm" and "lmi_comm unavailable" in backend and n_warn >= 1
         assert x == [3.0] * 4
     assert res[0][3] is True                                        # rank 0's communicator had come up and was destroyed
+
+
+def _tp_lo4_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from leopard_amd import dist as D
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    from leopard_amd.engine import KVCache, LeopardEngine
+    from leopard_amd.weights import EngineWeights, SynthSource
+    from tests.emu_util import emu_ops
+    D.init(backend="gloo")
+    ops = emu_ops()
+    cfg = LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16, image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=2,
+                               vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+    src = SynthSource(cfg, ops, "cpu", torch.float16)
+    eng = LeopardEngine(cfg, EngineWeights.build(cfg, src, torch.float16, tp_rank=rank, tp_size=world), ops=ops, device="cpu")
+    tiles = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
+    ids = torch.tensor([[5, 250, 9, 250, 17, 33, 101, 7]])
+    S = ids.shape[1] + 2 * (cfg.tokens_per_tile - 1)
+    fast = eng.prefill(ids, tiles).logits_last.clone()
+    sent_fast = eng.comm.sent_bytes
+    eng.precision = "lo4"
+    cache = KVCache(cfg, eng.tp_padded_len(S) + 4, torch.float16, "cpu", tp_size=world)
+    res = eng.prefill(ids, tiles, cache=cache)
+    sent_lo4 = eng.comm.sent_bytes - sent_fast
+    step = eng.decode_step(int(res.logits_last.argmax()), cache).clone()          # the decode step follows on the lo4 prefill's cache
+    ref = None
+    if rank == 0:
+        from leopard_amd.synth import synth_state_dict_numpy
+        from leopard_amd.tiler import siglip_normalize
+        from oracle import leopard_oracle as O
+        one = LeopardEngine(cfg, EngineWeights.build(cfg, src, torch.float16), ops=ops, device="cpu")
+        one.precision = "lo4"
+        r1 = one.prefill(ids, tiles).logits_last
+        Wt = O.weights_from_numpy(synth_state_dict_numpy(cfg))
+        o32 = O.prefill_logits(ids, torch.from_numpy(siglip_normalize(tiles.numpy())), Wt, cfg, last_only=True)[0, 0]
+        sc = float(o32.abs().max())
+        ref = (float((res.logits_last - r1).abs().max()) / sc, float((res.logits_last - o32).abs().max()) / sc, float((fast - o32).abs().max()) / sc,
+               float((r1 - o32).abs().max()) / sc, sent_fast, sent_lo4, bool(torch.isfinite(step).all()))
+    out.put((rank, res.logits_last.tolist(), ref))
+    D.barrier()
+
+
+def test_tensor_parallel_lo4_gloo():
+    """precision "lo4" on the tensor-parallel layer (round 5): two ranks over gloo on the emulated kernels — every rank holds the same logits;
+    they agree with the one-rank lo4 engine up to the partial-product exchange; against the fp32 oracle the TP lo4 run is no further than the TP
+    fast run; the all-gathers carry the residual images (+ ~27 % of the gathered bytes) and nothing else changes on the wire."""
+    mp.set_start_method("spawn", force=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tp_lo4_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, ref), (_, l1, _) = res
+    assert l0 == l1
+    d_one, e_tp_lo4, e_tp_fast, e_one_lo4, sent_fast, sent_lo4, finite = ref
+    print(f"[tp2 lo4, emulated kernels] vs one-rank lo4 {d_one:.2e}; vs fp32 oracle: tp lo4 {e_tp_lo4:.2e}, tp fast {e_tp_fast:.2e}, one-rank lo4 {e_one_lo4:.2e}; "
+          f"bytes on the wire fast {sent_fast} -> lo4 {sent_lo4}")
+    assert finite and d_one <= 2.5e-3
+    assert e_tp_lo4 <= e_tp_fast * 1.05
+    assert sent_fast < sent_lo4 < 1.35 * sent_fast

@@ -7,7 +7,7 @@ set -e
 export TMPDIR=/tmp
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/traffic
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python bench.py --steps 1 --warmup 1 --no-roofline --no-cpu-baseline"
+CMD="python bench.py --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --no-fast-line --no-other-configs"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)

@@ -48,31 +48,39 @@ def main():
         W = O.weights_from_numpy(synth_state_dict_numpy(cfg))
     out = {}
     arms = [("fp16", dict()), ("fp16_lo4", dict(lo_sites=ALL)), ("fp8", dict(operand_dtype=torch.float8_e4m3fn))]
+    part_path = args.out + ".partial.npz"            # resumable: every finished sample is saved (a full run is ~1.5 h of host time)
+    done = dict(np.load(part_path)) if os.path.exists(part_path) else {}
     for case, n, (ni, w, h) in (("c1", args.c1, (1, 336, 336)), ("c2", args.c2, (1, 1344, 896))):
-        top_ids, top_val, hashes, ids_all, emu_arg = [], [], [], [], {a: [] for a, _ in arms}
         t0 = time.perf_counter()
         for j in range(n):
+            key = f"{case}_{j}"
+            if f"{key}_top_ids" in done:
+                continue
             u8, ids, _ = sample_inputs(cfg, ni, w, h, seed=SEED0 + 16 * j)
             pix = torch.from_numpy(siglip_normalize(u8))
             ref = O.prefill_logits(ids, pix, W, cfg, last_only=True)[0, 0]
             v, i = ref.topk(8)
-            top_ids.append(i.numpy()); top_val.append(v.numpy()); ids_all.append(ids.numpy().reshape(-1))
-            hashes.append(np.frombuffer(hashlib.sha256(np.ascontiguousarray(u8).tobytes()).digest(), dtype=np.uint8))
+            done[f"{key}_top_ids"], done[f"{key}_top_logits"], done[f"{key}_ids"] = i.numpy(), v.numpy(), ids.numpy().reshape(-1)
+            done[f"{key}_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(u8).tobytes()).digest(), dtype=np.uint8)
             for a, kw in arms:
                 if case == "c2" and a != "fp16_lo4":
                     continue                                   # C2 arms other than lo4: predicted by the C1 set; keep the host time bounded
                 with O.emulate_rounding(torch.float16, **kw):
                     lg = O.prefill_logits(ids, pix, W, cfg, last_only=True)[0, 0]
-                emu_arg[a].append(lg.topk(8)[1].numpy())
+                done[f"{key}_emu_{a}"] = lg.topk(8)[1].numpy()
+            np.savez(part_path, **done)
             print(f"[{case} {j + 1}/{n}] {time.perf_counter() - t0:.0f} s  top1 {int(i[0])} margin {float(v[0] - v[1]):.4f}", flush=True)
-        out[f"{case}_top_ids"] = np.stack(top_ids); out[f"{case}_top_logits"] = np.stack(top_val)
-        out[f"{case}_tiles_sha256"] = np.stack(hashes)
-        out[f"{case}_ids"] = np.stack(ids_all)
+        out[f"{case}_top_ids"] = np.stack([done[f"{case}_{j}_top_ids"] for j in range(n)])
+        out[f"{case}_top_logits"] = np.stack([done[f"{case}_{j}_top_logits"] for j in range(n)])
+        out[f"{case}_tiles_sha256"] = np.stack([done[f"{case}_{j}_sha"] for j in range(n)])
+        out[f"{case}_ids"] = np.stack([done[f"{case}_{j}_ids"] for j in range(n)])
         for a, _ in arms:
-            if emu_arg[a]:
-                out[f"{case}_emu_{a}_top_ids"] = np.stack(emu_arg[a])
+            if f"{case}_0_emu_{a}" in done:
+                out[f"{case}_emu_{a}_top_ids"] = np.stack([done[f"{case}_{j}_emu_{a}"] for j in range(n)])
     out["seed0"] = np.asarray([SEED0])
     np.savez_compressed(args.out, **out)
+    if os.path.exists(part_path):
+        os.remove(part_path)
     print("wrote", args.out, os.path.getsize(args.out), "bytes")
 
 

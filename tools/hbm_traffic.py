@@ -35,6 +35,6 @@ out = {"kernel_family": "lmi::gemm_kernel + lmi::gemm_stagger_kernel (all epilog
        "fetch_bytes_per_launch": fetch_b / launches, "write_bytes_per_launch": write_b / launches,
        "hbm_bytes_per_launch": (fetch_b + write_b) / launches,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 1 --warmup 1 "
-                 "--no-roofline --no-cpu-baseline`; KiB -> bytes, FETCH_SIZE x2 (gfx950 wide-read under-count), Infinity-Cache hits included"}
+                 "--no-roofline --no-cpu-baseline --no-fast-line --no-other-configs` (the default schedule: lo4); KiB -> bytes, FETCH_SIZE x2 (gfx950 wide-read under-count), Infinity-Cache hits included"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

@@ -17,10 +17,13 @@ from leopard_amd.weights import EngineWeights, SynthSource  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 fp8 = len(sys.argv) > 2 and sys.argv[2] == "fp8"          # the fp8 schedule (leopard_amd.fp8) instead of the f16 one
+lo4 = len(sys.argv) > 2 and sys.argv[2] == "lo4"          # the lo4 schedule (precision mode of the prefill; decode steps follow on its cache)
 dev = torch.device("cuda:0")
 cfg = full_config()
 ops = Ops()
 eng = LeopardEngine(cfg, EngineWeights.build(cfg, SynthSource(cfg, ops, dev, torch.float16), torch.float16), ops=ops, device=dev)
+if lo4:
+    eng.precision = "lo4"
 tiles, plan = GpuTiler(ops, dev).tile_sample([synth_image_u8(i, 1344, 896) for i in range(6)])
 ids = torch.from_numpy(synth_prompt_ids(plan.vit_inputs_per_image, cfg, seed=0)).reshape(1, -1)
 S = ids.shape[1] + tiles.shape[0] * (cfg.tokens_per_tile - 1)
@@ -41,10 +44,10 @@ for r in range(reps):
         bad += 0 if same else 1
         if not same:
             print(f"rep {r}: MISMATCH max|d| prefill {float((ref - res.logits_last).abs().max()):.3e}")
-print(f"{'fp8' if fp8 else 'f16'} schedule: {reps} repetitions, {bad} mismatches")
+print(f"{'fp8' if fp8 else ('f16 lo4' if lo4 else 'f16 fast')} schedule: {reps} repetitions, {bad} mismatches")
 # batched decode (pooled KV slots, skinny-M projections, one captured step per token for the batch): same tokens and same final logits
 # every time
-if not fp8:
+if not fp8 and not lo4:
     samples = []
     for j, n in enumerate((1, 2, 1, 3)):
         t, pl = GpuTiler(ops, dev).tile_sample([synth_image_u8(40 + 10 * j + i, 700, 500) for i in range(n)])
