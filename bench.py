@@ -473,6 +473,9 @@ def bench_idefics2(args, dev, dtype, rank, world, D):
     tp = args.parallelism == "tp" and world > 1
     W = Idefics2Weights.build(cfg, Idefics2SynthSource(cfg, ops, dev, dtype), dtype, tp_rank=rank if tp else 0, tp_size=world if tp else 1)
     eng = Idefics2Engine(cfg, W, ops=ops, device=dev)
+    # the reference loads this model in fp16 (idefics2_multiimg.py:27-28): the fast fp16 schedule is its own arithmetic; --precision lo4 = tower + Mistral corrected
+    idef_precision = args.precision if getattr(args, "precision", None) in ("fast", "lo4") else "fast"
+    eng.precision = idef_precision
     n_img = 4
     seed = 0 if tp else rank
     imgs = [torch.from_numpy(preprocess_image_u8(Image.fromarray(synth_image_u8(seed * 16 + i, 1344, 896)), cfg.longest_edge).copy()).to(dev)
@@ -509,7 +512,7 @@ def bench_idefics2(args, dev, dtype, rank, world, D):
            "value": round((1 if tp else world) * n_img * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "strong" if tp else "weak",
-           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "precision_mode": PRECISION_NOTE[idef_precision],
            "config": {"workload": f"C4: 4x(1344x896) -> 980x653, 3220 patches each, 64 visual tokens each, S={S}; NaViT SigLIP (27L) + "
                                   "perceiver (3L) + Mistral-7B (32L) prefill to last-token logits; synthetic seeded weights",
                       "parallelism": (f"one sample on {world} ranks: images round-robin + 1 all-gather; TP{world} Mistral with sequence-parallel norms"
@@ -542,6 +545,10 @@ def measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler):
     Wt = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype, tp_rank=rank, tp_size=world)
     eng = LeopardEngine(cfg, Wt, ops=ops, device=dev)
     eng.fuse_norm_rope = not args.no_fuse
+    tp_precision = args.precision if getattr(args, "precision", None) in ("fast", "lo4") else ("lo4" if args.dtype == "f16" and getattr(args, "precision", None) is None else "fast")
+    if tp_precision == "lo4" and not eng.lo4_supported():
+        tp_precision = "fast"
+    eng.precision = tp_precision                 # lo4 (default, f16): the Lo4 pairs travel through the sequence-parallel norms and the all-gathers
     u8, ids_np, plan, _, raw = make_sample(cfg, args.images, args.width, args.height, seed=0)       # the SAME sample on every rank
     raw_dev = [torch.from_numpy(np.ascontiguousarray(r)).to(dev) for r in raw]
     ids = torch.from_numpy(ids_np).reshape(1, -1)
@@ -568,7 +575,7 @@ def measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler):
     assert res.seq_len == S and torch.isfinite(res.logits_last).all()
     fl = algorithmic_flops(cfg, u8.shape[0], S)
     return {"value": round(args.images * args.steps / elapsed, 3), "unit": "images/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "scaling": "strong", "n_gpus": world,
+            "scaling": "strong", "n_gpus": world, "precision_mode": PRECISION_NOTE[tp_precision],
             "parallelism": f"one sample on {world} ranks: ViT inputs sharded {u8.shape[0]} -> {world} + 1 all-gather; TP{world} LLM with "
                            f"sequence-parallel norms ({eng.tp_chunks} row chunks, all-gather + reduce-scatter per half layer in "
                            f"{'fp32' if eng.tp_comm_dtype == torch.float32 else args.dtype}), column-parallel head",
@@ -600,7 +607,10 @@ OTHER_CONFIGS = [   # (key, BASELINE.json configuration, extra argv) — short r
     ("c2_f16_lo4", "configs[1] shape (1 x 1344x896), fp16 + lo4: the parity-qualified line", ["--images", "1", "--steps", "10", "--warmup", "3"]),
     ("c2_bf16_fast", "configs[1] as worded (1 x 1344x896, bf16)", ["--images", "1", "--dtype", "bf16", "--steps", "10", "--warmup", "3"]),
     ("c3_f16_split", "configs[2] sample, split-operand precision mode (hi + lo 16-bit pairs at 2 K)", ["--precision", "split", "--steps", "3", "--warmup", "1"]),
-    ("c4_idefics2", "configs[3]: Leopard-Idefics2, 4 x 1344x896 (one rank; TP in the N > 1 runs)", ["--workload", "idefics2-c4", "--steps", "10", "--warmup", "3"]),
+    ("c4_idefics2", "configs[3]: Leopard-Idefics2, 4 x 1344x896 (one rank; TP in the N > 1 runs), fp16 fast = the reference's own arithmetic for this model",
+     ["--workload", "idefics2-c4", "--steps", "10", "--warmup", "3"]),
+    ("c4_idefics2_lo4", "configs[3] with the lo4 schedule on the NaViT tower and the Mistral layers (full-depth logits 5.4e-4 of the fp32 oracle's scale)",
+     ["--workload", "idefics2-c4", "--precision", "lo4", "--steps", "10", "--warmup", "3"]),
     ("configs4_fp8_graph", "configs[4]: batch 8 x 8 images, fp8 MFMA ViT + LLM prefill, HIP-graph-captured encode",
      ["--workload", "llava-c5", "--dtype", "fp8", "--graph-encode", "--steps", "3", "--warmup", "2"]),
 ]
