@@ -83,6 +83,7 @@ class GemmTimer:
     def __init__(self):
         self.records = []
         self.bytes = 0              # algorithmic operand + output bytes of the timed launches
+        self.lo4_flops = 0.0        # algorithmic FLOPs of the launches that also ran the fp4 correction phase
 
     def wrap(self, ops):
         inner = ops.gemm
@@ -126,6 +127,7 @@ class GemmTimer:
                 r = fn(a, w, w4, out, *args, **kw)
                 e1.record(torch.cuda.current_stream())
                 timer.records.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1, (M, w.shape[0], w.shape[1])))
+                timer.lo4_flops += 2.0 * M * w.shape[0] * w.shape[1]
                 timer.bytes += ((M + w.shape[0]) * w.shape[1] * w.element_size() + out.numel() * out.element_size()
                                 + a.img.numel() + a.sc.numel() + w4.img.numel())
                 return r
@@ -217,6 +219,8 @@ def roofline_from_timer(ops, run_once, passes: int, fp8: bool):
          "traffic": None, "traffic_unit": "HBM-side bytes per launch (PMC)", "algorithmic_bytes_per_launch": round(timer.bytes / n),
          "kernel_source_hash": kernel_source_hash(), "dominant": dominant, "launches_per_step": n // passes,
          "avg_launch_ms": round(gms / n, 4), "gemm_ms_per_step": round(gms / passes, 2)}
+    if timer.lo4_flops > 0 and not fp8:
+        r["correction_phase_flops_share"] = round(timer.lo4_flops / gflops, 4)
     if rest is not None and rest[2] > 0:
         r["f16_gemms_left"] = {"launches_per_step": rest[2] // passes, "ms_per_step": round(rest[1] / passes, 2),
                                "achieved": round(rest[0] / (rest[1] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS}
@@ -588,8 +592,9 @@ def measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler):
 DEFAULT_PRECISION = "lo4"     # the schedule whose full-depth logits are within north_star's 1e-3 of the fp32 reference
 PRECISION_NOTE = {
     "fast": "fast: one rounding of every activation to the 16-bit compute type per MFMA-operand hand-over",
-    "lo4": "lo4: fast + the MX fp4 image of every layer-linear operand's rounding residual multiplied with an fp4 weight image into the same "
-           "accumulators (v_mfma_scale_f32_32x32x64_f8f6f4, + 25 % matrix time; algorithmic FLOPs below are the model's, not the extra MFMA work)",
+    "lo4": "lo4: fast + the MX fp4 image of every LLM layer-linear operand's rounding residual multiplied with an fp4 weight image into the same "
+           "accumulators (v_mfma_scale_f32_32x32x64_f8f6f4, + 25 % matrix time on those GEMMs; algorithmic FLOPs below are the model's, not the extra "
+           "MFMA work; --lo4-vit 1 / LMI_LO4_VIT=1 extends it to the SigLIP layer linears)",
     "split": "split operands: every A operand of every ViT / LLM layer linear handed over as hi + lo 16-bit values, GEMMs at 2 K "
              "(algorithmic FLOPs below are the model's, not the doubled MFMA work)"}
 
@@ -675,6 +680,9 @@ def main():
     ap.add_argument("--no-fast-line", action="store_true", help="lo4 headline: skip the additional measurement of the fast schedule on the same sample")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configurations appended to the default line")
     ap.add_argument("--cpu-tflops", type=float, default=0.0, help="(internal) host TFLOP/s measured by the parent run: the cpu_baseline of an other_configs child")
+    ap.add_argument("--lo4-vit", type=int, default=0, choices=[0, 1],
+                    help="--precision lo4: 0 = the correction phase on the LLM layer linears (default: full-depth logits 2.4e-4 / 3.9e-4 / 7.3e-4 of the logit "
+                         "scale on C3 / C2 / C1), 1 = on the SigLIP layer linears too (2.4e-4 / 3.3e-4 / 6.1e-4 for + 6 %% of the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-tp", action="store_true", help="N > 1: skip the additional one-sample-on-all-ranks (strong scaling) measurement")
@@ -742,6 +750,7 @@ def main():
     if args.precision is None:
         args.precision = DEFAULT_PRECISION if args.dtype == "f16" else "fast"
     eng.precision = args.precision
+    eng.lo4_vit = bool(args.lo4_vit)
     load_s = time.perf_counter() - t0
 
     class Ctx:
@@ -881,14 +890,16 @@ def main():
         if args.precision == "lo4":
             # matrix-pipe time of the launches at the peak of each phase's operand type: the 16-bit pass at 2.5 PF + the fp4 phase (the same
             # M x N x K again: 2 M N K4 FLOP) at 10 PF — what MFMA-busy counters see; `frac` above prices only the ALGORITHMIC FLOPs
-            rl["frac_incl_correction_phase"] = round(rl["frac"] * (1.0 + MFMA_PEAK_TFLOPS / MFMA_PEAK_FP4_TFLOPS), 4)
-            rl["correction_phase_note"] = ("every launch of the family also runs K4 / 256 k-tiles of v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 images "
-                                           "(4 x the 16-bit rate, dense peak 10 PF): + 25 % matrix-pipe time that `frac` books as overhead")
+            share = rl.get("correction_phase_flops_share", 0.0)
+            rl["frac_incl_correction_phase"] = round(rl["frac"] * (1.0 + share * MFMA_PEAK_TFLOPS / MFMA_PEAK_FP4_TFLOPS), 4)
+            rl["correction_phase_note"] = ("the corrected launches of the family (correction_phase_flops_share of its FLOPs) also run K4 / 256 k-tiles of "
+                                           "v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 images (4 x the 16-bit rate, dense peak 10 PF): + 25 % matrix-pipe time "
+                                           "on those launches that `frac` books as overhead")
         out["roofline"] = rl
     if args.precision == "lo4":
-        lo_fl = fl["total"] - fl["llm_attention"] - fl["lm_head_last"] - n_tiles * vit_attention_flops(cfg) - fl["projector"]
+        lo_fl = fl["llm_linear"] + ((fl["vit"] - n_tiles * vit_attention_flops(cfg)) if args.lo4_vit else 0)
         out["matrix_pipe_frac"] = round((args.inflight * (fl["total"] / MFMA_PEAK_TFLOPS + lo_fl / MFMA_PEAK_FP4_TFLOPS) / 1e12) / (elapsed / args.steps), 4)
-        out["matrix_pipe_frac_note"] = ("algorithmic FLOPs at the 2.5 PF 16-bit peak + the correction phase's FLOPs (every ViT / LLM layer linear once more, "
+        out["matrix_pipe_frac_note"] = ("algorithmic FLOPs at the 2.5 PF 16-bit peak + the correction phase's FLOPs (every corrected layer linear once more, "
                                         f"{lo_fl / 1e12:.1f} TFLOP) at the 10 PF fp4 peak, over the step time; prefill_mfma_frac counts the algorithmic FLOPs only")
     if args.precision == "lo4" and not args.no_fast_line and args.dtype != "fp8":
         # the SAME sample on the fast schedule (one rounding per operand hand-over, no correction phase): the throughput ceiling of the

@@ -136,6 +136,10 @@ class LeopardEngine:
         # phase of v_mfma_scale_f32_32x32x64_f8f6f4 on the two images into the accumulators of the 16-bit pass (lmi_gemm_lo4).  Prefill only;
         # one rank.  ``precision`` = "fast" | "lo4" | "split" selects between the three schedules.
         self.lo4 = False
+        # lo4 corrects the LLM layer linears; ``lo4_vit`` (LMI_LO4_VIT=1) extends it to the SigLIP layer linears.  Off by default: measured at
+        # full depth, the tower's correction moves the logits of the benchmarked C3 sample by < 1 % (2.35e-4 vs 2.37e-4 of the logit scale) and
+        # those of the hardest case — C1: one ViT input, S = 228 — from 7.3e-4 to 6.1e-4, for + 6 % of the step (1.20 x vs 1.27 x the fast schedule)
+        self.lo4_vit = os.environ.get("LMI_LO4_VIT", "0") == "1"
         self._lo4_w = None
         self.skinny_fold_norm = True   # batched decode: RMSNorms folded into the projections (lmi_gemm_skinny_ex producer / consumer); False: norm launches
         self.skinny_packed = True      # batched decode over nn.Linear-layout weights (TP, pack_llm_weights=False): stream a packed second copy
@@ -369,7 +373,7 @@ class LeopardEngine:
             return self._vit_layers_fp8(x, n)
         if self.split_operands:
             return self._vit_layers_split(x, n)
-        if self.lo4:
+        if self.lo4 and self.lo4_vit:
             return self._vit_layers_lo4(x, n)
         qkv_w = W.vit_layers[0].qkv_w.shape[0] if W.vit_layers else 3 * D
         total, offs = ops.vit_workspace(M, D, qkv_w, W.vit_ff, self.dtype)

@@ -148,6 +148,7 @@ class Idefics2Engine(LeopardEngine):
 
     def __init__(self, cfg: Idefics2Config, weights: Idefics2Weights, ops: Optional[Ops] = None, device=None, use_tr: bool = True):
         super().__init__(cfg, weights, ops=ops, device=device, use_tr=use_tr)
+        self.lo4_vit = True            # this model's lo4 mode was qualified (C4 full depth: 5.4e-4) with the NaViT tower corrected as well
 
     # ---- NaViT tower over a list of images of arbitrary sizes ------------------------------------------------
     def vision_tower_images(self, images: Sequence[torch.Tensor]):
@@ -176,7 +177,7 @@ class Idefics2Engine(LeopardEngine):
         cu = self._pinned_to_device(torch.tensor(cu_list, dtype=torch.int32))
         h = self._empty(M, D)
         qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0])
-        if self.lo4:
+        if self.lo4 and self.lo4_vit:
             # precision "lo4" (LeopardEngine._vit_layers_lo4): every layer-linear operand of the NaViT tower travels with the fp4 image of its
             # rounding residual; the connector (modality projection + 3 perceiver layers) keeps the fast schedule, the Mistral layers take
             # LeopardEngine._llm_layers_lo4

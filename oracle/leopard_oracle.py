@@ -72,6 +72,7 @@ class _Emu:
                           # hand-over sites the A operand is handed over as T(x) PLUS an MX block-scaled low-bit image of the rounding
                           # residual x - T(x) (per-32-element E8M0 scale along the contraction axis), multiplied with a low-bit image of
                           # the weight (one E8M0 scale per weight row) into the same fp32 accumulators
+    tower = ""            # "vit" / "llm" while that stack runs: lo_sites / exact_sites entries may be tower-qualified ("llm.mlp_act")
     lo_fmt = "e2m1"       # element format of the residual and of the weight image: "e2m1" (fp4), "e2m3" / "e3m2" (fp6), "e4m3" (fp8)
     lo_wblock = 0         # 0 = one scale per weight row (what the engine does); 32 = per-32 block scales on the weight image (study)
     _wcache: dict = {}
@@ -139,10 +140,15 @@ def _qa(x: Tensor, site: str = "") -> Tensor:
     """Hand-over point that is the A operand of a ViT / LLM layer linear (norm outputs, attention output, GELU / SwiGLU output)."""
     if site and site in _Emu.exact_sites:
         return x
-    if site and site in _Emu.lo_sites and _Emu.dtype is not None and _Emu.operand_dtype is None:
+    if site and _site_in(site, _Emu.lo_sites) and _Emu.dtype is not None and _Emu.operand_dtype is None:
         hi = _q(x)
         return _Split(hi, _lo_round(x - hi, _Emu.lo_fmt, 32))
     return _q(x) if _Emu.operand_dtype is None else _fp8_round(x)
+
+
+def _site_in(site: str, sites) -> bool:
+    """``site`` ("norm" / "attn_out" / "mlp_act") is selected by ``sites`` either plainly or qualified with the running tower ("llm.mlp_act")."""
+    return site in sites or (_Emu.tower + "." + site) in sites
 
 
 def _lin(h, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
@@ -346,7 +352,7 @@ def siglip_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, prefix: str = "vi
     s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)      # full (non-causal) attention per tile
     a = _softmax_q(s)
     o = torch.matmul(a, v).transpose(1, 2).reshape(N, T, D)
-    o = _qa(o if "attn_out" in _Emu.exact_sites | _Emu.lo_sites else _q(o), "attn_out")
+    o = _qa(o if ("attn_out" in _Emu.exact_sites or _site_in("attn_out", _Emu.lo_sites)) else _q(o), "attn_out")
     x = r + _lin(o, W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"])
     r = x
     h = _qa(F.layer_norm(x, (D,), W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], vc.layer_norm_eps), "norm")
@@ -359,9 +365,11 @@ def siglip_vision_tower(pixel_values: Tensor, W: Dict[str, Tensor], cfg) -> Tens
     post-layernorm included, pooling head not computed (its output is unused by the reference)."""
     x = siglip_embeddings(pixel_values, W, cfg)
     _tr("vit.embed", x)
+    _Emu.tower = "vit"
     for i in range(cfg.vision_config.num_hidden_layers):
         x = siglip_layer(x, W, i, cfg)
         _tr(f"vit.{i}", x)
+    _Emu.tower = ""
     p = "vision_tower.vision_model.post_layernorm."
     return _q(F.layer_norm(x, (x.shape[-1],), W[p + "weight"], W[p + "bias"], cfg.vision_config.layer_norm_eps))
 
@@ -480,9 +488,9 @@ def _rms_norm_q(x: Tensor, w: Tensor, eps: float, first: bool) -> Tensor:
     if "norm" in _Emu.exact_sites:
         return rms_norm(x, w, eps)
     if _Emu.dtype is None or not _Emu.fused or first:
-        return _qa(rms_norm(x, w, eps), "norm" if "norm" in _Emu.lo_sites else "")
+        return _qa(rms_norm(x, w, eps), "norm" if _site_in("norm", _Emu.lo_sites) else "")
     v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
-    if "norm" in _Emu.lo_sites:                      # the producer also emits the low-bit image of x * gamma - T(x * gamma)
+    if _site_in("norm", _Emu.lo_sites):              # the producer also emits the low-bit image of x * gamma - T(x * gamma)
         return _qa(x * w, "norm").scaled(torch.rsqrt(v + eps))
     return _q(x * w) * torch.rsqrt(v + eps)          # producer epilogue rounds x * gamma; the consumer applies rstd in fp32
 
@@ -522,7 +530,7 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
         sc = sc.masked_fill(~causal, float("-inf"))
         o[:, :, s0:s1] = torch.matmul(_softmax_q(sc, fp8_p=a8), vv[:, :, :s1])
     o = o.transpose(1, 2).reshape(B, S, H * hd)
-    o = _qa(o if "attn_out" in _Emu.exact_sites | _Emu.lo_sites else _q(o), "attn_out")
+    o = _qa(o if ("attn_out" in _Emu.exact_sites or _site_in("attn_out", _Emu.lo_sites)) else _q(o), "attn_out")
     x = r + _lin(o, W[p + "self_attn.o_proj.weight"])
     r = x
     h = _rms_norm_q(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps, first=False)
@@ -541,9 +549,11 @@ def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tens
     cos, sin = rope_tables(position_ids, tc.head_dim, tc.rope_theta, tc.rope_scaling)
     x = inputs_embeds
     _tr("llm.embed", x)
+    _Emu.tower = "llm"
     for i in range(tc.num_hidden_layers):
         x = llama_layer(x, W, i, cfg, cos, sin, kv_out, prefix=prefix)
         _tr(f"llm.{i}", x)
+    _Emu.tower = ""
     x = rms_norm(x, W[prefix + "norm.weight"], tc.rms_norm_eps)
     if last_only:
         x = x[:, -1:, :]

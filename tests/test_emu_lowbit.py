@@ -303,8 +303,15 @@ def test_engine_lo4_mode_lands_on_the_oracle_prediction():
     with O.emulate_rounding(dtype, exact_sites=sites):
         floor = O.prefill_logits(ids, pix, Wt, cfg)[0]
     base = eng.prefill(ids, tiles, all_logits=True).logits_all.clone()
-    assert eng.precision == "fast"
+    assert eng.precision == "fast" and eng.lo4_vit is False          # default: the LLM layers only
     eng.precision = "lo4"
+    llm_only = eng.prefill(ids, tiles, all_logits=True).logits_all.clone()
+    with O.emulate_rounding(dtype, lo_sites=("llm.norm", "llm.attn_out", "llm.mlp_act")):
+        emu_llm = O.prefill_logits(ids, pix, Wt, cfg)[0]
+    e_l, e_lp = (llm_only - ref).abs().max().item() / ref.abs().max().item(), (emu_llm - ref).abs().max().item() / ref.abs().max().item()
+    # (1 + 3 layers: the uncorrected SigLIP layer and the attention operands dominate here; full depth: tests/test_gpu_parity.py)
+    assert e_l <= 1.05 * (base - ref).abs().max().item() / ref.abs().max().item() and 0.5 * e_lp <= e_l <= 2.0 * e_lp, (e_l, e_lp)
+    eng.lo4_vit = True                                                # + the SigLIP layer linears (what the oracle arm `sites` emulates)
     cache = KVCache(cfg, 64, dtype, "cpu")
     res = eng.prefill(ids, tiles, cache=cache, all_logits=True)
     got = res.logits_all
@@ -316,6 +323,7 @@ def test_engine_lo4_mode_lands_on_the_oracle_prediction():
     # (two runs with the same rounding points are as far from each other as each is from fp32 — DESIGN.md 2.1 — so got vs emu is not asserted)
     assert cache.length == res.seq_len and bool(cache.k[2][:cache.length].abs().sum() > 0)
     eng.precision = "fast"
+    eng.lo4_vit = False
     assert torch.equal(eng.prefill(ids, tiles, all_logits=True).logits_all, base)
     with pytest.raises(ValueError):
         eng.precision = "fp64"

@@ -225,7 +225,7 @@ def test_tensor_parallel_c2_full_depth_vs_oracle_fixture_and_tp_checkpoint_load(
     scale = ref.abs().max().item()
     errs = {k: (torch.tensor(v) - ref).abs().max().item() / scale for k, v in v0.items()}
     print("[tp2 C2 full depth fp16] max|logit diff| / max|logit| vs the fp32 oracle fixture:", {k: f"{e:.3e}" for k, e in errs.items()},
-          "(one rank, fast schedule: 1.14e-3; one rank, lo4: 3.3e-4)")
+          "(one rank, fast schedule: 1.14e-3; one rank, lo4: 3.9e-4)")
     for k, v in v0.items():
         assert int(torch.tensor(v).argmax()) == int(ref.argmax()), k
     # the 16-bit exchange adds one rounding per partial product and half layer; the fp32 exchange must stay on the one-rank fast budget

@@ -178,13 +178,14 @@ def rel_rms(a, b):
     return ((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt()).item()
 
 
-def run_full_depth(ops, fx, dtype, split=False, precision=None):
+def run_full_depth(ops, fx, dtype, split=False, precision=None, lo4_vit=False):
     from leopard_amd.engine import LeopardEngine
     from leopard_amd.weights import EngineWeights, SynthSource
     cfg = full_config()
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, torch.device(DEV), dtype), dtype)
     eng = LeopardEngine(cfg, W, ops=ops, device=torch.device(DEV))
     eng.precision = precision or ("split" if split else "fast")
+    eng.lo4_vit = lo4_vit
     probes = {}
     eng.trace = lambda name, x: probes.__setitem__(name, fx.probe_of(name, x.detach()).float().cpu())
     res = eng.prefill(fx.ids.to(DEV), torch.from_numpy(fx.u8).to(DEV))
@@ -253,9 +254,10 @@ def test_full_depth_split_operands_meets_1e_3(ops, full_depth_oracle, case):
 @pytest.mark.parametrize("case", ["c1", "c2", "c3"])
 def test_full_depth_lo4_meets_1e_3(ops, full_depth_oracle, case):
     """north_star's figure on the schedule the bench line is quoted on (round 5): engine.precision = "lo4" — the fast schedule + the fp4 image of
-    every layer-linear operand's rounding residual multiplied into the same accumulators (+ 25 % matrix time, not + 100 %).  Last-position
-    logits of C1, C2 and C3 at FULL depth within 1e-3 of the fp32 reference, normalised by the logit scale (the absolute figure is printed beside
-    it); predicted by the oracle that emulates exactly this arithmetic: C1 6.1e-4 (profiles/r05_lowbit_correction_study_c1.txt)."""
+    every LLM layer-linear operand's rounding residual multiplied into the same accumulators (+ 25 % matrix time on those GEMMs, not + 100 %).
+    Last-position logits of C1, C2 and C3 at FULL depth within 1e-3 of the fp32 reference, normalised by the logit scale (the absolute figure is
+    printed beside it); predicted by the oracle that emulates exactly this arithmetic: C1 7.9e-4, and 6.1e-4 with the SigLIP tower corrected as
+    well (profiles/r05_lowbit_correction_study_c1*.txt; the next test)."""
     fx = full_depth_oracle[case]
     got, probes = run_full_depth(ops, fx, torch.float16, precision="lo4")
     a, n, r = err_stats(got, fx.ref)
@@ -263,10 +265,23 @@ def test_full_depth_lo4_meets_1e_3(ops, full_depth_oracle, case):
     print(f"[{case} full depth fp16, lo4 correction] vs fp32 oracle: max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}  max|logit| {fx.ref.abs().max():.3f}  "
           f"residual stream after {last} (probe rows) rel-rms {rel_rms(probes[last], fx.probe[last]):.3e}  argmax equal = {int(got.argmax()) == int(fx.ref.argmax())}")
     assert n <= 1.0e-3 and int(got.argmax()) == int(fx.ref.argmax())
-    # and it is the fast schedule's error that was removed: the fp32 residual stream after the last layer is >= 2 x closer than the 16-bit budget
+    # and it is the fast schedule's error that was removed: the fp32 residual stream after the last layer is well inside the 16-bit budget
+    # (the SigLIP tower's share of that budget stays: lo4 corrects the LLM layer linears by default)
     pred16 = fx.pred.get("fp16", {}).get(last)
     if pred16:
-        assert rel_rms(probes[last], fx.probe[last]) <= 0.6 * pred16
+        assert rel_rms(probes[last], fx.probe[last]) <= 0.8 * pred16
+
+
+@pytest.mark.parametrize("case", ["c1", "c2", "c3"])
+def test_full_depth_lo4_with_the_tower_corrected_too(ops, full_depth_oracle, case):
+    """engine.lo4_vit = True (LMI_LO4_VIT=1, bench.py --lo4-vit 1): the correction phase on the SigLIP layer linears as well.  Measured: C1 6.1e-4
+    (7.3e-4 without), C2 3.3e-4 (3.9e-4), C3 2.37e-4 (2.35e-4: no difference on the benchmarked sample) for + 6 % of the step — which is why the
+    default corrects the LLM layers only (predicted for C1: 7.9e-4, profiles/r05_lowbit_correction_study_c1_sites.txt)."""
+    fx = full_depth_oracle[case]
+    got, _ = run_full_depth(ops, fx, torch.float16, precision="lo4", lo4_vit=True)
+    a, n, r = err_stats(got, fx.ref)
+    print(f"[{case} full depth fp16, lo4 incl. the SigLIP tower] vs fp32 oracle: max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}")
+    assert n <= 1.0e-3 and int(got.argmax()) == int(fx.ref.argmax())
 
 
 @pytest.mark.parametrize("case", ["c2"])

@@ -27,6 +27,10 @@ ARMS = {
     "none": ("all hand-overs rounded once (the fast schedule)", dict()),
     "e2m1": ("fp4 e2m1 residual x fp4 weight image, every layer linear", dict(lo_sites=ALL, lo_fmt="e2m1")),
     "e2m1-noattn": ("fp4 e2m1, norm + mlp_act operands only (attention output rounded once)", dict(lo_sites=("norm", "mlp_act"), lo_fmt="e2m1")),
+    "e2m1-no-llm-mlp": ("fp4 e2m1 everywhere except the Llama down_proj operand (SwiGLU output rounded once)",
+                        dict(lo_sites=("norm", "attn_out", "vit.mlp_act"), lo_fmt="e2m1")),
+    "e2m1-no-vit": ("fp4 e2m1 on the Llama layers only (SigLIP on the fast schedule)", dict(lo_sites=("llm.norm", "llm.attn_out", "llm.mlp_act"), lo_fmt="e2m1")),
+    "e2m1-no-llm-attn": ("fp4 e2m1 everywhere except the Llama o_proj operand", dict(lo_sites=("norm", "vit.attn_out", "mlp_act"), lo_fmt="e2m1")),
     "e2m1-wblock": ("fp4 e2m1, every layer linear, per-32 block scales on the weight image too", dict(lo_sites=ALL, lo_fmt="e2m1", lo_wblock=32)),
     "e2m3": ("fp6 e2m3 residual x fp6 weight image, every layer linear", dict(lo_sites=ALL, lo_fmt="e2m3")),
     "e4m3": ("fp8 e4m3 residual x fp8 weight image, every layer linear", dict(lo_sites=ALL, lo_fmt="e4m3")),
