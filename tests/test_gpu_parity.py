@@ -762,3 +762,29 @@ def test_full_size_engine_holds_one_copy_of_the_llm_weights(ops):
           f"with the KV pools and workspaces")
     assert resident < 19e9
     eng.release_batch_state()
+
+
+def test_prefills_on_two_streams_do_not_share_scratch(ops):
+    """the engine's activation workspaces were keyed by stage only, so two prefills in flight on different HIP streams
+    (bench.py --inflight 2) wrote the same scratch.  Workspaces are per (stage, launch stream) now: two samples prefilled concurrently on two
+    streams, three times over, give bit for bit the logits of the same samples prefilled one after the other — in the fast and lo4 schedules."""
+    cfg = mid_config()
+    eng = build_engine(cfg, ops, torch.float16)
+    samples = []
+    for n, w, h, seed in [(2, 1344, 896, 31), (1, 800, 500, 32)]:
+        u8, ids, _ = sample_inputs(cfg, n, w, h, seed=seed)
+        samples.append((ids, torch.from_numpy(u8).to(DEV)))
+    streams = [torch.cuda.Stream(device=DEV) for _ in samples]
+    for mode in ("fast", "lo4"):
+        eng.precision = mode
+        ref = [eng.prefill(ids, tiles).logits_last.clone() for ids, tiles in samples]
+        torch.cuda.synchronize()
+        for _ in range(3):
+            outs = []
+            for (ids, tiles), st in zip(samples, streams):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    outs.append(eng.prefill(ids, tiles).logits_last)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref)), mode
+    assert len({k[1] for k in eng._workspaces}) >= 2            # one workspace per launch stream
