@@ -1,3 +1,5 @@
+"""Isolated-launch timing of one Llama layer's gate/up and down GEMMs: fast schedule, lo4 without and with the residual image written
+(profiles/r05_lo4_epilogue_ab.txt).  GPU only:  python tools/bench_lo4_launch.py"""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from leopard_amd import _lib
