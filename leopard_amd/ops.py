@@ -22,6 +22,13 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _ptr_f32(t: Optional[torch.Tensor], what: str = "bias"):
+    """The C-ABI takes biases / addmats as ``const float*``: a 16-bit tensor would be read past its end as garbage, silently."""
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError(f"leopard_amd: {what} must be float32 (the C-ABI reads const float*), got {t.dtype}")
+    return _ptr(t)
+
+
 def lo4_k4(K: int) -> int:
     """Width of the fp4 images of a K-wide operand: K rounded up to the 256-element k-tile of the correction phase."""
     return (K + 255) // 256 * 256
@@ -115,7 +122,7 @@ class Ops:
         pixels: u8 [n,S,S,3] or fp32 [n,3,S,S]; w_fused: T [N, KP] in image K order (weights.patch_weight_image_order)."""
         from_u8 = pixels.dtype == torch.uint8
         assert pixels.is_contiguous() and out.is_contiguous() and (from_u8 or pixels.dtype == torch.float32) and out.dtype == torch.float32
-        self._check(self.lib.lmi_patch_embed(_ptr(pixels), int(from_u8), _ptr(w_fused), _ptr(bias), _ptr(pos_emb), _ptr(out), pixels.shape[0],
+        self._check(self.lib.lmi_patch_embed(_ptr(pixels), int(from_u8), _ptr(w_fused), _ptr_f32(bias), _ptr(pos_emb), _ptr(out), pixels.shape[0],
                                              image_size, patch, w_fused.shape[0], w_fused.stride(0), out.stride(0), _DT[w_fused.dtype],
                                              self._stream(out)))
         return out
@@ -135,7 +142,7 @@ class Ops:
         N, K = w.shape
         if M is None:
             M = a.shape[0]
-        self._check(self.lib.lmi_gemm_bias_act(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), M, N, K, a.stride(0), w.stride(0), out.stride(0), act,
+        self._check(self.lib.lmi_gemm_bias_act(_ptr(a), _ptr(w), _ptr(out), _ptr_f32(bias), M, N, K, a.stride(0), w.stride(0), out.stride(0), act,
                                                int(bool(residual)), int(ps_grid), _DT[w.dtype], self._stream(out)))
         return out
 
@@ -183,7 +190,7 @@ class Ops:
         if M is None:
             M = a.shape[0]
         add_period = 0 if addmat is None else addmat.shape[0]
-        self._check(self.lib.lmi_gemm(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(addmat), _ptr(add_rows), _ptr(row_map), M, N, K,
+        self._check(self.lib.lmi_gemm(_ptr(a), _ptr(w), _ptr(out), _ptr_f32(bias), _ptr_f32(addmat, "addmat"), _ptr(add_rows), _ptr(row_map), M, N, K,
                                       a.stride(0), self._ldw(w), out.stride(0), add_period, epilogue, act, a_mode,
                                       ps_grid, _DT[w.dtype], self._stream(out)))
         return out
@@ -313,7 +320,7 @@ class Ops:
     def gemv(self, w, x, out, bias=None, epilogue=0):
         N, K = w.shape
         assert not getattr(w, "_lmi_packed", False), "gemv: the GEMV kernels read the row-major layout"
-        self._check(self.lib.lmi_gemv(_ptr(w), _ptr(x), _ptr(bias), _ptr(out), N, K, w.stride(0), epilogue,
+        self._check(self.lib.lmi_gemv(_ptr(w), _ptr(x), _ptr_f32(bias), _ptr(out), N, K, w.stride(0), epilogue,
                                       _DT[w.dtype], self._stream(out)))
         return out
 
@@ -355,7 +362,7 @@ class Ops:
             assert rowsq_in.dtype == torch.float32 and rowsq_in.is_contiguous() and rowsq_in.shape[0] >= M
         if norm_out is not None:
             assert rowsq_out is not None and rowsq_out.dtype == torch.float32 and rowsq_out.is_contiguous() and rowsq_out.shape == (M, N // 64)
-        self._check(self.lib.lmi_gemm_ex(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), M, N, K, a.stride(0), self._ldw(w), out.stride(0), epilogue, act,
+        self._check(self.lib.lmi_gemm_ex(_ptr(a), _ptr(w), _ptr(out), _ptr_f32(bias), M, N, K, a.stride(0), self._ldw(w), out.stride(0), epilogue, act,
                                          _ptr(rowsq_in), parts, int(norm_dim), float(norm_eps), _ptr(norm_out), _ptr(norm_gamma), _ptr(rowsq_out),
                                          0 if norm_out is None else norm_out.stride(0), _DT[w.dtype], self._stream(out)))
         return out
@@ -396,7 +403,7 @@ class Ops:
             dt = _lib.LMI_FP8
         else:
             dt = _DT[out.dtype] if out.dtype in (torch.float16, torch.bfloat16) else LMI_F16
-        self._check(self.lib.lmi_gemm_fp8(_ptr(a8), _ptr(w8), _ptr(out), _ptr(bias), M, N, K, a8.stride(0), w8.stride(0), out.stride(0),
+        self._check(self.lib.lmi_gemm_fp8(_ptr(a8), _ptr(w8), _ptr(out), _ptr_f32(bias), M, N, K, a8.stride(0), w8.stride(0), out.stride(0),
                                           epilogue, act, int(scale_exp), dt, float(out_scale), self._stream(out)))
         return out
 
@@ -474,7 +481,7 @@ class Ops:
         M = a.hi.shape[0]
         parts = 0 if rowsq_in is None else rowsq_in.shape[1]
         d = self._lo4_desc(a, w4, out4)
-        self._check(self.lib.lmi_gemm_lo4(_ptr(a.hi), _ptr(w), _ptr(out), _ptr(bias), M, N, K, a.hi.stride(0), self._ldw(w), out.stride(0), epilogue, act,
+        self._check(self.lib.lmi_gemm_lo4(_ptr(a.hi), _ptr(w), _ptr(out), _ptr_f32(bias), M, N, K, a.hi.stride(0), self._ldw(w), out.stride(0), epilogue, act,
                                           _ptr(rowsq_in), parts, int(norm_dim), float(norm_eps), _ptr(norm_out), _ptr(norm_gamma), _ptr(rowsq_out),
                                           0 if norm_out is None else norm_out.stride(0), C.byref(d), _DT[w.dtype], self._stream(out)))
         return out

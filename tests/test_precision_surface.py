@@ -87,3 +87,15 @@ def test_streaming_harness_prepares_pixels_when_a_slot_admits_the_record(tmp_pat
     q, n_vit, enc = harness.plan_record(recs[3], "direct", Tok())
     s = harness.prepare_sample(recs[3], "direct")
     assert q == s.question and n_vit == len(s.vit_inputs)
+
+
+def test_ops_refuse_a_16_bit_bias():
+    """The C-ABI reads biases / addmats as const float*: the wrappers refuse anything else instead of letting the kernel read past the tensor."""
+    from tests.emu_util import emu_ops
+    ops = emu_ops()
+    a = torch.zeros(64, 128, dtype=torch.float16)
+    w = torch.zeros(128, 128, dtype=torch.float16)
+    out = torch.zeros(64, 128, dtype=torch.float16)
+    with pytest.raises(TypeError, match="float32"):
+        ops.gemm(a, w, out, bias=torch.zeros(128, dtype=torch.float16))
+    ops.gemm(a, w, out, bias=torch.zeros(128, dtype=torch.float32))
