@@ -14,8 +14,8 @@ Multi-GPU (`--gpus N`, one rank per GPU): the headline shards by SAMPLE exactly 
 (run_eval_llava_siglip_multiimg.sh:9-11, one process per GPU over dataset shards, no collective on the data path): every
 rank prefills its own sample, per-GPU work is fixed ("weak" scaling), value = ranks x images / max-over-ranks time.  The
 same line also carries `"tp"`: ONE sample per step on all ranks (tile-sharded ViT + all-gather, sequence-parallel
-tensor-parallel LLM over RCCL; strong scaling), measured after the headline under a watchdog; `--parallelism tp` makes
-it the headline.  `backend`, `rccl_ranks` and `comm_bytes_per_step` say what carried the ranks.
+tensor-parallel LLM over RCCL; strong scaling), measured after the headline in one child process per rank (a crash or hang
+there costs the `tp` object, not the line); `--parallelism tp` makes it the headline.  `backend`, `rccl_ranks` and `comm_bytes_per_step` say what carried the ranks.
 
 One JSON line on rank 0:  metric/value/unit + roofline (dominant kernel = the MFMA GEMM family incl. its fused norm / RoPE
 epilogues, HIP-event timed on the launch stream; `dominant` = the single largest shape) + cpu_baseline (the CPU oracle's
@@ -648,6 +648,44 @@ def run_other_configs(cpu_tflops: float, timeout_s: float = 240.0) -> dict:
     return res
 
 
+def run_tp_child(args, rank, world, D, dev) -> dict:
+    """The one-sample-on-all-ranks measurement (`--parallelism tp` of this script) as one child process per rank: same RANK / LOCAL_RANK /
+    WORLD_SIZE, a rendezvous port of its own (picked by rank 0, agreed over the parent group), the parent's GPU released first.  The
+    parent waits at most --tp-timeout seconds and kills exactly the child it started; rank 0 returns the child's "tp" object."""
+    import socket
+    import subprocess
+    port = 0
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    port = int(D.max_over_ranks(float(port), dev))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}      # the child is its own rendezvous, not the agent's
+    env["MASTER_PORT"] = str(port)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--parallelism", "tp", "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--dtype", args.dtype, "--images", str(args.images), "--width", str(args.width), "--height", str(args.height)]
+    if args.precision in ("fast", "lo4"):
+        cmd += ["--precision", args.precision]
+    if args.no_fuse:
+        cmd.append("--no-fuse")
+    for kv in args.opt:
+        cmd += ["--opt", kv]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = p.communicate(timeout=args.tp_timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        so, se = p.communicate()
+        return {"error": f"tensor-parallel measurement (child process of rank {rank}) did not finish within {args.tp_timeout:.0f} s", "stderr_tail": (se or "")[-300:]}
+    if rank != 0:
+        return {}
+    line = [l for l in so.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not line:
+        return {"error": f"child process of rank 0 exited with {p.returncode}", "stderr_tail": (se or "no output")[-300:]}
+    return json.loads(line[-1]).get("tp", {"error": "child line has no tp object"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -935,32 +973,20 @@ def main():
             "c3_extrapolated": {"value": round(args.images / (fl["total"] / 1e12 / tflops), 5), "unit": "images/s",
                                 "sample": f"2 SigLIP layers x 2 tiles + 1 Llama layer at S=1024 ({t:.2f} s, {tflops:.3f} TFLOP/s), "
                                           "scaled to the C3 sample (140.1 TFLOP) by algorithmic FLOPs"}}
-    if world > 1 and not args.no_tp:
-        # The same sample on ALL ranks (strong scaling), reported beside the replica headline.  It is the part of this program that
-        # no 1-GPU box can exercise, so it runs under a watchdog: whatever happens in it, rank 0 still prints the headline line.
-        import threading
-        done = threading.Event()
-
-        def give_up():
-            if done.is_set():
-                return
-            if rank == 0:
-                out["tp"] = {"error": f"tensor-parallel measurement did not finish within {args.tp_timeout:.0f} s"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        timer = threading.Timer(args.tp_timeout, give_up)
-        timer.daemon = True
-        timer.start()
+    if world > 1 and not args.no_tp and args.dtype == "fp8":
+        out["tp"] = {"skipped": "the tensor-parallel layer runs the 16-bit schedules (fast / lo4)"}
+    elif world > 1 and not args.no_tp:
+        # The same sample on ALL ranks (strong scaling), reported beside the replica headline.  It is the part of this program that no
+        # 1-GPU box can exercise, so every rank runs it in a CHILD process (own process group on its own port, run_tp_child): an RCCL
+        # abort, a hang or a crash there costs the "tp" object, never the headline line.
+        del eng, W
+        ctxs.clear()
+        torch.cuda.empty_cache()
         try:
-            del eng, W
-            ctxs.clear()
-            torch.cuda.empty_cache()
             D.barrier()
-            out["tp"] = measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler)
+            out["tp"] = run_tp_child(args, rank, world, D, dev)
         except Exception as e:                                      # noqa: BLE001  (reported, not swallowed: the line carries it)
             out["tp"] = {"error": repr(e)[:500]}
-        done.set()
-        timer.cancel()
     default_line = (args.workload == "llava-c3" and (args.images, args.width, args.height) == (6, 1344, 896) and args.dtype == "f16" and args.inflight == 1)
     if rank == 0 and world == 1 and default_line and not args.no_other_configs:
         if "eng" in dir():
