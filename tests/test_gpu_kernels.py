@@ -114,6 +114,34 @@ def test_gemm_residual_storef32_addmat_rowmap(ops, dtype):
     assert (big[perm.long()] - ref).abs().max() <= 2e-4
 
 
+@pytest.mark.parametrize("case", ["gelu_tanh", "gelu_erf", "swiglu", "plain"])
+def test_gemm_epilogue_rows_do_not_depend_on_their_position(ops, case):
+    """A row's result must not depend on where it sits in the launch (which unrolled copy of the epilogue, which tile geometry handles it): the
+    packed == separate bit-identities of the engine rest on it.  hipcc contracts plain `*` / `+` chains differently in different unrolled copies
+    (round 5: a rewritten tanh-GELU flipped one fp16 tie in ~3e5 elements until its multiplies were individually rounded), so every activation
+    epilogue is checked here: the same rows at shifted positions of the same geometry, and through three geometries (M = 300 / 729 / 6000)."""
+    from leopard_amd.weights import interleave_gate_up
+    dtype = torch.float16
+    K = 1152
+    N = 4352 if case != "swiglu" else 2 * 2176
+    a = rnd((6100, K), dtype, 31, 0.5)
+    w = rnd((N, K), dtype, 32, 0.05)
+    bias = None if case == "swiglu" else rnd((N,), torch.float32, 33, 0.1)
+    if case == "swiglu":
+        w = interleave_gate_up(w[:N // 2].contiguous(), w[N // 2:].contiguous())
+    kw = {"gelu_tanh": dict(act=_lib.ACT_GELU_TANH), "gelu_erf": dict(act=_lib.ACT_GELU_ERF), "swiglu": dict(epilogue=_lib.EPI_SWIGLU), "plain": {}}[case]
+
+    def run(rows):
+        out = torch.empty(rows.shape[0], N // 2 if case == "swiglu" else N, dtype=dtype, device=DEV)
+        ops.gemm(rows, w, out, bias=bias, **kw)
+        return out
+    base = run(a[:6000])
+    for sh in (1, 7, 32, 33, 64, 100):
+        assert torch.equal(run(a[sh:sh + 6000])[:6000 - sh], base[sh:]), f"{case}: rows shifted by {sh} differ"
+    for lo, hi in ((0, 300), (41, 341), (0, 729), (729, 1458), (100, 164)):
+        assert torch.equal(run(a[lo:hi]), base[lo:hi]), f"{case}: rows {lo}:{hi} alone differ from the same rows inside M = 6000"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_swiglu_llama_shape(ops, dtype):
     from leopard_amd.weights import interleave_gate_up

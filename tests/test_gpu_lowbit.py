@@ -208,6 +208,48 @@ def test_gemm_lo4_production_shapes(ops, name, M, N, K, kind):
         assert after < 0.3 * before, (before, after)
 
 
+@pytest.mark.parametrize("kind", ["gelu_out4", "producer", "swiglu_out4"])
+def test_gemm_lo4_rows_and_their_images_do_not_depend_on_their_position(ops, kind):
+    """The 16-bit result, the residual image and its block scales of a row are the same bits wherever the row sits in the launch and whichever tile
+    geometry handles it (M = 300 / 729 / 3000): hipcc contracts `a * b - T(a * b)` into a fused multiply-subtract or not per unrolled copy of an
+    epilogue unless the product is individually rounded — which would move image ties with the row's position (the packed == separate
+    bit-identities of the lo4 engine rest on this; the fast-schedule twin is tests/test_gpu_kernels.py)."""
+    dtype = torch.float16
+    K, N = 1152, (2176 * 2 if kind == "swiglu_out4" else 2304)
+    x = rnd((3100, K), torch.float32, 40, 1.5)
+    w = rnd((N, K), dtype, 41, 0.03)
+    if kind == "swiglu_out4":
+        w = interleave_gate_up(w[:N // 2].contiguous(), w[N // 2:].contiguous())
+    w4 = ops.quantize_w4(w)
+    bias = rnd((N,), torch.float32, 42, 0.5)
+    gamma = (torch.rand(N, generator=torch.Generator().manual_seed(43)) + 0.5).to(DEV)
+
+    def run(lo, hi):
+        act = act_from(ops, x[lo:hi], dtype)
+        M = hi - lo
+        if kind == "gelu_out4":
+            o4 = Lo4Act.empty(M, N, dtype, DEV)
+            ops.gemm_lo4(act, w, w4, o4.hi, bias=bias, act=_lib.ACT_GELU_TANH, out4=o4)
+            return (o4.hi, o4.img, o4.sc)
+        if kind == "producer":
+            xs = torch.ones(M, N, dtype=torch.float32, device=DEV)
+            h = Lo4Act.empty(M, N, dtype, DEV)
+            sq = torch.empty(M, N // 64, dtype=torch.float32, device=DEV)
+            ops.gemm_lo4(act, w, w4, xs, epilogue=_lib.EPI_RESIDUAL, norm_out=h.hi, norm_gamma=gamma, rowsq_out=sq, out4=h)
+            return (xs, h.hi, h.img, h.sc, sq)
+        o4 = Lo4Act.empty(M, N // 2, dtype, DEV)
+        ops.gemm_lo4(act, w, w4, o4.hi, epilogue=_lib.EPI_SWIGLU, out4=o4)
+        return (o4.hi, o4.img, o4.sc)
+
+    base = run(0, 3000)
+    for sh in (1, 7, 32, 33, 64, 100):
+        for t, b in zip(run(sh, sh + 3000), base):
+            assert torch.equal(t[:3000 - sh], b[sh:]), f"{kind}: rows shifted by {sh} differ"
+    for lo, hi in ((0, 300), (41, 341), (0, 729), (729, 1458), (100, 164)):
+        for t, b in zip(run(lo, hi), base):
+            assert torch.equal(t, b[lo:hi]), f"{kind}: rows {lo}:{hi} alone differ from the same rows inside M = 3000"
+
+
 def test_rmsnorm_rope_lo4_at_the_llama_shape(ops):
     dtype = torch.float16
     S, nq, nkv, D, K = 7187, 32, 8, 128, 4096
