@@ -114,7 +114,10 @@ struct GemmCfg {
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int SMEM = STAGES * STAGE_BYTES;
     static constexpr int SMEM_TOTAL = SMEM + BM * 4;             // + the row scales of a folded RMSNorm (GemmRowScale)
-    static constexpr int SC_BYTES = BM * 8;                      // LO4: 8 E8M0 block scales per A row and fp4 k-tile, one slot per ring stage
+    // LO4: 8 E8M0 block scales per A row and fp4 k-tile, one slot per ring stage — rounded up to a whole number of 4-byte pieces per THREAD: every
+    // wave issues the same number of VMEM operations per k-tile (the counted vmcnt waits of the ring rely on it); the surplus pieces read rows past
+    // the tile (or past M: 0 from the bounds-checked buffer) into the slot's padding
+    static constexpr int SC_BYTES = (2 * BM + NT - 1) / NT * NT * 4;
     static constexpr int SMEM_LO4 = SMEM_TOTAL + STAGES * SC_BYTES;
     static constexpr int D = STAGES - 1;                       // prefetch distance in k-tiles (>= 1)
     static_assert(STAGES >= 2, "ring needs at least two slots");
@@ -235,10 +238,11 @@ struct GemmLo4 {
         for (int ni = 0; ni < C::NI; ++ni) w_sc[ni] = (int)p.w4_scale[imin(n0 + wn * C::WTN + ni * 32 + fr, p.N - 1)];
     }
     LMI_DEV void issue(int kt, int slot) const {
+        // every wave issues all SP pieces, also those past the tile's 2 BM dwords (64 x 128: waves 2 - 3; 384 x 128: waves 4 - 7 of the second
+        // piece): a wave that skipped them had fewer VMEM operations in flight per fp4 k-tile than the counted wait of k_tile() assumes, which let
+        // it read a ring slot before its own last operand pieces had landed (round 5: found by the packed == separate bit-identity at M = 228)
 #pragma unroll
-        for (int j = 0; j < SP; ++j)
-            if (j * C::NT + wave_off / 4 < 2 * C::BM)             // wave-uniform (2 BM % 64 == 0)
-                glds4_buf(s_buf, s_src[j], (unsigned)kt * 8u, sc_base + slot * C::SC_BYTES + j * C::NT * 4 + wave_off);
+        for (int j = 0; j < SP; ++j) glds4_buf(s_buf, s_src[j], (unsigned)kt * 8u, sc_base + slot * C::SC_BYTES + j * C::NT * 4 + wave_off);
     }
     // scale dwords of row `row` of the tile for this lane's k-half: lo = blocks 0..3, hi = blocks 4..7 (bytes 0 / 2 after the shift)
     LMI_DEV void read(int slot, int row, int fh, int& lo, int& hi) const {

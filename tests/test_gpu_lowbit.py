@@ -250,6 +250,31 @@ def test_gemm_lo4_rows_and_their_images_do_not_depend_on_their_position(ops, kin
             assert torch.equal(t, b[lo:hi]), f"{kind}: rows {lo}:{hi} alone differ from the same rows inside M = 3000"
 
 
+def test_gemm_lo4_small_m_ring_at_the_llama_gate_up_shape(ops):
+    """The 64 x 128 ring (M < 512: BASELINE config C1, S = 228) and the M-complete 384 x 128 ring (256 < M <= 384: Idefics2's text side) through
+    16 fp4 k-tiles at N = 28672 with the folded RMSNorm, against the same rows inside M = 3225 on the staggered 256 x 256 schedule, twice each.
+    Round 5 regression: the waves of those two geometries that have no scale piece to fetch issued one VMEM operation fewer per fp4 k-tile than
+    the ring's counted vmcnt wait assumes and could read a slot before their own last operand pieces had landed (a few rows off by an ulp, image
+    bytes wrong, different from run to run)."""
+    dtype = torch.float16
+    M, F, K = 3225, 14336, 4096
+    x = rnd((M, K), torch.float32, 50, 1.5)
+    w = interleave_gate_up(rnd((F, K), dtype, 51, 0.02), rnd((F, K), dtype, 52, 0.02))
+    w4, wp = ops.quantize_w4(w), as_packed(w)
+    sq = (torch.rand(M, K // 64, generator=torch.Generator().manual_seed(53)) * 64 + 32).to(DEV)
+
+    def run(lo, hi):
+        act = act_from(ops, x[lo:hi], dtype)
+        o4 = Lo4Act.empty(hi - lo, F, dtype, DEV)
+        ops.gemm_lo4(act, wp, w4, o4.hi, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq[lo:hi].contiguous(), norm_dim=K, norm_eps=1e-5, out4=o4)
+        return (o4.hi, o4.img, o4.sc)
+    base = run(0, M)
+    for lo, hi in ((2997, 3225), (0, 228), (100, 412), (566, 878), (0, 566)):
+        for rep in range(2):
+            for t, b in zip(run(lo, hi), base):
+                assert torch.equal(t, b[lo:hi]), f"rows {lo}:{hi} alone (M = {hi - lo}) differ from the same rows inside M = {M} (repetition {rep})"
+
+
 def test_rmsnorm_rope_lo4_at_the_llama_shape(ops):
     dtype = torch.float16
     S, nq, nkv, D, K = 7187, 32, 8, 128, 4096

@@ -489,11 +489,15 @@ def test_smoke_entry():
 
 
 @pytest.mark.gpu
-def test_prefill_batch_equals_per_sample_prefill(ops):
+@pytest.mark.parametrize("precision", ["fast", "lo4", "lo4+vit"])
+def test_prefill_batch_equals_per_sample_prefill(ops, precision):
     """BASELINE config C5 shape (a batch of multi-image samples) at the mid depth: one packed pass over three samples with
-    different image counts / sizes gives, per sample, exactly the logits of its own prefill call."""
+    different image counts / sizes gives, per sample, exactly the logits of its own prefill call — on the fast schedule and on the
+    low-bit-corrected one (the residual images are position-independent too)."""
     cfg = mid_config()
     eng = build_engine(cfg, ops, torch.float16)
+    eng.precision = precision.split("+")[0]
+    eng.lo4_vit = precision.endswith("+vit")
     shapes = [(1, 800, 500, 3), (2, 1344, 896, 5), (1, 336, 336, 7)]
     samples = []
     for n, w, h, seed in shapes:
