@@ -45,6 +45,20 @@ for r in range(reps):
         if not same:
             print(f"rep {r}: MISMATCH max|d| prefill {float((ref - res.logits_last).abs().max()):.3e}")
 print(f"{'fp8' if fp8 else ('f16 lo4' if lo4 else 'f16 fast')} schedule: {reps} repetitions, {bad} mismatches")
+# lo4 at the small shapes (BASELINE configs C1 / C2 and two in-between sizes): they run the 64 x 128 / 384 x 128 / 256 x 128 ring instantiations of the
+# correction phase instead of the staggered kernel of the C3 sample — where round 5's under-counted LDS-DMA wait lived
+if lo4:
+    for n, w, h in ((1, 336, 336), (1, 700, 500), (1, 1344, 896), (2, 1344, 896)):
+        t_s, pl_s = GpuTiler(ops, dev).tile_sample([synth_image_u8(70 + i, w, h) for i in range(n)])
+        ids_s = torch.from_numpy(synth_prompt_ids(pl_s.vit_inputs_per_image, cfg, seed=3)).reshape(1, -1)
+        first, bad_s = None, 0
+        for r in range(max(10, reps)):
+            lg = eng.prefill(ids_s, t_s).logits_last.clone()
+            if first is None:
+                first = lg
+            elif not torch.equal(first, lg):
+                bad_s += 1
+        print(f"f16 lo4 schedule, {n} x ({w}x{h}), S = {ids_s.shape[1] + t_s.shape[0] * (cfg.tokens_per_tile - 1)}: {max(10, reps)} repetitions, {bad_s} mismatches")
 # batched decode (pooled KV slots, skinny-M projections, one captured step per token for the batch): same tokens and same final logits
 # every time
 if not fp8 and not lo4:
