@@ -489,7 +489,7 @@ def test_smoke_entry():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fast", "lo4", "lo4+vit"])
+@pytest.mark.parametrize("precision", ["fast", "lo4", "lo4+vit", "split"])
 def test_prefill_batch_equals_per_sample_prefill(ops, precision):
     """BASELINE config C5 shape (a batch of multi-image samples) at the mid depth: one packed pass over three samples with
     different image counts / sizes gives, per sample, exactly the logits of its own prefill call — on the fast schedule and on the
