@@ -100,7 +100,10 @@ def test_idefics2_full_depth_c4_vs_oracle(ops):
     res = eng.prefill(ids, u8, keep_parts=True)
     got, feats = res.logits_last.float().cpu(), res.parts["image_features"].float().cpu()
     eng.precision = "lo4"                                  # the precision mode of Leopard-Idefics2 (tower + Mistral; connector fast)
-    got4 = eng.prefill(ids, u8).logits_last.float().cpu()
+    first4 = eng.prefill(ids, u8).logits_last.clone()
+    got4 = first4.float().cpu()
+    for rep in range(6):                                   # the text side (S = 312) runs the M-complete 384 x 128 ring of the correction phase: bit-reproducible
+        assert torch.equal(eng.prefill(ids, u8).logits_last, first4), f"lo4 prefill repetition {rep} differs"
     del eng, W
     torch.cuda.empty_cache()
     Wt = {name: src.get(name).float().cpu() for name in src.specs}
