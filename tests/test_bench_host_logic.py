@@ -57,3 +57,48 @@ def test_fp8_detail_names_the_attention_arithmetic():
     on, off = types.SimpleNamespace(fp8_attention=1), types.SimpleNamespace(fp8_attention=0)
     assert "f8f6f4" in bench.fp8_detail(on) and "f16 SigLIP attention" in bench.fp8_detail(on)
     assert bench.fp8_detail(off) == bench.FP8_DETAIL and "f16 attention" in bench.FP8_DETAIL
+
+
+class _FakeD:
+    @staticmethod
+    def max_over_ranks(v, dev):
+        return v
+
+
+def _tp_args(**kw):
+    d = dict(steps=2, warmup=1, dtype="f16", images=6, width=1344, height=896, precision="lo4", no_fuse=False, opt=[], tp_timeout=5.0)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+@pytest.mark.parametrize("case", ["ok", "crash", "hang", "silent"])
+def test_tp_child_failures_cost_the_tp_object_not_the_line(monkeypatch, tmp_path, case):
+    """bench.run_tp_child: the N > 1 tensor-parallel measurement is a child process per rank with its own rendezvous port; whatever the child does
+    (result, non-zero exit, hang, no output) the parent gets a dict back — the headline line is printed either way."""
+    import subprocess
+    import sys
+    body = {"ok": "import json, os; assert os.environ['MASTER_PORT'].isdigit() and 'TORCHELASTIC_RUN_ID' not in os.environ; print(json.dumps({'tp': {'value': 1.5, 'n_gpus': 2}}))",
+            "crash": "import sys; sys.stderr.write('RCCL abort'); sys.exit(134)",
+            "hang": "import time; time.sleep(60)",
+            "silent": "pass"}[case]
+    script = tmp_path / "child.py"
+    script.write_text(body)
+    real_popen = subprocess.Popen
+    seen = {}
+
+    def fake_popen(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw["env"]
+        return real_popen([sys.executable, str(script)], **kw)
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "x")
+    res = bench.run_tp_child(_tp_args(tp_timeout=3.0 if case == "hang" else 30.0), 0, 2, _FakeD, None)
+    assert "--parallelism" in seen["cmd"] and seen["cmd"][seen["cmd"].index("--parallelism") + 1] == "tp" and "--gpus" in seen["cmd"]
+    assert seen["env"]["MASTER_PORT"].isdigit() and not any(k.startswith("TORCHELASTIC_") for k in seen["env"])
+    if case == "ok":
+        assert res == {"value": 1.5, "n_gpus": 2}
+    else:
+        assert "error" in res
+        if case == "crash":
+            assert "134" in res["error"] and "RCCL abort" in res["stderr_tail"]
+        if case == "hang":
+            assert "did not finish" in res["error"]
