@@ -56,8 +56,8 @@ class Lo4Act:
     def empty(M: int, K: int, dtype, device, k4: Optional[int] = None) -> "Lo4Act":
         # a padded k order, or K not a multiple of 256: the attention kernel and the GEMM epilogues write their own blocks only — the padding
         # must read as zero codes / zero scales (the norm and split kernels write theirs)
-        alloc = torch.zeros if (k4 or lo4_k4(K) != K) else torch.empty
         k4 = k4 or lo4_k4(K)
+        alloc = torch.zeros if k4 != K else torch.empty
         return Lo4Act(torch.empty(M, K, dtype=dtype, device=device), alloc(M, k4 // 2, dtype=torch.uint8, device=device),
                       alloc(M, k4 // 32, dtype=torch.uint8, device=device))
 
