@@ -8,6 +8,7 @@
 // and checks that the barrier version observed every hand-over (a checksum), so the fences measured are the ones a real kernel needs.
 // Build: hipcc --offload-arch=gfx950 -O2 -o grid_barrier grid_barrier.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -53,6 +54,26 @@ __global__ void __launch_bounds__(256) persistent(float* buf, unsigned* counter,
         }
         __syncthreads();
         __atomic_thread_fence(__ATOMIC_ACQUIRE);                                   // (every thread reads other workgroups' data)
+        carry = __hip_atomic_load(&buf[((size_t)(r & 1) * G + (b + 37) % G) * 256 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    out[(size_t)b * 256 + t] = carry + acc * 0.f;
+}
+
+// the runtime's own grid barrier (cooperative launch, cooperative_groups::this_grid().sync()) with the same payload
+template <int STREAM>
+__global__ void __launch_bounds__(256) persistent_cg(float* buf, const float* stream, size_t stream_elems, float* out, int R) {
+    namespace cg = cooperative_groups;
+    cg::grid_group grid = cg::this_grid();
+    const int G = gridDim.x, b = blockIdx.x, t = threadIdx.x;
+    float carry = 0.f, acc = 0.f;
+    for (int r = 0; r < R; ++r) {
+        buf[((size_t)(r & 1) * G + b) * 256 + t] = carry + (float)(b + r);
+        if (STREAM) {
+            const size_t base = ((size_t)r * G + b) * 256 * STREAM % (stream_elems - 256 * STREAM);
+#pragma unroll
+            for (int i = 0; i < STREAM; ++i) acc += __builtin_nontemporal_load(stream + base + i * 256 + t);
+        }
+        grid.sync();
         carry = __hip_atomic_load(&buf[((size_t)(r & 1) * G + (b + 37) % G) * 256 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     out[(size_t)b * 256 + t] = carry + acc * 0.f;
@@ -115,6 +136,23 @@ static void run(int G, int R, float* stream, size_t stream_elems) {
         for (int b = 0; b < G; b += 17)
             if ((double)h[(size_t)b * 256 + 5] != (double)(float)expected(G, b, R)) ++bad;
     }
+    float ms_cg = 1e30f;
+    {
+        int Rv = R;
+        void* kargs[] = {&buf, &stream, &stream_elems, &out, &Rv};
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipEventRecord(e0, s));
+            CK(hipLaunchCooperativeKernel((const void*)persistent_cg<STREAM>, dim3(G), dim3(256), kargs, 0, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < ms_cg) ms_cg = ms;
+        }
+        CK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < G; b += 17)
+            if ((double)h[(size_t)b * 256 + 5] != (double)(float)expected(G, b, R)) ++bad;
+    }
     // the same rounds as a graph of dependent launches
     hipGraph_t graph;
     hipGraphExec_t exec;
@@ -131,8 +169,8 @@ static void run(int G, int R, float* stream, size_t stream_elems) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep && ms < ms_g) ms_g = ms;
     }
-    printf("G = %4d workgroups, %3d rounds, %5.1f KiB streamed per workgroup and round:  grid barrier %6.2f (acquire polls) %6.2f (relaxed polls) %6.2f (two-level) us / round   graph of launches %6.2f us / round   hand-overs %s\n",
-           G, R, STREAM * 1.0, ms_v[0] * 1e3 / R, ms_v[1] * 1e3 / R, ms_v[2] * 1e3 / R, ms_g * 1e3 / R, bad ? "WRONG" : "verified");
+    printf("G = %4d workgroups, %3d rounds, %5.1f KiB streamed per workgroup and round:  grid barrier %6.2f (acquire polls) %6.2f (relaxed polls) %6.2f (two-level) %6.2f (cooperative-groups grid.sync) us / round   graph of launches %6.2f us / round   hand-overs %s\n",
+           G, R, STREAM * 1.0, ms_v[0] * 1e3 / R, ms_v[1] * 1e3 / R, ms_v[2] * 1e3 / R, ms_cg * 1e3 / R, ms_g * 1e3 / R, bad ? "WRONG" : "verified");
     CK(hipGraphExecDestroy(exec));
     CK(hipGraphDestroy(graph));
     CK(hipFree(buf));
