@@ -251,8 +251,8 @@ LMI_DEV float sub_rn(float a, float b) { float r = a - b; asm volatile("" : "+v"
 
 inline int lane_id() { return threadIdx.x & 63; }
 inline int wave_id() { return (int)(threadIdx.x >> 6); }
-template <int N> inline void wait_vmcnt_barrier() { __syncthreads(); }
-template <int N> inline void wait_vmcnt() {}
+template <int N> inline void wait_vmcnt_barrier() { hipemu::dma_wait(N); hipemu::barrier(); }     // the counted wait is modelled: hipemu.h
+template <int N> inline void wait_vmcnt() { hipemu::dma_wait(N); }
 inline float emu_fp8_decode(uint8_t v) {
     const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
     float f;
@@ -322,7 +322,7 @@ inline f32x16 mfma32_fp4(u32x4 a, u32x4 b, f32x16 c, int scale_a, int scale_b) {
     hipemu::wave_sync();
     return c;
 }
-inline void raw_barrier() { __syncthreads(); }
+inline void raw_barrier() { hipemu::barrier(); }                                                 // s_barrier alone retires no LDS-DMA piece
 inline void lds_write_drain() {}
 inline void wave_lds_fence() { hipemu::wave_sync(); }
 
@@ -372,15 +372,13 @@ template <int AUX = 0>
 inline void glds16_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
     char* dst = (char*)lds_wave_base + lane_id() * 16;
     const unsigned long off = (unsigned long)voffset + soffset;
-    if (off + 16 <= b.num_records) __builtin_memcpy(dst, b.base + off, 16);
-    else __builtin_memset(dst, 0, 16);
+    hipemu::dma_issue(dst, off + 16 <= b.num_records ? b.base + off : nullptr, 16);
 }
 
 inline void glds4_buf(const BufRsrc& b, unsigned voffset, unsigned soffset, void* lds_wave_base) {
     char* dst = (char*)lds_wave_base + lane_id() * 4;
     const unsigned long off = (unsigned long)voffset + soffset;
-    if (off + 4 <= b.num_records) __builtin_memcpy(dst, b.base + off, 4);
-    else __builtin_memset(dst, 0, 4);
+    hipemu::dma_issue(dst, off + 4 <= b.num_records ? b.base + off : nullptr, 4);
 }
 
 inline u32x2 ds_read_tr16_b64(const void* lds_ptr) {

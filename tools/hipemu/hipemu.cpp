@@ -3,7 +3,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <ucontext.h>
+#include <deque>
 #include <vector>
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -41,6 +43,7 @@ hipemu_switch:
 #endif
 
 namespace hipemu {
+void dma_wait(int max_outstanding);
 namespace {
 struct Fiber {
     ucontext_t ctx;
@@ -62,6 +65,13 @@ std::vector<int> wave_count;
 std::vector<unsigned> wave_gen;
 std::vector<char> wave_scratch;
 std::vector<char> smem;
+struct PendingDma {
+    char* dst;
+    unsigned char data[16];
+    int n;
+};
+std::vector<std::deque<PendingDma>> dma_q;          // per thread, in issue order
+const bool dma_sync = getenv("HIPEMU_SYNC_DMA") != nullptr;
 int n_threads = 0;
 unsigned long ticks = 0;     // bumped on every barrier arrival / thread exit: the scheduler's progress signal
 
@@ -75,6 +85,7 @@ void yield() {
 }
 void trampoline() {
     (*body_fn)();
+    dma_wait(0);                               // the end of the program retires everything
     fibers[cur].done = true;
 #if HIPEMU_FAST_SWITCH
     hipemu_switch(&fibers[cur].sp, main_sp);
@@ -95,6 +106,26 @@ void prepare(Fiber& f) {
 }
 #endif
 }  // namespace
+
+void dma_issue(void* lds_dst, const void* src, int bytes) {
+    if (dma_sync) {
+        if (src) memcpy(lds_dst, src, bytes); else memset(lds_dst, 0, bytes);
+        return;
+    }
+    PendingDma p;
+    p.dst = (char*)lds_dst;
+    p.n = bytes;
+    if (src) memcpy(p.data, src, bytes); else memset(p.data, 0, bytes);
+    memset(lds_dst, 0xFF, bytes);
+    dma_q[cur].push_back(p);
+}
+void dma_wait(int max_outstanding) {
+    auto& q = dma_q[cur];
+    while ((int)q.size() > max_outstanding) {
+        memcpy(q.front().dst, q.front().data, q.front().n);
+        q.pop_front();
+    }
+}
 
 char* dyn_smem() { return smem.data(); }
 void* wave_buf() { return wave_scratch.data() + (size_t)(cur / 64) * 64 * 256; }
@@ -123,6 +154,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
     wave_count.assign((n_threads + 63) / 64, 0);
     wave_gen.assign((n_threads + 63) / 64, 0);
     wave_scratch.assign((size_t)((n_threads + 63) / 64) * 64 * 256, 0);
+    dma_q.assign(n_threads, {});
     if ((int)fibers.size() < n_threads) {
         size_t old = fibers.size();
         fibers.resize(n_threads);
@@ -134,6 +166,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
                 blockIdx = dim3(bx, by, bz);
                 bar_count = 0;
                 for (auto& c : wave_count) c = 0;
+                for (auto& q : dma_q) q.clear();
                 for (int t = 0; t < n_threads; ++t) {
                     Fiber& f = fibers[t];
                     f.done = false;
@@ -179,8 +212,8 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
 }
 }  // namespace hipemu
 
-void __syncthreads() {
-    using namespace hipemu;
+namespace hipemu {
+void barrier() {
     const unsigned gen = bar_gen;
     ++ticks;
     if (++bar_count == n_threads) {
@@ -191,4 +224,11 @@ void __syncthreads() {
         while (bar_gen == gen) yield();
         fibers[cur].waiting = false;
     }
+}
+}  // namespace hipemu
+
+// hipcc's __syncthreads() is fence + s_barrier: s_waitcnt vmcnt(0) lgkmcnt(0) first — outstanding LDS-DMA pieces of the thread are retired
+void __syncthreads() {
+    hipemu::dma_wait(0);
+    hipemu::barrier();
 }

@@ -44,7 +44,15 @@ void __syncthreads();
 
 namespace hipemu {
 void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<void()>& body);
+void barrier();            // workgroup rendezvous and nothing else (s_barrier)
 void wave_sync();          // rendezvous of the 64 lanes of the calling thread's wave
+// LDS-DMA (buffer_load ... lds) with its asynchrony modelled at BOTH worst cases: the destination is poisoned (0xFF: NaN in every operand
+// type) the moment the piece is issued — the hardware may overwrite it at any time from then on — and receives its bytes only when a
+// vmcnt wait of the issuing thread retires the piece (in order, oldest first) — the hardware may deliver it that late.  A kernel that
+// reads a ring slot before its counted wait covers the slot's pieces, or still reads the previous tenant after issuing into the slot, gets
+// NaNs on the host exactly where it has a race on the device.  HIPEMU_SYNC_DMA=1 restores immediate copies (debugging).
+void dma_issue(void* lds_dst, const void* src, int bytes);     // src == nullptr: zeros (out-of-range buffer read)
+void dma_wait(int max_outstanding);                            // s_waitcnt vmcnt(N) of the calling thread
 void* wave_buf();          // per-wave scratch (64 lanes x 256 B)
 char* dyn_smem();
 }  // namespace hipemu
