@@ -57,3 +57,35 @@ def test_lds_dma_pieces_land_at_the_counted_wait(tmp_path):
     env = {k: v for k, v in os.environ.items() if k != "HIPEMU_SYNC_DMA"}
     p = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
+
+
+RACY = r'''
+#include "hipemu.h"
+#include <stdio.h>
+static int flag, seen;
+int main() {
+    flag = 0; seen = -1;
+    hipemu::launch(dim3(1), dim3(128), 0, [&]() {          // wave 0 hands a value to wave 1 through memory WITHOUT a barrier
+        if (threadIdx.x == 0) flag = 1;
+        if (threadIdx.x == 64) seen = flag;
+        __syncthreads();
+    });
+    printf("%d\n", seen);
+    return 0;
+}
+'''
+
+
+@pytest.mark.skipif(not os.path.exists("/usr/bin/g++"), reason="needs g++")
+def test_wave_order_fuzzing_exposes_a_hand_over_without_a_barrier(tmp_path):
+    """HIPEMU_ORDER=reverse / random runs the waves of a workgroup in another (legal) order between rendezvous points: a kernel whose result
+    changes with it has an inter-wave race.  The emulator-based suite is order-independent (profiles/r05_emulator_race_screens.txt)."""
+    main = tmp_path / "racy.cpp"
+    main.write_text(RACY)
+    exe = tmp_path / "racy"
+    hip = os.path.join(REPO, "tools", "hipemu")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", hip, str(main), os.path.join(hip, "hipemu.cpp"), "-o", str(exe)], check=True)
+    base = {k: v for k, v in os.environ.items() if k != "HIPEMU_ORDER"}
+    out = {o: subprocess.run([str(exe)], capture_output=True, text=True, env={**base, **({"HIPEMU_ORDER": o} if o else {})}).stdout.strip()
+           for o in ("", "reverse")}
+    assert out[""] == "1" and out["reverse"] == "0", out

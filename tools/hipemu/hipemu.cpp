@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
+#include <algorithm>
 #include <deque>
 #include <vector>
 
@@ -184,9 +185,28 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
                 }
                 int alive = n_threads;
                 long spins = 0;
+                // HIPEMU_ORDER: the order in which the WAVES of a workgroup get the processor between rendezvous points.  Between two barriers the
+                // hardware may run waves in any order, so a correct kernel gives the same bits under every choice; "reverse" and "random[:seed]"
+                // expose an LDS hand-over between waves that has no barrier (with the default ascending order the producer wave of such a
+                // hand-over often happens to run first).  Lanes of a wave stay in ascending order (wave-collective operations rendezvous anyway).
+                static const char* order_env = getenv("HIPEMU_ORDER");
+                const int n_waves = (n_threads + 63) / 64;
+                std::vector<int> wave_order(n_waves);
+                for (int w = 0; w < n_waves; ++w) wave_order[w] = w;
+                const bool order_random = order_env && !strncmp(order_env, "random", 6);
+                if (order_env && !strcmp(order_env, "reverse"))
+                    for (int w = 0; w < n_waves; ++w) wave_order[w] = n_waves - 1 - w;
+                static unsigned long rng = order_random && strchr(order_env, ':') ? strtoul(strchr(order_env, ':') + 1, nullptr, 10) * 2654435761ul + 1 : 88172645463325252ul;
                 while (alive > 0) {
                     const unsigned long before = ticks;
-                    for (int t = 0; t < n_threads; ++t) {
+                    if (order_random)
+                        for (int w = n_waves - 1; w > 0; --w) {
+                            rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+                            std::swap(wave_order[w], wave_order[rng % (unsigned long)(w + 1)]);
+                        }
+                    for (int idx = 0; idx < n_waves * 64; ++idx) {
+                        const int t = wave_order[idx / 64] * 64 + idx % 64;
+                        if (t >= n_threads) continue;
                         Fiber& f = fibers[t];
                         if (f.done) continue;
                         cur = t;
