@@ -84,6 +84,7 @@ class GemmTimer:
         self.records = []
         self.bytes = 0              # algorithmic operand + output bytes of the timed launches
         self.lo4_flops = 0.0        # algorithmic FLOPs of the launches that also ran the fp4 correction phase
+        self.sel_frac = {}
 
     def wrap(self, ops):
         inner = ops.gemm
@@ -127,9 +128,17 @@ class GemmTimer:
                 r = fn(a, w, w4, out, *args, **kw)
                 e1.record(torch.cuda.current_stream())
                 timer.records.append((2.0 * M * w.shape[0] * w.shape[1], e0, e1, (M, w.shape[0], w.shape[1])))
-                timer.lo4_flops += 2.0 * M * w.shape[0] * w.shape[1]
+                # row selection (engine.lo4_rows): only the 256-row tiles that hold a selected row run the fp4 k-tiles and read the images
+                cf = 1.0
+                if a.unit_sel is not None:
+                    cf = timer.sel_frac.get(a.unit_sel.data_ptr())
+                    if cf is None:                                                       # (one device read per selection table, not per launch)
+                        u = a.unit_sel.cpu().numpy().astype(bool)
+                        u = np.pad(u, (0, (-len(u)) % 4)).reshape(-1, 4).any(axis=1)      # 256-row tiles = 4 units
+                        cf = timer.sel_frac[a.unit_sel.data_ptr()] = min(1.0, float(u.sum()) * 256 / M)
+                timer.lo4_flops += 2.0 * M * w.shape[0] * w.shape[1] * cf
                 timer.bytes += ((M + w.shape[0]) * w.shape[1] * w.element_size() + out.numel() * out.element_size()
-                                + a.img.numel() + a.sc.numel() + w4.img.numel())
+                                + int((a.img.numel() + a.sc.numel()) * cf) + w4.img.numel())
                 return r
             return call
         ops.gemm_lo4, ops.rmsnorm_rope_lo4 = timed_lo4(ops.gemm_lo4), timed_lo4(ops.rmsnorm_rope_lo4)
@@ -935,7 +944,12 @@ def main():
                                            "on those launches that `frac` books as overhead")
         out["roofline"] = rl
     if args.precision == "lo4":
-        lo_fl = fl["llm_linear"] + ((fl["vit"] - n_tiles * vit_attention_flops(cfg)) if args.lo4_vit else 0)
+        tail = eng.lo4_tail_rows(S)                                  # rows that carry the correction (engine.lo4_rows); the fp4 k-tiles run on their 256-row tiles
+        corrected_rows = min(S, (((S - 1) // 256) - ((S - tail) // 256) + 1) * 256)
+        out["lo4_rows"] = {"policy": eng.lo4_rows, "rows_with_residual_images": tail, "rows_in_corrected_tiles": corrected_rows, "of": S,
+                           "note": "the correction covers the trailing rows of each sequence — the rows whose logits are read; the other rows' "
+                                   "hand-over roundings reach them only through the softmax average (DESIGN.md 2.1, profiles/r06_lo4_policy_study_*.txt)"}
+        lo_fl = fl["llm_linear"] * corrected_rows / S + ((fl["vit"] - n_tiles * vit_attention_flops(cfg)) if args.lo4_vit else 0)
         out["matrix_pipe_frac"] = round((args.inflight * (fl["total"] / MFMA_PEAK_TFLOPS + lo_fl / MFMA_PEAK_FP4_TFLOPS) / 1e12) / (elapsed / args.steps), 4)
         out["matrix_pipe_frac_note"] = ("algorithmic FLOPs at the 2.5 PF 16-bit peak + the correction phase's FLOPs (every corrected layer linear once more, "
                                         f"{lo_fl / 1e12:.1f} TFLOP) at the 10 PF fp4 peak, over the step time; prefill_mfma_frac counts the algorithmic FLOPs only")

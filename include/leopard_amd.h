@@ -264,12 +264,19 @@ int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* 
  * the two images share a padded k order: lmi_attn_varlen_fwd_lo4), zero codes and zero scale bytes in the padding; lda4 / ldw4 / ld_out4 in BYTES; a4_scale [M, lds4] with lds4 >= K4 / 32; w4_scale [N].
  * lmi_lo4: inputs (a4, a4_scale, w4, w4_scale: all four) consumed by this launch, outputs (out4, out4_scale: both or neither) = the image of
  * the residual of this launch's own 16-bit result — `out` for LMI_EPI_STORE (+ activation) and LMI_EPI_SWIGLU, `norm_out` for the
- * RESIDUAL producer mode — for the next GEMM. */
+ * RESIDUAL producer mode — for the next GEMM.
+ * Row selection (round 6): the last-position logits of a sequence are dominated by the hand-over roundings of THAT row's own path through the
+ * layers — the other rows' roundings reach it only through the softmax average over ~S keys — so the correction need only cover the rows whose
+ * logits are read.  row_sel [M] bytes: != 0 <=> row m's operands carry a residual image (producers write the images of selected rows only: the
+ * image buffers must be zero-filled once before the pass, an unselected row then reads as zero codes and its results are bit for bit the fast
+ * schedule's wherever it sits in a tile); unit_sel [ceil(M / 64)] bytes: OR of row_sel over rows [64 u, 64 u + 64) — a tile none of whose units
+ * is set skips the fp4 k-tiles.  Both null (or both given): null = every row. */
 typedef struct lmi_lo4 {
     const void* a4; const void* a4_scale; const void* w4; const void* w4_scale;
     int lda4, ldw4, lds4, k4;
     void* out4; void* out4_scale;
     int ld_out4, ld_out4s;
+    const void* row_sel; const void* unit_sel;
 } lmi_lo4;
 /* lmi_gemm_ex / lmi_rmsnorm_rope with the correction phase (plain A, row-major or packed W for the 16-bit pass, K >= 128). */
 int lmi_gemm_lo4(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,
@@ -285,12 +292,19 @@ int lmi_rmsnorm_rope_lo4(const void* A, const void* Wqkv, void* qkv, const float
 int lmi_attn_varlen_fwd_lo4(const void* q, const void* k, const void* v, void* out, void* out4, void* out4_scale, int ld_out4, int ld_out4s,
                             const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                             int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int dtype, void* stream);
+/* the same with a row selection (lmi_lo4.row_sel: [total_q] bytes, null = every row): unselected rows get their 16-bit row only */
+int lmi_attn_varlen_fwd_lo4_rows(const void* q, const void* k, const void* v, void* out, void* out4, void* out4_scale, int ld_out4, int ld_out4s,
+                                 const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                                 int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, const void* row_sel, int dtype, void* stream);
 /* fp32 activation [M, K] (K % 32 == 0) -> hi = T(x) [M, ldh] + the fp4 image of x - T(x) [M, ld4 bytes] + its block scales [M, lds]
  * (attention outputs: lmi_attn_varlen_fwd_f32 hands over fp32). */
 int lmi_split_lo4(const float* x, void* hi, void* lo4, void* scales, int M, int K, int K4, int ldx, int ldh, int ld4, int lds, int dtype, void* stream);
 /* LayerNorm (b != null) / RMSNorm (b == null) writing T(y) and the fp4 image of y - T(y) in one launch (D % 32 == 0, D <= 4096). */
 int lmi_norm_lo4(const float* x, const float* w, const float* b, void* out, void* out4, void* scales, int M, int D, int K4, int ldx, int ldo,
                  int ld4, int lds, float eps, int dtype, void* stream);
+/* the same with a row selection (lmi_lo4.row_sel: [M] bytes, null = every row): unselected rows get T(y) only */
+int lmi_norm_lo4_rows(const float* x, const float* w, const float* b, void* out, void* out4, void* scales, int M, int D, int K4, int ldx, int ldo,
+                      int ld4, int lds, float eps, const void* row_sel, int dtype, void* stream);
 /* lmi_add_rmsnorm (tensor parallel: residual add of the reduce-scattered partial products + RMSNorm on the rank's rows) writing the Lo4 pair. */
 int lmi_add_rmsnorm_lo4(float* x, const void* delta, int delta_dtype, const float* w, void* out, void* out4, void* scales, int M, int D, int K4,
                         int ldx, int ldd, int ldo, int ld4, int lds, float eps, int dtype, void* stream);

@@ -24,7 +24,7 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 class Lo4Desc(C.Structure):
     """``lmi_lo4`` of include/leopard_amd.h: the fp4 images a GEMM with the low-bit correction phase consumes / produces."""
     _fields_ = [("a4", _P), ("a4_scale", _P), ("w4", _P), ("w4_scale", _P), ("lda4", _I), ("ldw4", _I), ("lds4", _I), ("k4", _I),
-                ("out4", _P), ("out4_scale", _P), ("ld_out4", _I), ("ld_out4s", _I)]
+                ("out4", _P), ("out4_scale", _P), ("ld_out4", _I), ("ld_out4s", _I), ("row_sel", _P), ("unit_sel", _P)]
 
 
 # name -> argtypes  (restype is int unless noted); mirrors include/leopard_amd.h one to one
@@ -65,6 +65,8 @@ SIGNATURES = {
     "lmi_gemm_lo4": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _P, _P, _I, C.POINTER(Lo4Desc), _I, _P],
     "lmi_rmsnorm_rope_lo4": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(Lo4Desc), _I, _P],
     "lmi_attn_varlen_fwd_lo4": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
+    "lmi_attn_varlen_fwd_lo4_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P],
+    "lmi_norm_lo4_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "lmi_split_lo4": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_norm_lo4": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "lmi_add_rmsnorm_lo4": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],

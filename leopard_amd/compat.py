@@ -89,7 +89,9 @@ class LeopardForConditionalGeneration:
                                     tp_size=self.tp_size)
             self._engine = LeopardEngine(self.config, W, ops=ops, device=device)
             if self.precision == "lo4" and not self._engine.lo4_supported():
-                self.precision = "split"                 # a model shape the lo4 schedule does not cover: the 2 K mode meets the same figure
+                # a model shape the lo4 schedule does not cover: the 2 K mode meets the same figure on one rank; tensor-parallel engines only
+                # run fast / lo4 (resolve_precision's rule for an explicit "split" request)
+                self.precision = "split" if self.tp_size == 1 else "fast"
             self._engine.precision = self.precision
             self.device = device
         return self

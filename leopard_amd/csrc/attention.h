@@ -57,6 +57,7 @@ struct AttnArgs {
     uint8_t* out4;            // [total_q, ld_out4 bytes]: head h, block db at byte (h * NDB + db) * 16
     uint8_t* out4_scale;      // [total_q, ld_out4s]: byte h * NDB + db
     int ld_out4, ld_out4s;
+    const uint8_t* row_sel;   // [total_q] or null: the rows whose image is wanted (gemm.h GemmArgs::row_sel); the others only get their 16-bit row
     int gqa_pack;             // LDS-DMA kernel, decode: a workgroup's 4 waves take the 4 query heads of ONE kv head (32 query rows per block)
     int check_k_extent;       // 1 = the launcher could not bound a sequence's K / V extent (< 4 GiB): the kernel checks (and traps)
 };
@@ -617,12 +618,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
             }
         return;
     }
-    if (p.out4) {
-        // (workgroup-uniform) residual image of the rows about to be rounded.  Block db of this head = the 16 values of this lane + the 16 of
+    const long row4 = q_beg + imin(my_q, len_q - 1);
+    const bool sel4 = p.out4 && (!p.row_sel || p.row_sel[row4]);
+    if (p.out4 && wave_any(sel4)) {
+        // (wave-uniform) residual image of the rows about to be rounded.  Block db of this head = the 16 values of this lane + the 16 of
         // its half-wave partner: block maximum by one lane exchange; this lane's codes are two dwords (quads qd = 0, 1 and 2, 3: 16 bits per
         // quad); after trading one dword the low lane owns bytes 0..7 of the block (d 0..15) and the high lane bytes 8..15 — the same trade
         // as the 16-bit rows below.
-        const long row4 = q_beg + imin(my_q, len_q - 1);
         uint8_t* o4 = p.out4 + row4 * p.ld_out4 + head * (NDB * 16);
         uint8_t* s4 = p.out4_scale + row4 * p.ld_out4s + head * NDB;
 #pragma unroll
@@ -645,7 +647,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
             const unsigned own = fh ? b : a, other = fh ? a : b;
             const unsigned w0 = fh ? ((other & 0xffffu) | (own << 16)) : ((own & 0xffffu) | (other << 16));
             const unsigned w1 = fh ? ((other >> 16) | (own & 0xffff0000u)) : ((own >> 16) | (other & 0xffff0000u));
-            if (my_q < len_q) {
+            if (my_q < len_q && sel4) {
                 *(u32x2*)(o4 + db * 16 + fh * 8) = u32x2{w0, w1};
                 if (fh == 0) s4[db] = (uint8_t)sb;
             }

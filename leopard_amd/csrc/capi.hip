@@ -811,6 +811,7 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     a.A4 = nullptr; a.W4 = nullptr; a.a4_scale = nullptr; a.w4_scale = nullptr; a.lda4 = a.ldw4 = a.lds4 = a.K4 = 0;
     a.a4_bytes = a.w4_bytes = a.a4s_bytes = 0;
     a.out4 = nullptr; a.out4_scale = nullptr; a.ld_out4 = a.ld_out4s = 0;
+    a.row_sel = nullptr; a.unit_sel = nullptr;
     if (lo) {                                                       // low-bit correction phase (lmi_gemm_lo4 / lmi_rmsnorm_rope_lo4)
         const int k4 = lo->k4;          // K rounded up to 256, or wider: the images may carry their own (padded) k order — see lmi_attn_varlen_fwd_lo4
         if (!lo->a4 || !lo->a4_scale || !lo->w4 || !lo->w4_scale || k4 < K || (k4 & 255) || K < 128 || a_mode != LMI_A_PLAIN || (lo->lda4 & 15) ||
@@ -822,12 +823,22 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
             (lo->out4 && (((uintptr_t)lo->out4 & 3) || (lo->ld_out4 & 3) || lo->ld_out4s <= 0 ||
                           !(epilogue == LMI_EPI_SWIGLU || epilogue == LMI_EPI_STORE || (epilogue == LMI_EPI_RESIDUAL && x.norm_out)) || a.swiglu_f32)))
             return fail(LMI_EINVAL, "%s: lo4 output needs out4 and out4_scale, ld_out4 %% 4 == 0, and the STORE / SWIGLU epilogue or the RESIDUAL producer mode", who);
+        if (lo->out4) {                                             // rows of the output image must not overlap (advisor r05)
+            const int out_cols = epilogue == LMI_EPI_SWIGLU ? N / 2 : N;
+            if (lo->ld_out4 < out_cols / 2 || lo->ld_out4s < out_cols / 32)
+                return fail(LMI_EINVAL, "%s: lo4 output rows overlap: ld_out4 (%d) must be >= %d bytes and ld_out4s (%d) >= %d for %d output columns", who,
+                            lo->ld_out4, out_cols / 2, lo->ld_out4s, out_cols / 32, out_cols);
+        }
         const long a4b = (long)(M - 1) * lo->lda4 + k4 / 2, w4b = (long)(N - 1) * lo->ldw4 + k4 / 2, sb = (long)(M - 1) * lo->lds4 + k4 / 32;
         if (a4b >= (1L << 32) || w4b >= (1L << 32)) return fail(LMI_EINVAL, "%s: lo4 image extent >= 4 GiB", who);
         a.A4 = lo->a4; a.W4 = lo->w4; a.a4_scale = (const uint8_t*)lo->a4_scale; a.w4_scale = (const uint8_t*)lo->w4_scale;
         a.lda4 = lo->lda4; a.ldw4 = lo->ldw4; a.lds4 = lo->lds4; a.K4 = k4;
         a.a4_bytes = (unsigned)a4b; a.w4_bytes = (unsigned)w4b; a.a4s_bytes = (unsigned)sb;
         a.out4 = lo->out4; a.out4_scale = (uint8_t*)lo->out4_scale; a.ld_out4 = lo->ld_out4; a.ld_out4s = lo->ld_out4s;
+        if ((lo->row_sel != nullptr) != (lo->unit_sel != nullptr))
+            return fail(LMI_EINVAL, "%s: lo4 row selection needs row_sel [M] and unit_sel [ceil(M / 64)] together (or neither: every row)", who);
+        if (lo->row_sel && row_map) return fail(LMI_EINVAL, "%s: lo4 row selection does not combine with row_map", who);
+        a.row_sel = (const uint8_t*)lo->row_sel; a.unit_sel = (const uint8_t*)lo->unit_sel;
         LMI_DISPATCH_T(dtype, dispatch_gemm_lo4<f16_t>(a, epilogue, act, stream), dispatch_gemm_lo4<bf16_t>(a, epilogue, act, stream));
     }
     // (Measured and dropped, profiles/r03_ab_tail_split_and_prologue.txt: computing the last 256-column tile of SigLIP q|k|v / fc1 with a
@@ -861,7 +872,7 @@ int lmi_add_rmsnorm_lo4(float* x, const void* delta, int delta_dtype, const floa
     if (delta_dtype != LMI_F32 && delta_dtype != dtype) return fail(LMI_EINVAL, "lmi_add_rmsnorm_lo4: delta_dtype must be LMI_F32 or dtype");
     if (M == 0) return LMI_OK;
     NormLo4 lo;
-    lo.out4 = (uint8_t*)out4; lo.scales = (uint8_t*)scales; lo.ld4 = ld4; lo.lds = lds; lo.K4 = K4;
+    lo.out4 = (uint8_t*)out4; lo.scales = (uint8_t*)scales; lo.ld4 = ld4; lo.lds = lds; lo.K4 = K4; lo.row_sel = nullptr;
     const int grid = (M + 3) / 4;
 #define LMI_ADDNORM4(T_, DT_)                                                                                                                     \
     do {                                                                                                                                          \
@@ -960,17 +971,22 @@ int lmi_split_lo4(const float* x, void* hi, void* lo4, void* scales, int M, int 
     return check_launch("lmi_split_lo4");
 }
 
-int lmi_norm_lo4(const float* x, const float* w, const float* b, void* out, void* out4, void* scales, int M, int D, int K4, int ldx, int ldo,
-                 int ld4, int lds, float eps, int dtype, void* stream) {
+int lmi_norm_lo4_rows(const float* x, const float* w, const float* b, void* out, void* out4, void* scales, int M, int D, int K4, int ldx, int ldo,
+                      int ld4, int lds, float eps, const void* row_sel, int dtype, void* stream) {
     if (!x || !w || !out || !out4 || !scales || M < 0 || D <= 0 || (D & 31) || D > 4096 || K4 != (D + 255) / 256 * 256 || (ldx & 3) || (ldo & 7) ||
         (ld4 & 3) || ld4 < K4 / 2 || lds < K4 / 32 || !aligned16(x) || !aligned16(w) || !aligned16(out) || ((uintptr_t)out4 & 3) || (b && !aligned16(b)))
-        return fail(LMI_EINVAL, "lmi_norm_lo4: bad argument (M=%d D=%d K4=%d; D %% 32 == 0, D <= 4096, K4 = D rounded up to 256)", M, D, K4);
+        return fail(LMI_EINVAL, "lmi_norm_lo4[_rows]: bad argument (M=%d D=%d K4=%d; D %% 32 == 0, D <= 4096, K4 = D rounded up to 256)", M, D, K4);
     if (M == 0) return LMI_OK;
     NormLo4 lo;
-    lo.out4 = (uint8_t*)out4; lo.scales = (uint8_t*)scales; lo.ld4 = ld4; lo.lds = lds; lo.K4 = K4;
+    lo.out4 = (uint8_t*)out4; lo.scales = (uint8_t*)scales; lo.ld4 = ld4; lo.lds = lds; lo.K4 = K4; lo.row_sel = (const uint8_t*)row_sel;
     if (dtype == LMI_F16) return b ? norm_lo4_impl<f16_t, false>(x, w, b, out, lo, M, D, ldx, ldo, eps, stream) : norm_lo4_impl<f16_t, true>(x, w, b, out, lo, M, D, ldx, ldo, eps, stream);
     if (dtype == LMI_BF16) return b ? norm_lo4_impl<bf16_t, false>(x, w, b, out, lo, M, D, ldx, ldo, eps, stream) : norm_lo4_impl<bf16_t, true>(x, w, b, out, lo, M, D, ldx, ldo, eps, stream);
-    return fail(LMI_EINVAL, "lmi_norm_lo4: dtype must be LMI_F16 or LMI_BF16");
+    return fail(LMI_EINVAL, "lmi_norm_lo4[_rows]: dtype must be LMI_F16 or LMI_BF16");
+}
+
+int lmi_norm_lo4(const float* x, const float* w, const float* b, void* out, void* out4, void* scales, int M, int D, int K4, int ldx, int ldo,
+                 int ld4, int lds, float eps, int dtype, void* stream) {
+    return lmi_norm_lo4_rows(x, w, b, out, out4, scales, M, D, K4, ldx, ldo, ld4, lds, eps, nullptr, dtype, stream);
 }
 
 int lmi_quantize_w4(const void* W, void* w4, void* scales, int N, int K, int K4, int ldw, int ld4, int dtype, void* stream) {
@@ -1062,7 +1078,7 @@ int lmi_gemm_fp8(const void* A, const void* W, void* out, const float* bias, int
 static int attn_varlen_entry(const char* who, const void* q, const void* k, const void* v, void* out, float* out_f32, int ldo32, void* out_fp8, int ldo8, float out_fp8_scale,
                              const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                              int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int use_tr, int dtype, void* stream,
-                             void* out4 = nullptr, void* out4_scale = nullptr, int ld_out4 = 0, int ld_out4s = 0) {
+                             void* out4 = nullptr, void* out4_scale = nullptr, int ld_out4 = 0, int ld_out4s = 0, const uint8_t* row_sel = nullptr) {
     if (!q || !k || !v || (!out && !out_fp8 && !out_f32) || !cu_seqlens_q || !cu_seqlens_k) return fail(LMI_EINVAL, "%s: null pointer", who);
     if (out4) {
         const int ndb = (head_dim + 31) / 32;
@@ -1086,7 +1102,7 @@ static int attn_varlen_entry(const char* who, const void* q, const void* k, cons
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = nullptr;
     a.out_fp8 = out_fp8; a.ldo8 = ldo8; a.out_fp8_scale = out_fp8_scale; a.out_f32 = out_f32; a.ldo32 = ldo32;
-    a.out4 = (uint8_t*)out4; a.out4_scale = (uint8_t*)out4_scale; a.ld_out4 = ld_out4; a.ld_out4s = ld_out4s;
+    a.out4 = (uint8_t*)out4; a.out4_scale = (uint8_t*)out4_scale; a.ld_out4 = ld_out4; a.ld_out4s = ld_out4s; a.row_sel = row_sel;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window; a.n_qblocks = 0;
     a.n_splits = 1; a.split_tiles = 0; a.part_rows = 0; a.part_o = nullptr; a.part_ml = nullptr; a.gqa_pack = 0;
     a.check_k_extent = 1;
@@ -1173,12 +1189,20 @@ int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* 
                              n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, 0, scale, causal, window, 1, dtype, stream);
 }
 
+int lmi_attn_varlen_fwd_lo4_rows(const void* q, const void* k, const void* v, void* out, void* out4, void* out4_scale, int ld_out4, int ld_out4s,
+                                 const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
+                                 int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, const void* row_sel, int dtype, void* stream) {
+    if (!out || !out4 || !out4_scale) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd_lo4: null pointer");
+    return attn_varlen_entry("lmi_attn_varlen_fwd_lo4", q, k, v, out, nullptr, 0, nullptr, 0, 0.f, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads,
+                             n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, causal, window, 1, dtype, stream, out4, out4_scale, ld_out4, ld_out4s,
+                             (const uint8_t*)row_sel);
+}
+
 int lmi_attn_varlen_fwd_lo4(const void* q, const void* k, const void* v, void* out, void* out4, void* out4_scale, int ld_out4, int ld_out4s,
                             const int* cu_seqlens_q, const int* cu_seqlens_k, int n_seq, int max_seqlen_q, int n_heads, int n_kv_heads, int head_dim,
                             int ldq, int ldk, int ldv, int ldo, float scale, int causal, int window, int dtype, void* stream) {
-    if (!out || !out4 || !out4_scale) return fail(LMI_EINVAL, "lmi_attn_varlen_fwd_lo4: null pointer");
-    return attn_varlen_entry("lmi_attn_varlen_fwd_lo4", q, k, v, out, nullptr, 0, nullptr, 0, 0.f, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads,
-                             n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, causal, window, 1, dtype, stream, out4, out4_scale, ld_out4, ld_out4s);
+    return lmi_attn_varlen_fwd_lo4_rows(q, k, v, out, out4, out4_scale, ld_out4, ld_out4s, cu_seqlens_q, cu_seqlens_k, n_seq, max_seqlen_q, n_heads,
+                                        n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, causal, window, nullptr, dtype, stream);
 }
 
 int lmi_split_hi_lo(const float* x, void* out, int M, int K, int ldx, int ldo, int dtype, void* stream) {
@@ -1256,7 +1280,7 @@ static int attn_decode_entry(const char* who, const void* q, const void* k, cons
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.k_len = k_len;
     a.out_fp8 = nullptr; a.ldo8 = 0; a.out_fp8_scale = 0.f; a.out_f32 = nullptr; a.ldo32 = 0;
-    a.out4 = nullptr; a.out4_scale = nullptr; a.ld_out4 = a.ld_out4s = 0;
+    a.out4 = nullptr; a.out4_scale = nullptr; a.ld_out4 = a.ld_out4s = 0; a.row_sel = nullptr;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window;
     if (((long)max_seqlen_k * ldk + head_dim) * 2 >= (1L << 32) || ((long)max_seqlen_k * ldv + head_dim) * 2 >= (1L << 32))
         return fail(LMI_EINVAL, "%s: one sequence's K / V rows span >= 4 GiB (max_seqlen_k %d, ldk %d, ldv %d)", who, max_seqlen_k, ldk, ldv);

@@ -120,6 +120,7 @@ struct NormLo4 {
     uint8_t* out4;
     uint8_t* scales;
     int ld4, lds, K4;
+    const uint8_t* row_sel;      // [M] or null: rows whose image is wanted (gemm.h GemmArgs::row_sel); the others get T(y) only
 };
 template <typename T, bool RMS, int MAXV, bool LO4 = false>     // MAXV = max 8-element chunks per lane (D <= MAXV*512)
 __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* w, const float* b, T* out,
@@ -165,6 +166,7 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
         rstd = 1.0f / sqrtf(q / (float)D + eps);
     }
     T* orow = out + (long)row * ldo;
+    const bool want4 = LO4 && (!lo.row_sel || lo.row_sel[row]);      // (wave-uniform: one wave per row) this row hands over a residual image
     float lo_y[LO4 ? MAXV : 1][8];                                   // LO4: the normalised values, encoded wave-uniformly below
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -194,12 +196,14 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
             }
             if constexpr (!(LO4 && sizeof(T) == 2)) *(T8*)(orow + c * 8) = o;
             if constexpr (LO4 && sizeof(T) == 2) {
+                if (!want4) *(T8*)(orow + c * 8) = o;                 // the same T(y) lo4_encode8 returns below
 #pragma unroll
                 for (int e = 0; e < 8; ++e) lo_y[i][e] = yv[e];
             }
         }
     }
     if constexpr (LO4 && sizeof(T) == 2) {
+        if (!want4) return;
         // every lane of the wave takes part in the quad exchange (idle lanes on zeros: they also write the zero padding up to K4);
         // nvec % 4 == 0, so a block's four lanes are live or idle together
 #pragma unroll

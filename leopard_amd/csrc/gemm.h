@@ -97,7 +97,25 @@ struct GemmArgs {
     void* out4;
     uint8_t* out4_scale;
     int ld_out4, ld_out4s;       // bytes per row of out4 / of out4_scale
+    // ---- row selection of the correction phase (round 6; LeopardEngine.lo4_rows) ---------------------------------------------
+    // The logits of a row are dominated by the hand-over roundings of THAT row's own path through the layers; the other rows' roundings reach it
+    // only through the softmax average over ~S keys.  So only the rows whose logits are read (the last rows of every sequence) need the
+    // correction.  row_sel[m] != 0 <=> row m's operands carry a residual image: producers write the image of selected rows only (the buffers are
+    // zero-filled once per pass, so an unselected row's image is all zero codes: its correction term is exactly 0 and its bits are the fast
+    // schedule's wherever it sits in a tile), and a tile none of whose rows is selected skips the fp4 k-tiles altogether.  unit_sel[u] = OR of
+    // row_sel over rows [64 u, 64 u + 64) (what a tile tests: a handful of scalar loads).  Both null = every row selected (round 5's schedule).
+    const uint8_t* row_sel;
+    const uint8_t* unit_sel;
 };
+
+// does any row of the tile [m0, m0 + bm) carry a residual image?  (m0 % 64 == 0 for every geometry; workgroup-uniform scalar loads)
+LMI_DEV bool gemm_tile_selected(const GemmArgs& p, int m0, int bm) {
+    if (!p.unit_sel) return true;
+    const int u1 = ((m0 + bm < p.M ? m0 + bm : p.M) + 63) >> 6;
+    unsigned any = 0;
+    for (int u = m0 >> 6; u < u1; ++u) any |= p.unit_sel[u];
+    return any != 0;
+}
 
 constexpr int GEMM_BK = 64;
 constexpr int GEMM_GROUP_M = 4;                 // end-to-end sweep 2..16 on the C3 prefill: 4-6 best (-0.5 % vs 8), 16 +4 %
@@ -472,13 +490,14 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     o[4 + e] = OutCvt<T>::cvt(fast_silu(g1[e]) * u1[e] * os);
                 }
                 if constexpr (OUT4 && sizeof(T) == 2) {
-                    if (p.out4) {                                    // (wave-uniform) residual image of the products: a row's 4 lanes = one 32-column block
+                    const bool sel = !p.row_sel || p.row_sel[m < p.M ? m : p.M - 1];
+                    if (p.out4 && wave_any(sel)) {                   // (wave-uniform) residual image of the products: a row's 4 lanes = one 32-column block
                         float y[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { y[e] = fast_silu(g0[e]) * u0[e]; y[4 + e] = fast_silu(g1[e]) * u1[e]; }
                         unsigned sb;
                         const unsigned codes = lo4_encode8<T>(y, o, sb);
-                        if (m < p.M) {
+                        if (m < p.M && sel) {
                             const long orow4 = p.row_map ? (long)p.row_map[m] : (long)m;
                             const int col = (nw0 >> 1) + oc;
                             *(unsigned*)((char*)p.out4 + orow4 * p.ld_out4 + (col >> 1)) = codes;
@@ -548,8 +567,10 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
             // residual image of the 16-bit values handed to the next GEMM (every lane takes part in the quad exchange, rows past M included)
             unsigned codes4 = 0, sb4 = 0;
             T8 o4;
+            bool sel4 = false;
             if constexpr (OUT4 && sizeof(T) == 2 && (EPI == EPI_STORE_T || EPI == EPI_RESID_F32)) {
-                if (p.out4 && (EPI == EPI_STORE_T || p.norm_out)) {
+                if (p.out4 && (EPI == EPI_STORE_T || p.norm_out)) sel4 = !p.row_sel || p.row_sel[imin(mb + it * RPI + r_in, p.M - 1)];
+                if (wave_any(sel4)) {
                     float y[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -561,7 +582,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
             }
             if (mb + it * RPI + r_in >= p.M) continue;
             if constexpr (OUT4 && sizeof(T) == 2 && (EPI == EPI_STORE_T || EPI == EPI_RESID_F32)) {
-                if (p.out4 && (EPI == EPI_STORE_T || p.norm_out)) {
+                if (sel4) {
                     *(unsigned*)((char*)p.out4 + orow[it] * p.ld_out4 + ((nw0 + oc) >> 1)) = codes4;
                     if ((lane & 3) == 0) p.out4_scale[orow[it] * p.ld_out4s + ((nw0 + oc) >> 5)] = (uint8_t)sb4;
                 }
@@ -736,7 +757,8 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     const int nt = p.K / (128 / ES);                                // k-tiles of 128 bytes per row
     // LO4: the ring simply continues over the fp4 k-tiles (global tile index tg = nt + u for fp4 tile u); the stager switches sources
     // when the first fp4 tile is issued, the fragment offsets / MFMA when it is multiplied
-    const int nt_all = LO4 ? nt + p.K4 / 256 : nt;
+    const bool sel_tile = LO4 && gemm_tile_selected(p, m0, C::BM);   // (workgroup-uniform) no selected row: the 16-bit pass alone
+    const int nt_all = sel_tile ? nt + p.K4 / 256 : nt;
     GemmLo4<C> lo4;
     if constexpr (LO4) lo4.init(p, m0, n0, tid, wave, wn, fr, smem);
     // VMEM operations per k-tile and thread: G operand pieces (+ the scale pieces of an fp4 tile).  The counted wait of tile t uses the
@@ -800,8 +822,10 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     };
     for (int t = 0; t < nt; ++t) k_tile(std::false_type{}, t);
     if constexpr (LO4) {
-        w_off.init(0, fr, fh);                                       // the fp4 weight image is row-major
-        for (int t = nt; t < nt_all; ++t) k_tile(std::true_type{}, t);
+        if (sel_tile) {
+            w_off.init(0, fr, fh);                                   // the fp4 weight image is row-major
+            for (int t = nt; t < nt_all; ++t) k_tile(std::true_type{}, t);
+        }
     }
 
     if (CAN_SCALE && p.rowsq_in) row_scale.finish(p, tid, rstd_lds);   // published by the barrier below
@@ -942,9 +966,21 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
+    const bool sel_tile = LO4 && gemm_tile_selected(p, m0, C::BM);   // (workgroup-uniform) no selected row: the 16-bit pass alone
     auto run = [&](auto full_tag) {
         const std::false_type hi{};
+        auto fast_seq = [&]() {                                    // the 16-bit k-tiles alone
+            if (TWO && nt > 1) {
+                tile(I0{}, full_tag, hi, 0, 0);                    // k-tile 1 is already in flight; its pieces drain in k-step 3 as usual
+                for (int t = 1; t + 1 < nt; ++t) tile(I1{}, full_tag, hi, t, t + 1);
+                tile(I0{}, full_tag, hi, nt - 1, 0);
+            } else {
+                for (int t = 0; t + 1 < nt; ++t) tile(I1{}, full_tag, hi, t, t + 1);
+                tile(I0{}, full_tag, hi, nt - 1, 0);
+            }
+        };
         if constexpr (LO4) {
+            if (!sel_tile) { fast_seq(); return; }                 // (workgroup-uniform) no row of this tile carries a residual image
             // 16-bit tiles 0 .. nt-1 (nt >= 2, checked by the launcher), then fp4 tiles 0 .. n4-1 in the same ring: the last 16-bit tile
             // issues fp4 tile 0 (its operand pieces were issued under tile nt-2 and drained there, so the stager may switch sources)
             const int n4 = p.K4 / 256;
@@ -956,13 +992,8 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
             const std::true_type lo{};
             for (int u = 0; u + 1 < n4; ++u) tile(I2{}, full_tag, lo, nt + u, u + 1);
             tile(I0{}, full_tag, lo, nt + n4 - 1, 0);
-        } else if (TWO && nt > 1) {
-            tile(I0{}, full_tag, hi, 0, 0);                        // k-tile 1 is already in flight; its pieces drain in k-step 3 as usual
-            for (int t = 1; t + 1 < nt; ++t) tile(I1{}, full_tag, hi, t, t + 1);
-            tile(I0{}, full_tag, hi, nt - 1, 0);
         } else {
-            for (int t = 0; t + 1 < nt; ++t) tile(I1{}, full_tag, hi, t, t + 1);
-            tile(I0{}, full_tag, hi, nt - 1, 0);
+            fast_seq();
         }
     };
     if (nmi == C::MI) run(std::true_type{}); else run(std::false_type{});

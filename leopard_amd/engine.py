@@ -123,6 +123,7 @@ class LeopardEngine:
         self._workspaces: Dict[tuple, torch.Tensor] = {}   # caller-owned scratch per (stage, launch stream) (lmi_llm_prefill_workspace_bytes / lmi_vit_workspace_bytes)
         self.graph_encode = False      # capture the vision encode per ViT-input count in a HIP graph (BASELINE config 5)
         self._encode_graphs: Dict[tuple, tuple] = {}   # (ViT-input count, stream) -> (graph, static in, static out)
+        self._private_scratch = False  # True while an encode graph is warmed up / captured: _carve hands out fresh allocations the graph owns
         self.fuse_norm_rope = True     # Llama layers: RMSNorm + RoPE + KV append inside the GEMM epilogues (lmi_rmsnorm_rope / lmi_gemm_ex)
         self.suppress_tokens = None    # optional int64 device tensor of token ids that greedy decoding may never emit (HF bad_words_ids)
         self.trace = None              # optional callable(name, fp32 residual stream) after the embeddings / every layer (tests)
@@ -140,7 +141,17 @@ class LeopardEngine:
         # full depth, the tower's correction moves the logits of the benchmarked C3 sample by < 1 % (2.35e-4 vs 2.37e-4 of the logit scale) and
         # those of the hardest case — C1: one ViT input, S = 228 — from 7.3e-4 to 6.1e-4, for + 6 % of the step (1.20 x vs 1.27 x the fast schedule)
         self.lo4_vit = os.environ.get("LMI_LO4_VIT", "0") == "1"
-        self._lo4_w = None
+        self._lo4_w = {}               # tower -> fp4 weight images (built when the mode is selected / on first use; dropped by invalidate_lo4_weights)
+        # WHICH ROWS carry the correction (round 6; DESIGN.md 2.1 "row selection", tools/lo4_policy_study.py).  The logits of a row are dominated by
+        # the hand-over roundings on that row's OWN path through the 32 layers; the roundings of the other rows reach it only through the softmax
+        # average over the keys, i.e. attenuated by ~sqrt(S) (emulating oracle, C1: correcting ONLY the last row removes 90 % of what correcting all
+        # 228 rows removes).  The rows whose logits are read are the last rows of each sequence, so by default ("auto") a sequence longer than
+        # LO4_FULL_BELOW rows carries the correction on its last LO4_TAIL_ROWS rows only; shorter sequences on every row.  "all" = every row (round
+        # 5's schedule); an int = that many trailing rows.  A property of the ROW (its distance from the end of its sequence), not of where the row
+        # lands in a tile: packed == separate stays bit for bit.  LMI_LO4_ROWS overrides.
+        env_rows = os.environ.get("LMI_LO4_ROWS", "auto")
+        self.lo4_rows = env_rows if env_rows in ("auto", "all") else int(env_rows)
+        self._lo4_sel_cache: Dict[tuple, tuple] = {}
         self.skinny_fold_norm = True   # batched decode: RMSNorms folded into the projections (lmi_gemm_skinny_ex producer / consumer); False: norm launches
         self.skinny_packed = True      # batched decode over nn.Linear-layout weights (TP, pack_llm_weights=False): stream a packed second copy
         self.fp8_fused = True          # fp8 schedule: attention writes the fp8 o_proj operand, q|k|v GEMM does RoPE + KV append (False: separate launches)
@@ -197,6 +208,8 @@ class LeopardEngine:
             raise ValueError("precision 'lo4' needs the fused Llama / Mistral layer shape (head_dim 128, hidden % 256 == 0): use 'split'")
         self.split_operands, self.lo4 = mode == "split", mode == "lo4"
         self._encode_graphs.clear()                           # captured encodes replay the launches of the old schedule
+        if self.lo4 and self.device.type == "cuda":
+            self._lo4_weights("llm")                          # the multi-GB quantisation happens HERE, not inside the first (timed) prefill
 
     def _llm_heads(self) -> Tuple[int, int]:
         """(query heads, kv heads) this rank computes."""
@@ -304,16 +317,20 @@ class LeopardEngine:
         order.  Per stream because passes on different HIP streams are not ordered against each other (bench.py --inflight > 1, a graph
         capture beside eager work): they must not share scratch.  A workspace is allocated while its stream is current, so the caching
         allocator's own stream bookkeeping covers its release."""
-        sid = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-        key = (which, sid)
-        ws = self._workspaces.get(key)
-        if ws is None or ws.numel() < total:
-            if ws is None and len(self._workspaces) >= 16:              # streams come and go (graph captures): bound the table
-                self._workspaces.pop(next(iter(self._workspaces)))
-            ws = self._workspaces[key] = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
-            if which == "vit":                                          # graphs captured on this stream point into the old workspace
-                for k in [k for k in self._encode_graphs if k[1] == sid]:
-                    self._encode_graphs.pop(k)
+        if self._private_scratch:
+            # warm-up and capture of a vision-encode graph (_encode_images_graph): inside capture the current stream is torch's capture stream,
+            # whatever stream the graph is later launched on — a table keyed by it would hand every captured graph the SAME scratch, and
+            # replays of two graphs on two launch streams (bench.py --inflight 2 --graph-encode) would race on it.  A graph therefore OWNS its
+            # scratch: allocated here, inside the capture, from the graph's private pool; it lives and dies with the graph (round 6, advisor).
+            ws = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
+        else:
+            sid = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+            key = (which, sid)
+            ws = self._workspaces.get(key)
+            if ws is None or ws.numel() < total:
+                if ws is None and len(self._workspaces) >= 16:          # streams come and go: bound the table.  An evicted workspace was allocated on
+                    self._workspaces.pop(next(iter(self._workspaces)))  # ITS stream and only ever used there, so the allocator's reuse is ordered; no
+                ws = self._workspaces[key] = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)   # graph points into the table
         out = []
         for off, (r, c, dt) in zip(offsets, specs):
             nbytes = r * c * torch.empty(0, dtype=dt).element_size()
@@ -512,24 +529,66 @@ class LeopardEngine:
                 self.trace(f"llm.{i}", x)
 
     # ---- low-bit correction mode --------------------------------------------------------------------------------------------------------
-    def _lo4_weights(self):
-        """fp4 images (+ one E8M0 scale per row) of the layer-linear weights, built on first use from the row-major order of each weight:
-        + 0.5 B per parameter (0.2 GB SigLIP + 3.5 GB Llama-3.1-8B)."""
-        lw = self._lo4_w
+    LO4_FULL_BELOW = 1024              # "auto": sequences up to this length carry the correction on every row ...
+    LO4_TAIL_ROWS = 256                # ... longer ones on their last LO4_TAIL_ROWS rows (tools/lo4_policy_study.py, profiles/r06_lo4_policy_study_*.txt)
+
+    def _lo4_weights(self, tower: str = "llm"):
+        """fp4 images (+ one E8M0 scale per row) of one tower's layer-linear weights, built from the row-major order of each weight when the
+        mode is selected (or on first use): + 0.5 B per parameter (3.5 GB Llama-3.1-8B; 0.2 GB SigLIP, only with ``lo4_vit``)."""
+        lw = self._lo4_w.get(tower)
         if lw is None:
             from .weights import as_row_major
             q = lambda w, head_pad=None: self.ops.quantize_w4(as_row_major(w).contiguous(), head_pad=head_pad)
             W, vc = self.W, self.cfg.vision_config
-            vhp = (vc.num_attention_heads, vc.head_dim)          # out_proj's image in the per-head padded k order of the attention's residual image
-            lw = self._lo4_w = {
-                "vit": [(q(L.qkv_w), q(L.o_w, vhp), q(L.fc1_w), q(L.fc2_w)) for L in W.vit_layers],
-                "llm": [(q(L.qkv_w_rope if L.qkv_w_rope is not None else L.qkv_w), q(L.o_w), q(L.gu_w), q(L.down_w)) for L in W.llm_layers]}
+            if tower == "vit":
+                vhp = (vc.num_attention_heads, vc.head_dim)      # out_proj's image in the per-head padded k order of the attention's residual image
+                lw = [(q(L.qkv_w), q(L.o_w, vhp), q(L.fc1_w), q(L.fc2_w)) for L in W.vit_layers]
+            else:
+                lw = [(q(L.qkv_w_rope if L.qkv_w_rope is not None else L.qkv_w), q(L.o_w), q(L.gu_w), q(L.down_w)) for L in W.llm_layers]
+            self._lo4_w[tower] = lw
         return lw
 
-    def _lo4_act(self, rows: int, width: int, heads: Optional[tuple] = None):
-        """Operand pair buffers; ``heads`` = (n_heads, head_dim): an attention output (image in the per-head padded k order)."""
+    def invalidate_lo4_weights(self) -> None:
+        """Drop the fp4 weight images: call after replacing or changing the VALUES of layer weights (the images are a function of the values; a
+        change of layout — pack / unpack — keeps them valid)."""
+        self._lo4_w = {}
+
+    def lo4_tail_rows(self, seq_len: int) -> int:
+        """How many trailing rows of a ``seq_len``-row sequence carry the correction under ``lo4_rows``."""
+        r = self.lo4_rows
+        if r == "all":
+            return seq_len
+        if r == "auto":
+            return seq_len if seq_len <= self.LO4_FULL_BELOW else min(self.LO4_TAIL_ROWS, seq_len)
+        return max(1, min(int(r), seq_len))
+
+    def _lo4_selection(self, seq_lens: Sequence[int]):
+        """(row_sel uint8 [S], unit_sel uint8 [ceil(S / 64)]) device tensors for the packed rows of ``seq_lens``, or None when every row is selected."""
+        tails = [self.lo4_tail_rows(int(l)) for l in seq_lens]
+        if all(t == int(l) for t, l in zip(tails, seq_lens)):
+            return None
+        key = (tuple(int(l) for l in seq_lens), tuple(tails))
+        hit = self._lo4_sel_cache.get(key)
+        if hit is None:
+            S = int(sum(key[0]))
+            row = np.zeros(S, dtype=np.uint8)
+            end = 0
+            for l, t in zip(*key):
+                end += l
+                row[end - t:end] = 1
+            unit = np.zeros((S + 63) // 64 * 64, dtype=np.uint8)
+            unit[:S] = row
+            unit = unit.reshape(-1, 64).max(axis=1)
+            if len(self._lo4_sel_cache) >= 64:
+                self._lo4_sel_cache.pop(next(iter(self._lo4_sel_cache)))
+            hit = self._lo4_sel_cache[key] = (self._pinned_to_device(torch.from_numpy(row)), self._pinned_to_device(torch.from_numpy(unit)))
+        return hit
+
+    def _lo4_act(self, rows: int, width: int, heads: Optional[tuple] = None, sel: Optional[tuple] = None):
+        """Operand pair buffers; ``heads`` = (n_heads, head_dim): an attention output (image in the per-head padded k order); ``sel``: the row
+        selection of the pass (_lo4_selection) — the images then start out zero and only selected rows are ever written."""
         from .ops import Lo4Act, lo4_head_k4
-        return Lo4Act.empty(rows, width, self.dtype, self.device, k4=lo4_head_k4(*heads) if heads else None)
+        return Lo4Act.empty(rows, width, self.dtype, self.device, k4=lo4_head_k4(*heads) if heads else None, sel=sel)
 
     def _vit_layers_lo4(self, x: torch.Tensor, n: int) -> torch.Tensor:
         """The SigLIP layers with the low-bit correction phase: the LayerNorms and fc1's GELU epilogue hand over T(y) + the fp4 image of
@@ -542,7 +601,7 @@ class LeopardEngine:
         qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0])
         cu = self._vit_cu_cache[n]
         scale = hd ** -0.5
-        for li, (L, (qkv4, o4, fc14, fc24)) in enumerate(zip(W.vit_layers, self._lo4_weights()["vit"])):
+        for li, (L, (qkv4, o4, fc14, fc24)) in enumerate(zip(W.vit_layers, self._lo4_weights("vit"))):
             ops.norm_lo4(x, L.ln1_w, L.ln1_b, h, vc.layer_norm_eps)
             ops.gemm_lo4(h, L.qkv_w, qkv4, qkv, bias=L.qkv_b)
             ops.attention_lo4(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, cu, cu, T, H, H, hd, scale, False)
@@ -556,7 +615,7 @@ class LeopardEngine:
         ops.layernorm(x, W.post_ln_w, W.post_ln_b, out, vc.layer_norm_eps)
         return out
 
-    def _llm_layers_lo4(self, x, cache, cu, cos, sin, max_len):
+    def _llm_layers_lo4(self, x, cache, cu, cos, sin, max_len, seq_lens=None, all_rows=False):
         """The Llama / Mistral layers with the low-bit correction phase, on the FUSED schedule of the fast path: the RMSNorms ride in the GEMM
         epilogues (the producers o_proj / down_proj also write the fp4 image of the residual of T(x gamma)), q|k|v + RoPE + KV append is one
         launch, gate/up's SwiGLU epilogue writes down_proj's operand pair, the attention kernel o_proj's: no launch is added to the fast schedule."""
@@ -566,13 +625,17 @@ class LeopardEngine:
         qw, kw = H * hd, KV * hd
         if not (hd == 128 and D % 256 == 0 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None):
             raise RuntimeError("precision 'lo4' needs head_dim 128 and the rope-ordered q|k|v weights (the fused Llama / Mistral schedule)")
-        h, att, gu = self._lo4_act(S, D), self._lo4_act(S, qw, heads=(H, hd)), self._lo4_act(S, W.llm_ff)
+        # row selection (lo4_rows): only the trailing rows of each sequence hand over residual images; the other rows' images stay zero and the
+        # tiles without a selected row skip the fp4 k-tiles (csrc/gemm.h GemmArgs::row_sel)
+        # (``all_rows``: the caller reads the logits of EVERY row — all_logits — so every row is a logits row)
+        sel = None if all_rows else self._lo4_selection(seq_lens if seq_lens is not None else [S])
+        h, att, gu = self._lo4_act(S, D, sel=sel), self._lo4_act(S, qw, heads=(H, hd), sel=sel), self._lo4_act(S, W.llm_ff, sel=sel)
         qkv = self._empty(S, qw + 2 * kw)
         parts = (D + 63) // 64
         sq_a, sq_b = self._empty(S, parts, dtype=torch.float32), self._empty(S, parts, dtype=torch.float32)
         scale = hd ** -0.5
         n_layers = len(W.llm_layers)
-        for i, (L, (qkv4, o4, gu4, down4)) in enumerate(zip(W.llm_layers, self._lo4_weights()["llm"])):
+        for i, (L, (qkv4, o4, gu4, down4)) in enumerate(zip(W.llm_layers, self._lo4_weights("llm"))):
             if i == 0:
                 ops.norm_lo4(x, L.in_norm, None, h, tc.rms_norm_eps)
             ops.rmsnorm_rope_lo4(h, L.qkv_w_rope, qkv4, qkv, None if i == 0 else sq_b, tc.rms_norm_eps, cos, sin,
@@ -632,12 +695,16 @@ class LeopardEngine:
             static_in.copy_(tiles)
             side = torch.cuda.Stream(device=self.device)                       # warm-up outside capture (LDS attributes, allocator)
             side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):
-                self.project(self.vision_tower(static_in), n)
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                static_out = self.project(self.vision_tower(static_in), n)
+            self._private_scratch = True                                       # the graph owns its tower scratch (see _carve)
+            try:
+                with torch.cuda.stream(side):
+                    self.project(self.vision_tower(static_in), n)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    static_out = self.project(self.vision_tower(static_in), n)
+            finally:
+                self._private_scratch = False
             if len(self._encode_graphs) >= 8:                                  # a handful of distinct N per workload; bound the pools
                 self._encode_graphs.pop(next(iter(self._encode_graphs)))
             ent = self._encode_graphs[key] = (g, static_in, static_out)
@@ -688,7 +755,7 @@ class LeopardEngine:
             if self.fp8 is not None:
                 self._llm_layers_fp8(x, cache, cu, cos, sin, max_len, seq_lens)
             elif self.lo4:
-                self._llm_layers_lo4(x, cache, cu, cos, sin, max_len)
+                self._llm_layers_lo4(x, cache, cu, cos, sin, max_len, seq_lens, all_rows=all_logits)
             else:
                 self._llm_layers_split(x, cache, cu, cos, sin, max_len)
             if cache is not None:
@@ -963,7 +1030,7 @@ class LeopardEngine:
             from .ops import lo4_packed_act
             if not (hd == 128 and W.llm_layers and W.llm_layers[0].qkv_w_rope is not None):
                 raise RuntimeError("precision 'lo4' needs head_dim 128 and the rope-ordered q|k|v weights")
-            L4 = self._lo4_weights()["llm"]
+            L4 = self._lo4_weights("llm")
             h_loc = [lo4_packed_act(Sl, D_, T, dev) for _ in range(NC)]
             h_full = [lo4_packed_act(Sc, D_, T, dev) for _ in range(NC)]
             att, gu = self._lo4_act(Sc, qw, heads=(H, hd)), self._lo4_act(Sc, W.llm_ff)

@@ -182,7 +182,7 @@ class Idefics2Engine(LeopardEngine):
             # rounding residual; the connector (modality projection + 3 perceiver layers) keeps the fast schedule, the Mistral layers take
             # LeopardEngine._llm_layers_lo4
             h4, att4, ff4 = self._lo4_act(M, D), self._lo4_act(M, D, heads=(H, hd)), self._lo4_act(M, W.vit_ff)
-            for L, (qkv4, o4, fc14, fc24) in zip(W.vit_layers, self._lo4_weights()["vit"]):
+            for L, (qkv4, o4, fc14, fc24) in zip(W.vit_layers, self._lo4_weights("vit")):
                 ops.norm_lo4(x, L.ln1_w, L.ln1_b, h4, vc.layer_norm_eps)
                 ops.gemm_lo4(h4, L.qkv_w, qkv4, qkv, bias=L.qkv_b)
                 ops.attention_lo4(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att4, cu, cu, max(counts), H, H, hd, hd ** -0.5, False)

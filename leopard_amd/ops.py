@@ -43,23 +43,30 @@ class Lo4Act:
     """One A operand of a GEMM with the low-bit correction phase (include/leopard_amd.h ``lmi_lo4``): ``hi`` = T(x) [M, K], ``img`` = the
     fp4 (e2m1) image of x - T(x) [M, K4 / 2] bytes, ``sc`` = its E8M0 block scales [M, K4 / 32].  The three are views into caller-owned
     scratch; the producers (lmi_norm_lo4, lmi_split_lo4, the GEMM epilogues) write all of them, padding included."""
-    __slots__ = ("hi", "img", "sc", "K", "K4", "buf")
+    __slots__ = ("hi", "img", "sc", "K", "K4", "buf", "row_sel", "unit_sel")
 
     def __init__(self, hi: torch.Tensor, img: torch.Tensor, sc: torch.Tensor):
         self.hi, self.img, self.sc, self.buf = hi, img, sc, None
+        # row selection of the correction phase (lmi_lo4.row_sel / unit_sel; LeopardEngine.lo4_rows): uint8 [M] / [ceil(M / 64)] device tensors, or
+        # None = every row.  With a selection the image and scales MUST start out zero (Lo4Act.empty(..., zero=True)): producers skip unselected rows
+        self.row_sel = self.unit_sel = None
         self.K = hi.shape[1]
         self.K4 = img.shape[1] * 2          # lo4_k4(K), or wider when the image carries a padded k order (attention outputs, head_dim 72 / 96)
         assert img.dtype == torch.uint8 and sc.dtype == torch.uint8 and self.K4 % 256 == 0 and self.K4 >= self.K and sc.shape[0] == hi.shape[0] == img.shape[0]
         assert sc.shape[1] >= self.K4 // 32 and sc.stride(0) % 4 == 0 and img.stride(0) % 16 == 0
 
     @staticmethod
-    def empty(M: int, K: int, dtype, device, k4: Optional[int] = None) -> "Lo4Act":
+    def empty(M: int, K: int, dtype, device, k4: Optional[int] = None, sel: Optional[tuple] = None) -> "Lo4Act":
         # a padded k order, or K not a multiple of 256: the attention kernel and the GEMM epilogues write their own blocks only — the padding
-        # must read as zero codes / zero scales (the norm and split kernels write theirs)
+        # must read as zero codes / zero scales (the norm and split kernels write theirs); a row selection: the unselected rows are never written
         k4 = k4 or lo4_k4(K)
-        alloc = torch.zeros if k4 != K else torch.empty
-        return Lo4Act(torch.empty(M, K, dtype=dtype, device=device), alloc(M, k4 // 2, dtype=torch.uint8, device=device),
-                      alloc(M, k4 // 32, dtype=torch.uint8, device=device))
+        alloc = torch.zeros if (k4 != K or sel is not None) else torch.empty
+        act = Lo4Act(torch.empty(M, K, dtype=dtype, device=device), alloc(M, k4 // 2, dtype=torch.uint8, device=device),
+                     alloc(M, k4 // 32, dtype=torch.uint8, device=device))
+        if sel is not None:
+            act.row_sel, act.unit_sel = sel
+            assert act.row_sel.dtype == torch.uint8 and act.row_sel.numel() == M and act.unit_sel.numel() == (M + 63) // 64
+        return act
 
 
 def lo4_packed_act(M: int, K: int, dtype, device) -> Lo4Act:
@@ -417,6 +424,10 @@ class Ops:
             d.w4, d.w4_scale, d.ldw4 = w4.img.data_ptr(), w4.sc.data_ptr(), w4.img.stride(0)
         if out4 is not None:
             d.out4, d.out4_scale, d.ld_out4, d.ld_out4s = out4.img.data_ptr(), out4.sc.data_ptr(), out4.img.stride(0), out4.sc.stride(0)
+        sel = a if (a is not None and a.row_sel is not None) else out4          # consumer and producer share ONE row space: the same selection
+        if sel is not None and sel.row_sel is not None:
+            assert out4 is None or a is None or out4.row_sel is None or out4.row_sel.data_ptr() == a.row_sel.data_ptr()
+            d.row_sel, d.unit_sel = sel.row_sel.data_ptr(), sel.unit_sel.data_ptr()
         return d
 
     def quantize_w4(self, w: torch.Tensor, head_pad: Optional[tuple] = None) -> Lo4Weight:
@@ -441,10 +452,10 @@ class Ops:
         per-head padded k order (act must have k4 = lo4_head_k4(n_heads, head_dim))."""
         n_seq = cu_q.numel() - 1
         assert act.K4 == lo4_head_k4(n_heads, head_dim)
-        self._check(self.lib.lmi_attn_varlen_fwd_lo4(_ptr(q), _ptr(k), _ptr(v), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), act.img.stride(0), act.sc.stride(0),
-                                                     _ptr(cu_q), _ptr(cu_k), n_seq, int(max_seqlen_q), n_heads, n_kv_heads, head_dim, q.stride(0), k.stride(0),
-                                                     v.stride(0), act.hi.stride(0), float(scale), int(bool(causal)), int(window), _DT[q.dtype],
-                                                     self._stream(act.hi)))
+        self._check(self.lib.lmi_attn_varlen_fwd_lo4_rows(_ptr(q), _ptr(k), _ptr(v), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), act.img.stride(0),
+                                                          act.sc.stride(0), _ptr(cu_q), _ptr(cu_k), n_seq, int(max_seqlen_q), n_heads, n_kv_heads, head_dim,
+                                                          q.stride(0), k.stride(0), v.stride(0), act.hi.stride(0), float(scale), int(bool(causal)),
+                                                          int(window), _ptr(act.row_sel), _DT[q.dtype], self._stream(act.hi)))
         return act
 
     def split_lo4(self, x_f32: torch.Tensor, act: Lo4Act) -> Lo4Act:
@@ -459,8 +470,9 @@ class Ops:
         """LayerNorm (b given) / RMSNorm (b None) of the fp32 rows x, handed over as a Lo4Act (lmi_norm_lo4)."""
         M, D = x.shape
         assert act.hi.shape == (M, D)
-        self._check(self.lib.lmi_norm_lo4(_ptr(x), _ptr(w), _ptr(b), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), M, D, act.K4, x.stride(0),
-                                          act.hi.stride(0), act.img.stride(0), act.sc.stride(0), float(eps), _DT[act.hi.dtype], self._stream(x)))
+        self._check(self.lib.lmi_norm_lo4_rows(_ptr(x), _ptr(w), _ptr(b), _ptr(act.hi), _ptr(act.img), _ptr(act.sc), M, D, act.K4, x.stride(0),
+                                               act.hi.stride(0), act.img.stride(0), act.sc.stride(0), float(eps), _ptr(act.row_sel), _DT[act.hi.dtype],
+                                               self._stream(x)))
         return act
 
     def add_rmsnorm_lo4(self, x, delta, w, act: Lo4Act, eps) -> Lo4Act:

@@ -76,14 +76,14 @@ _PRECISION_TEXT = {"fast": "fast (one rounding per MFMA-operand hand-over)",
                    "split": "split operands (hi + lo 16-bit pairs, GEMMs at 2 K)"}
 
 
-def _record_run_info(model_class: str, checkpoint: str, requested, compute, precision: str = "fast") -> None:
+def _record_run_info(model_class: str, checkpoint: str, requested, compute, precision: str = "fast", warn: bool = True) -> None:
     """Side file of the result rows: what arithmetic the script's ``torch_dtype`` request was actually served with.  Written where the
     script writes its result shards — the checkpoint directory (EVAL:496-497) — or ``LEOPARD_AMD_RUN_INFO_DIR``; a location that cannot be
     written falls back to the working directory, then to the warning alone."""
     import json
     import warnings
     req, cmp_ = str(requested).replace("torch.", ""), str(compute).replace("torch.", "")
-    if requested is not None and requested != compute:
+    if warn and requested is not None and requested != compute:
         warnings.warn(f"{model_class}.from_pretrained: torch_dtype={req} was requested; leopard_amd computes with {cmp_} MFMA operands "
                       f"(fp32 accumulation, fp32 residual streams), precision mode {precision} — recorded in leopard_amd_run_info.json",
                       UserWarning, stacklevel=3)
@@ -142,15 +142,23 @@ def _llava_class():
             cfg = load_config(path)
             if compute_dtype is None:                     # a 16-bit request is honoured as is; fp32 (EVAL:373) is served in 16 bits, loudly
                 compute_dtype = _compute_dtype(torch_dtype if torch_dtype in (torch.float16, torch.bfloat16) else torch.float16)
-            _record_run_info("LlavaForConditionalGeneration", path, torch_dtype, compute_dtype, resolve_precision(torch_dtype, compute_dtype, precision))
+            recorded = resolve_precision(torch_dtype, compute_dtype, precision)
+            _record_run_info("LlavaForConditionalGeneration", path, torch_dtype, compute_dtype, recorded)
             cls._pending = (path, compute_dtype, ops if ops is not None else _ops_from_env(), torch_dtype, precision)
             try:
-                return cls(cfg)
+                m = cls(cfg)
             finally:
                 cls._pending = None
+            m._run_info = (path, torch_dtype, compute_dtype, recorded)
+            return m
 
         def to(self, device):
-            return super().to(_device(device))
+            m = super().to(_device(device))
+            info = getattr(self, "_run_info", None)
+            if info is not None and self.precision != info[3]:      # the engine fell back (a shape lo4 does not cover): the side file says what RAN
+                _record_run_info("LlavaForConditionalGeneration", info[0], info[1], info[2], self.precision, warn=False)
+                self._run_info = info[:3] + (self.precision,)
+            return m
 
         def generate(self, *args, max_new_tokens=128, **kw):
             return super().generate(*args, max_new_tokens=_cap_tokens(max_new_tokens), **kw)

@@ -73,6 +73,12 @@ class _Emu:
                           # residual x - T(x) (per-32-element E8M0 scale along the contraction axis), multiplied with a low-bit image of
                           # the weight (one E8M0 scale per weight row) into the same fp32 accumulators
     tower = ""            # "vit" / "llm" while that stack runs: lo_sites / exact_sites entries may be tower-qualified ("llm.mlp_act")
+    layer = -1            # index of the running layer: lo_sites entries may carry a layer range ("llm.mlp_act@0-15"; round 6, the
+                          # per-site correction policy of engine.lo4_policy / tools/lo4_policy_study.py)
+    sub = ""              # which of a layer's two norm operands is being handed over: "norm1" (q|k|v) / "norm2" (fc1, gate/up) — an
+                          # entry "norm" selects both
+    lo_row_start = 0      # round 6 (engine.lo4_rows): the correction is applied to the rows >= lo_row_start of the LLM stream only — the rows
+                          # whose logits are read; the other rows' roundings reach them through the softmax average over ~S keys
     lo_fmt = "e2m1"       # element format of the residual and of the weight image: "e2m1" (fp4), "e2m3" / "e3m2" (fp6), "e4m3" (fp8)
     lo_wblock = 0         # 0 = one scale per weight row (what the engine does); 32 = per-32 block scales on the weight image (study)
     _wcache: dict = {}
@@ -142,13 +148,31 @@ def _qa(x: Tensor, site: str = "") -> Tensor:
         return x
     if site and _site_in(site, _Emu.lo_sites) and _Emu.dtype is not None and _Emu.operand_dtype is None:
         hi = _q(x)
-        return _Split(hi, _lo_round(x - hi, _Emu.lo_fmt, 32))
+        lo = _lo_round(x - hi, _Emu.lo_fmt, 32)
+        if _Emu.lo_row_start > 0 and _Emu.tower == "llm":           # [..., S, D]: the rows below lo_row_start are handed over once (no image)
+            lo = lo.clone()
+            lo[..., :_Emu.lo_row_start, :] = 0
+        return _Split(hi, lo)
     return _q(x) if _Emu.operand_dtype is None else _fp8_round(x)
 
 
 def _site_in(site: str, sites) -> bool:
-    """``site`` ("norm" / "attn_out" / "mlp_act") is selected by ``sites`` either plainly or qualified with the running tower ("llm.mlp_act")."""
-    return site in sites or (_Emu.tower + "." + site) in sites
+    """``site`` ("norm" / "attn_out" / "mlp_act") is selected by ``sites`` either plainly or qualified with the running tower ("llm.mlp_act").
+    Round 6: the two norm operands of a layer can be named apart ("norm1" = the q|k|v operand, "norm2" = the fc1 / gate-up operand; "norm"
+    still means both) and an entry may end in a layer range, "llm.norm2@8-31" (inclusive)."""
+    names = (site, _Emu.sub) if (site == "norm" and _Emu.sub) else (site,)
+    for n in names:
+        if n in sites or (_Emu.tower + "." + n) in sites:
+            return True
+    for ent in sites:
+        if "@" not in ent:
+            continue
+        key, rng = ent.split("@", 1)
+        if key in names or any(key == _Emu.tower + "." + n for n in names):
+            lo, _, hi = rng.partition("-")
+            if int(lo) <= _Emu.layer <= int(hi or lo):
+                return True
+    return False
 
 
 def _lin(h, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
@@ -176,9 +200,10 @@ def _tr(name: str, x: Tensor) -> None:
 
 class emulate_rounding:
     def __init__(self, dtype, trace: Optional[list] = None, operand_dtype=None, exact_sites=(), fp8_block: int = 0, fp8_attention: bool = False,
-                 lo_sites=(), lo_fmt: str = "e2m1", lo_wblock: int = 0):
+                 lo_sites=(), lo_fmt: str = "e2m1", lo_wblock: int = 0, lo_row_start: int = 0):
         self.dtype, self.trace, self.operand_dtype, self.exact_sites = dtype, trace, operand_dtype, frozenset(exact_sites)
         self.lo = (frozenset(lo_sites), lo_fmt, lo_wblock)
+        self.lo_row_start = int(lo_row_start)
         self.fp8_block = fp8_block
         self.fp8_attention = bool(fp8_attention) and operand_dtype is not None
 
@@ -187,6 +212,7 @@ class emulate_rounding:
         self._old_sites, self._old_block, self._old_a8 = _Emu.exact_sites, _Emu.fp8_block, _Emu.fp8_attention
         self._old_lo = (_Emu.lo_sites, _Emu.lo_fmt, _Emu.lo_wblock)
         _Emu.lo_sites, _Emu.lo_fmt, _Emu.lo_wblock = self.lo
+        self._old_row_start, _Emu.lo_row_start = _Emu.lo_row_start, self.lo_row_start
         _Emu.fp8_block = self.fp8_block
         _Emu.fp8_attention = self.fp8_attention
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype = self.dtype, self.trace, self.operand_dtype
@@ -199,6 +225,7 @@ class emulate_rounding:
         _Emu.dtype, _Emu.trace, _Emu.operand_dtype, _Emu.fused = self._old
         _Emu.exact_sites, _Emu.fp8_block, _Emu.fp8_attention = self._old_sites, self._old_block, self._old_a8
         _Emu.lo_sites, _Emu.lo_fmt, _Emu.lo_wblock = self._old_lo
+        _Emu.lo_row_start = self._old_row_start
         _Emu._wcache.clear()
         return False
 
@@ -367,9 +394,10 @@ def siglip_vision_tower(pixel_values: Tensor, W: Dict[str, Tensor], cfg) -> Tens
     _tr("vit.embed", x)
     _Emu.tower = "vit"
     for i in range(cfg.vision_config.num_hidden_layers):
+        _Emu.layer = i
         x = siglip_layer(x, W, i, cfg)
         _tr(f"vit.{i}", x)
-    _Emu.tower = ""
+    _Emu.tower, _Emu.layer = "", -1
     p = "vision_tower.vision_model.post_layernorm."
     return _q(F.layer_norm(x, (x.shape[-1],), W[p + "weight"], W[p + "bias"], cfg.vision_config.layer_norm_eps))
 
@@ -483,8 +511,16 @@ def rms_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
     return w * (x * torch.rsqrt(v + eps))
 
 
-def _rms_norm_q(x: Tensor, w: Tensor, eps: float, first: bool) -> Tensor:
+def _rms_norm_q(x: Tensor, w: Tensor, eps: float, first: bool, sub: str = "") -> Tensor:
     """rms_norm followed by the hand-over rounding of the HIP path (identity without emulate_rounding)."""
+    _Emu.sub = sub
+    try:
+        return _rms_norm_q_impl(x, w, eps, first)
+    finally:
+        _Emu.sub = ""
+
+
+def _rms_norm_q_impl(x: Tensor, w: Tensor, eps: float, first: bool) -> Tensor:
     if "norm" in _Emu.exact_sites:
         return rms_norm(x, w, eps)
     if _Emu.dtype is None or not _Emu.fused or first:
@@ -503,7 +539,7 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
     H, KV, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     r = x
     pre = (lambda t: t) if _Emu.fused else _q          # unfused schedule: q / k are also rounded before the rotation
-    h = _rms_norm_q(x, W[p + "input_layernorm.weight"], tc.rms_norm_eps, first=(i == 0))
+    h = _rms_norm_q(x, W[p + "input_layernorm.weight"], tc.rms_norm_eps, first=(i == 0), sub="norm1")
     q = pre(_lin(h, W[p + "self_attn.q_proj.weight"])).view(B, S, H, hd).transpose(1, 2)
     k = pre(_lin(h, W[p + "self_attn.k_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
     v = _q(_lin(h, W[p + "self_attn.v_proj.weight"])).view(B, S, KV, hd).transpose(1, 2)
@@ -533,7 +569,7 @@ def llama_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg, cos: Tensor, sin: 
     o = _qa(o if ("attn_out" in _Emu.exact_sites or _site_in("attn_out", _Emu.lo_sites)) else _q(o), "attn_out")
     x = r + _lin(o, W[p + "self_attn.o_proj.weight"])
     r = x
-    h = _rms_norm_q(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps, first=False)
+    h = _rms_norm_q(x, W[p + "post_attention_layernorm.weight"], tc.rms_norm_eps, first=False, sub="norm2")
     g = _lin(h, W[p + "mlp.gate_proj.weight"])
     u = _lin(h, W[p + "mlp.up_proj.weight"])
     return r + _lin(_qa(F.silu(g) * u, "mlp_act"), W[p + "mlp.down_proj.weight"])       # XFMR:136-139
@@ -551,9 +587,10 @@ def llama_forward(inputs_embeds: Tensor, position_ids: Tensor, W: Dict[str, Tens
     _tr("llm.embed", x)
     _Emu.tower = "llm"
     for i in range(tc.num_hidden_layers):
+        _Emu.layer = i
         x = llama_layer(x, W, i, cfg, cos, sin, kv_out, prefix=prefix)
         _tr(f"llm.{i}", x)
-    _Emu.tower = ""
+    _Emu.tower, _Emu.layer = "", -1
     x = rms_norm(x, W[prefix + "norm.weight"], tc.rms_norm_eps)
     if last_only:
         x = x[:, -1:, :]

@@ -368,3 +368,174 @@ def test_attention_lo4_image_is_the_oracle_rule_in_the_padded_head_order(ops, hd
     exact = o32 @ w.float().T
     base = plain.float() @ w.float().T
     assert (out - exact).pow(2).mean().sqrt() < 0.35 * (base - exact).pow(2).mean().sqrt()
+
+
+# ---- row selection of the correction phase (round 6: GemmArgs::row_sel / unit_sel, LeopardEngine.lo4_rows) ----------------------------------
+def _selection(M, rows):
+    row = torch.zeros(M, dtype=torch.uint8)
+    row[list(rows)] = 1
+    unit = torch.zeros((M + 63) // 64 * 64, dtype=torch.uint8)
+    unit[:M] = row
+    return row, unit.view(-1, 64).max(dim=1).values.contiguous()
+
+
+def _select(act: Lo4Act, sel):
+    """The contract of a selected pass: unselected rows carry all-zero images."""
+    act.row_sel, act.unit_sel = sel
+    keep = sel[0].bool()
+    act.img[~keep] = 0
+    act.sc[~keep] = 0
+    return act
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 2, 5, 8, 10])
+def test_gemm_lo4_row_selection_selected_rows_are_lo4_the_others_fast_bit_for_bit(ops, cfg):
+    """Rows with row_sel != 0 get exactly the corrected result, the others exactly the fast schedule's, whatever tile they share; tiles
+    without a selected row skip the fp4 k-tiles; the output image is written for selected rows only (the rest of it stays as it was: zero)."""
+    dtype = torch.float16
+    M, N, K = 700, 256, 320
+    x, w = _operands(M, N, K, dtype, 60)
+    bias = rnd((N,), torch.float32, 61)
+    rows = list(range(100, 131)) + [255, 256] + list(range(690, 700))          # inside a tile, across a tile edge, the ragged tail; tiles 384.. unselected
+    sel = _selection(M, rows)
+    full, w4 = _act_from(ops, x, dtype), ops.quantize_w4(w)
+    part = _select(_act_from(ops, x, dtype), sel)
+    keep = sel[0].bool()
+    ops.set_option("gemm.config", cfg)
+    try:
+        want_lo4, want_fast, got = (torch.empty(M, N, dtype=torch.float32) for _ in range(3))
+        ops.gemm_lo4(full, w, w4, want_lo4, bias=bias, epilogue=_lib.EPI_STORE_F32)
+        ops.gemm(full.hi, w, want_fast, bias=bias, epilogue=_lib.EPI_STORE_F32)
+        ops.gemm_lo4(part, w, w4, got, bias=bias, epilogue=_lib.EPI_STORE_F32)
+        assert torch.equal(got[keep], want_lo4[keep]) and torch.equal(got[~keep], want_fast[~keep])
+        assert not torch.equal(want_lo4[keep], want_fast[keep])
+        # producer side: STORE + GELU with the image of its own output
+        o_full, o_part = Lo4Act.empty(M, N, dtype, "cpu"), Lo4Act.empty(M, N, dtype, "cpu", sel=sel)
+        ops.gemm_lo4(full, w, w4, o_full.hi, bias=bias, act=_lib.ACT_GELU_TANH, out4=o_full)
+        ops.gemm_lo4(part, w, w4, o_part.hi, bias=bias, act=_lib.ACT_GELU_TANH, out4=o_part)
+        assert torch.equal(o_part.hi[keep], o_full.hi[keep])
+        assert torch.equal(o_part.img[keep], o_full.img[keep]) and torch.equal(o_part.sc[keep], o_full.sc[keep])
+        assert o_part.img[~keep].abs().max() == 0 and o_part.sc[~keep].abs().max() == 0
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
+@pytest.mark.parametrize("cfg", [-1, 5, 8])
+def test_lo4_row_selection_through_the_llama_half_layer(ops, cfg):
+    """RESIDUAL producer -> SwiGLU consumer with a selection: the producer writes T(x gamma) for every row and the image for selected rows; the
+    consumer's products equal the full-lo4 products on selected rows and the fast products on the others."""
+    dtype = torch.float16
+    M, N, K, F = 330, 256, 256, 128
+    x_att, w = _operands(M, N, K, dtype, 70)
+    x0 = rnd((M, N), torch.float32, 72)
+    gamma = torch.rand(N, generator=torch.Generator().manual_seed(73)) + 0.5
+    gu_w = interleave_gate_up(rnd((F, N), dtype, 74, 0.1), rnd((F, N), dtype, 75, 0.1))
+    w4, gu4 = ops.quantize_w4(w), ops.quantize_w4(gu_w)
+    sel = _selection(M, range(300, 330))
+    keep = sel[0].bool()
+
+    def run(mode):
+        a = _act_from(ops, x_att, dtype)
+        s = sel if mode == "sel" else None
+        if s is not None:
+            _select(a, s)
+        xs = x0.clone()
+        sq = torch.empty(M, N // 64)
+        prod = Lo4Act.empty(M, F, dtype, "cpu", sel=s)
+        if mode == "fast":
+            h = torch.empty(M, N, dtype=dtype)
+            ops.gemm_ex(a.hi, w, xs, epilogue=_lib.EPI_RESIDUAL, norm_out=h, norm_gamma=gamma, rowsq_out=sq)
+            ops.gemm_ex(h, gu_w, prod.hi, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq, norm_dim=N, norm_eps=1e-5)
+            return xs, h, prod
+        h = Lo4Act.empty(M, N, dtype, "cpu", sel=s)
+        ops.gemm_lo4(a, w, w4, xs, epilogue=_lib.EPI_RESIDUAL, norm_out=h.hi, norm_gamma=gamma, rowsq_out=sq, out4=h)
+        ops.gemm_lo4(h, gu_w, gu4, prod.hi, epilogue=_lib.EPI_SWIGLU, rowsq_in=sq, norm_dim=N, norm_eps=1e-5, out4=prod)
+        return xs, h, prod
+
+    ops.set_option("gemm.config", cfg)
+    try:
+        (x_f, h_f, p_f), (x_l, h_l, p_l), (x_s, h_s, p_s) = run("fast"), run("lo4"), run("sel")
+        assert torch.equal(x_s[keep], x_l[keep]) and torch.equal(x_s[~keep], x_f[~keep])
+        assert torch.equal(h_s.hi[keep], h_l.hi[keep]) and torch.equal(h_s.hi[~keep], h_f[~keep])
+        assert torch.equal(h_s.img[keep], h_l.img[keep]) and h_s.img[~keep].abs().max() == 0 and h_s.sc[~keep].abs().max() == 0
+        assert torch.equal(p_s.hi[keep], p_l.hi[keep]) and torch.equal(p_s.hi[~keep], p_f.hi[~keep])
+        assert torch.equal(p_s.img[keep], p_l.img[keep]) and p_s.img[~keep].abs().max() == 0
+    finally:
+        ops.set_option("gemm.config", -1)
+
+
+def test_norm_and_attention_lo4_row_selection(ops):
+    dtype = torch.float16
+    M, D = 70, 256
+    x = rnd((M, D), torch.float32, 80, 2.0)
+    w = torch.rand(D, generator=torch.Generator().manual_seed(81)) + 0.5
+    sel = _selection(M, [0, 5, 63, 64, 69])
+    keep = sel[0].bool()
+    full, part = Lo4Act.empty(M, D, dtype, "cpu"), Lo4Act.empty(M, D, dtype, "cpu", sel=sel)
+    ops.norm_lo4(x, w, None, full, 1e-5)
+    ops.norm_lo4(x, w, None, part, 1e-5)
+    assert torch.equal(part.hi, full.hi)
+    assert torch.equal(part.img[keep], full.img[keep]) and torch.equal(part.sc[keep], full.sc[keep])
+    assert part.img[~keep].abs().max() == 0 and part.sc[~keep].abs().max() == 0
+    # attention: two sequences, head_dim 128, causal
+    from leopard_amd.ops import lo4_head_k4
+    H, KV, hd = 2, 1, 128
+    lens = [150, 37]
+    S = sum(lens)
+    cu = torch.tensor([0, lens[0], S], dtype=torch.int32)
+    q, k, v = rnd((S, H * hd), dtype, 82), rnd((S, KV * hd), dtype, 83), rnd((S, KV * hd), dtype, 84)
+    sel = _selection(S, list(range(140, 150)) + [S - 1])
+    keep = sel[0].bool()
+    k4 = lo4_head_k4(H, hd)
+    full, part = Lo4Act.empty(S, H * hd, dtype, "cpu", k4=k4), Lo4Act.empty(S, H * hd, dtype, "cpu", k4=k4, sel=sel)
+    ops.attention_lo4(q, k, v, full, cu, cu, max(lens), H, KV, hd, hd ** -0.5, True)
+    ops.attention_lo4(q, k, v, part, cu, cu, max(lens), H, KV, hd, hd ** -0.5, True)
+    assert torch.equal(part.hi, full.hi)
+    assert torch.equal(part.img[keep], full.img[keep]) and torch.equal(part.sc[keep], full.sc[keep])
+    assert part.img[~keep].abs().max() == 0 and part.sc[~keep].abs().max() == 0 and full.img[~keep].abs().max() > 0
+
+
+def test_engine_lo4_rows_policy_and_packed_equals_separate():
+    """LeopardEngine.lo4_rows: 'auto' / 'all' / an int — the selection is a property of a row's distance from the end of ITS sequence, so a
+    packed batch gives each sample exactly the logits of its own prefill; the selected-rows run lands on the oracle that corrects those rows."""
+    from leopard_amd.config import LeopardConfig, RopeScaling, TextConfig, VisionConfig
+    from leopard_amd.engine import LeopardEngine
+    from leopard_amd.synth import synth_state_dict_numpy
+    from leopard_amd.tiler import siglip_normalize
+    from leopard_amd.weights import EngineWeights, SynthSource
+    ops = emu_ops()
+    cfg = LeopardConfig(
+        vision_config=VisionConfig(hidden_size=1152, intermediate_size=100, num_hidden_layers=1, num_attention_heads=16,
+                                   image_size=28, patch_size=14),
+        text_config=TextConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                               num_key_value_heads=1, vocab_size=256, rope_scaling=RopeScaling()),
+        image_token_index=250)
+    dtype = torch.float16
+    W = EngineWeights.build(cfg, SynthSource(cfg, ops, "cpu", dtype), dtype)
+    eng = LeopardEngine(cfg, W, ops=ops, device="cpu")
+    assert eng.lo4_rows == "auto" and eng.lo4_tail_rows(228) == 228 and eng.lo4_tail_rows(7187) == eng.LO4_TAIL_ROWS
+    assert eng._lo4_selection([228, 100]) is None                     # every row of every (short) sequence: no tables
+    eng.lo4_rows = 3
+    row, unit = eng._lo4_selection([70, 9])
+    assert row.tolist() == [0] * 67 + [1] * 3 + [0] * 6 + [1] * 3 and unit.tolist() == [0, 1]
+    tiles = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
+    ids_a = torch.tensor([[5, 250, 9, 250, 17, 33, 101, 7, 3, 11, 200, 90]])
+    ids_b = torch.tensor([[5, 250, 9, 17, 33]])
+    eng.precision = "lo4"
+    one_a, one_b = eng.prefill(ids_a, tiles).logits_last.clone(), eng.prefill(ids_b, tiles[:1]).logits_last.clone()
+    both, _ = eng.prefill_batch([(ids_a, tiles), (ids_b, tiles[:1])])
+    assert torch.equal(both[0], one_a.reshape(-1)) and torch.equal(both[1], one_b.reshape(-1))
+    # where the run sits: the oracle with the correction on the last 3 rows of the LLM stream
+    pix = torch.from_numpy(siglip_normalize(tiles.numpy()))
+    Wt = O.weights_from_numpy(synth_state_dict_numpy(cfg))
+    ref = O.prefill_logits(ids_a, pix, Wt, cfg, last_only=True)[0, 0]
+    S = eng.prefill(ids_a, tiles).seq_len
+    with O.emulate_rounding(dtype, lo_sites=("llm.norm", "llm.attn_out", "llm.mlp_act"), lo_row_start=S - 3):
+        pred = O.prefill_logits(ids_a, pix, Wt, cfg, last_only=True)[0, 0]
+    scale = ref.abs().max().item()
+    e_got, e_pred = (one_a.reshape(-1) - ref).abs().max().item() / scale, (pred - ref).abs().max().item() / scale
+    assert 0.5 * e_pred <= e_got <= 2.0 * e_pred, (e_got, e_pred)
+    eng.lo4_rows = "all"
+    all_rows = eng.prefill(ids_a, tiles).logits_last.clone()
+    eng.lo4_rows = 10 ** 6                                             # more rows than the sequence has = every row
+    assert torch.equal(eng.prefill(ids_a, tiles).logits_last, all_rows)

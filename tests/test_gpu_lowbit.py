@@ -336,3 +336,111 @@ def test_attention_lo4_at_the_production_shapes(ops, name, lens, H, KV, hd, caus
     assert ((lo.view(len(rows), -1).cpu() - got).pow(2).mean().sqrt() / lo.pow(2).mean().sqrt().cpu()).item() < 0.25
     if H * nb < act.K4:
         assert act.img[:, H * nb // 2:].abs().max() == 0
+
+
+# ---- row selection of the correction phase (round 6: GemmArgs::row_sel / unit_sel, LeopardEngine.lo4_rows) ----------------------------------
+def _selection(M, rows):
+    row = torch.zeros(M, dtype=torch.uint8)
+    row[list(rows)] = 1
+    unit = torch.zeros((M + 63) // 64 * 64, dtype=torch.uint8)
+    unit[:M] = row
+    return row.to(DEV), unit.view(-1, 64).max(dim=1).values.contiguous().to(DEV)
+
+
+def _select(act, sel):
+    act.row_sel, act.unit_sel = sel
+    keep = sel[0].bool()
+    act.img[~keep] = 0
+    act.sc[~keep] = 0
+    return act
+
+
+@pytest.mark.parametrize("name,N,K,kind", [("gate/up", 28672, 4096, "swiglu"), ("down", 4096, 14336, "producer"), ("o_proj", 4096, 4096, "producer")])
+def test_gemm_lo4_row_selection_at_the_llama_shapes(ops, name, N, K, kind):
+    """M = 7187 (the C3 sequence) with the correction on the last 256 rows — rows 6931 .. 7186: the tail of row tile 27 and the 19-row tile 28.
+    Selected rows: the bits of the every-row lo4 launch (results AND the image of the output); every other row: the bits of the fast launch; the
+    image of an unselected row is never written; three launches bit-identical."""
+    dtype = torch.float16
+    M = 7187
+    x = rnd((M, K), torch.float32, 90, 2.0)
+    w = rnd((N, K), dtype, 91, 0.05)
+    if kind == "swiglu":
+        w = interleave_gate_up(w[:N // 2].contiguous(), w[N // 2:].contiguous())
+    w_run = as_packed(w)
+    w4 = ops.quantize_w4(w)
+    sel = _selection(M, range(M - 256, M))
+    keep = sel[0].bool()
+    full, part = act_from(ops, x, dtype), _select(act_from(ops, x, dtype), sel)
+    gamma = (torch.rand(N, generator=torch.Generator().manual_seed(92)) + 0.5).to(DEV)
+
+    def run(mode):
+        a = {"full": full, "sel": part, "fast": full}[mode]
+        s = sel if mode == "sel" else None
+        if kind == "swiglu":
+            o = Lo4Act.empty(M, N // 2, dtype, DEV, sel=s)
+            if mode == "fast":
+                ops.gemm_ex(a.hi, w_run, o.hi, epilogue=_lib.EPI_SWIGLU)
+            else:
+                ops.gemm_lo4(a, w_run, w4, o.hi, epilogue=_lib.EPI_SWIGLU, out4=o)
+            return (o.hi, o.img, o.sc)
+        xs = torch.ones(M, N, dtype=torch.float32, device=DEV)
+        h = Lo4Act.empty(M, N, dtype, DEV, sel=s)
+        sq = torch.empty(M, N // 64, dtype=torch.float32, device=DEV)
+        if mode == "fast":
+            ops.gemm_ex(a.hi, w_run, xs, epilogue=_lib.EPI_RESIDUAL, norm_out=h.hi, norm_gamma=gamma, rowsq_out=sq)
+        else:
+            ops.gemm_lo4(a, w_run, w4, xs, epilogue=_lib.EPI_RESIDUAL, norm_out=h.hi, norm_gamma=gamma, rowsq_out=sq, out4=h)
+        return (xs, sq, h.hi, h.img, h.sc)
+
+    f, l, s1, s2, s3 = run("fast"), run("full"), run("sel"), run("sel"), run("sel")
+    for t1, t2, t3 in zip(s1, s2, s3):
+        assert torch.equal(t1, t2) and torch.equal(t1, t3), name
+    n_val = len(s1) - 2                                                # the value tensors; the last two are the image and its scales
+    for i in range(n_val):
+        assert torch.equal(s1[i][keep], l[i][keep]) and torch.equal(s1[i][~keep], f[i][~keep]), (name, i)
+    assert not torch.equal(l[0][keep], f[0][keep])
+    assert torch.equal(s1[-2][keep], l[-2][keep]) and torch.equal(s1[-1][keep], l[-1][keep])
+    assert s1[-2][~keep].abs().max().item() == 0 and s1[-1][~keep].abs().max().item() == 0
+
+
+def test_norm_attention_and_qkv_lo4_row_selection_at_the_llama_shape(ops):
+    dtype = torch.float16
+    S, D, H, KV, hd = 7187, 4096, 32, 8, 128
+    sel = _selection(S, range(S - 256, S))
+    keep = sel[0].bool()
+    x = rnd((S, D), torch.float32, 95, 2.0)
+    g = (torch.rand(D, generator=torch.Generator().manual_seed(96)) + 0.5).to(DEV)
+    full, part = Lo4Act.empty(S, D, dtype, DEV), Lo4Act.empty(S, D, dtype, DEV, sel=sel)
+    ops.norm_lo4(x, g, None, full, 1e-5)
+    ops.norm_lo4(x, g, None, part, 1e-5)
+    assert torch.equal(part.hi, full.hi) and torch.equal(part.img[keep], full.img[keep]) and torch.equal(part.sc[keep], full.sc[keep])
+    assert part.img[~keep].abs().max().item() == 0 and part.sc[~keep].abs().max().item() == 0
+    # q|k|v + RoPE + KV append consuming the selected operand: selected rows == every-row launch, the others == the fast launch
+    w = rnd(((H + 2 * KV) * hd, D), dtype, 97, 0.05)
+    w_rope = torch.cat([rope_permute_rows(w[:(H + KV) * hd], hd), w[(H + KV) * hd:]], 0).contiguous()
+    w4 = ops.quantize_w4(w_rope)
+    pos = torch.arange(S, device=DEV).float()
+    inv = 1.0 / (5e5 ** (torch.arange(0, hd, 2, device=DEV).float() / hd))
+    cos, sin = (pos[:, None] * inv[None]).cos().contiguous(), (pos[:, None] * inv[None]).sin().contiguous()
+    outs = []
+    for mode in ("fast", "full", "sel"):
+        qkv = torch.empty(S, (H + 2 * KV) * hd, dtype=dtype, device=DEV)
+        kc, vc = torch.zeros(S, KV * hd, dtype=dtype, device=DEV), torch.zeros(S, KV * hd, dtype=dtype, device=DEV)
+        if mode == "fast":
+            ops.rmsnorm_rope(full.hi, as_packed(w_rope), qkv, None, 1e-5, cos, sin, kc, vc, 0, H, KV, hd)
+        else:
+            ops.rmsnorm_rope_lo4(full if mode == "full" else part, as_packed(w_rope), w4, qkv, None, 1e-5, cos, sin, kc, vc, 0, H, KV, hd)
+        outs.append((qkv, kc, vc))
+    for i in range(3):
+        assert torch.equal(outs[2][i][keep], outs[1][i][keep]) and torch.equal(outs[2][i][~keep], outs[0][i][~keep])
+    # attention writing the image of selected rows only
+    from leopard_amd.ops import lo4_head_k4
+    cu = torch.tensor([0, S], dtype=torch.int32, device=DEV)
+    qkv = outs[0][0]
+    qw, kw = H * hd, KV * hd
+    k4 = lo4_head_k4(H, hd)
+    a_full, a_part = Lo4Act.empty(S, qw, dtype, DEV, k4=k4), Lo4Act.empty(S, qw, dtype, DEV, k4=k4, sel=sel)
+    for a in (a_full, a_part):
+        ops.attention_lo4(qkv[:, :qw], qkv[:, qw:qw + kw], qkv[:, qw + kw:], a, cu, cu, S, H, KV, hd, hd ** -0.5, True)
+    assert torch.equal(a_part.hi, a_full.hi) and torch.equal(a_part.img[keep], a_full.img[keep]) and torch.equal(a_part.sc[keep], a_full.sc[keep])
+    assert a_part.img[~keep].abs().max().item() == 0 and a_part.sc[~keep].abs().max().item() == 0
