@@ -270,13 +270,17 @@ int lmi_attn_varlen_fwd_f32(const void* q, const void* k, const void* v, float* 
  * logits are read.  row_sel [M] bytes: != 0 <=> row m's operands carry a residual image (producers write the images of selected rows only: the
  * image buffers must be zero-filled once before the pass, an unselected row then reads as zero codes and its results are bit for bit the fast
  * schedule's wherever it sits in a tile); unit_sel [ceil(M / 64)] bytes: OR of row_sel over rows [64 u, 64 u + 64) — a tile none of whose units
- * is set skips the fp4 k-tiles.  Both null (or both given): null = every row. */
+ * is set skips the fp4 k-tiles.  Both null (or both given): null = every row.
+ * sel_ranges (optional, HOST memory, read during the call): n_sel_ranges pairs [begin, end) of rows, ascending and disjoint, covering the selected
+ * rows — a hint for the TILE ORDER only: the row tiles that hold selected rows are dispatched first and spread evenly over the XCDs (workgroups
+ * are dispatched in order and the XCDs advance in lock-step: a few 1.25 x longer tiles inside one XCD's slab would slow the whole launch). */
 typedef struct lmi_lo4 {
     const void* a4; const void* a4_scale; const void* w4; const void* w4_scale;
     int lda4, ldw4, lds4, k4;
     void* out4; void* out4_scale;
     int ld_out4, ld_out4s;
     const void* row_sel; const void* unit_sel;
+    const int* sel_ranges; int n_sel_ranges;
 } lmi_lo4;
 /* lmi_gemm_ex / lmi_rmsnorm_rope with the correction phase (plain A, row-major or packed W for the 16-bit pass, K >= 128). */
 int lmi_gemm_lo4(const void* A, const void* W, void* out, const float* bias, int M, int N, int K, int lda, int ldw, int ldo, int epilogue, int act,

@@ -24,7 +24,8 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 class Lo4Desc(C.Structure):
     """``lmi_lo4`` of include/leopard_amd.h: the fp4 images a GEMM with the low-bit correction phase consumes / produces."""
     _fields_ = [("a4", _P), ("a4_scale", _P), ("w4", _P), ("w4_scale", _P), ("lda4", _I), ("ldw4", _I), ("lds4", _I), ("k4", _I),
-                ("out4", _P), ("out4_scale", _P), ("ld_out4", _I), ("ld_out4s", _I), ("row_sel", _P), ("unit_sel", _P)]
+                ("out4", _P), ("out4_scale", _P), ("ld_out4", _I), ("ld_out4s", _I), ("row_sel", _P), ("unit_sel", _P),
+                ("sel_ranges", _P), ("n_sel_ranges", _I)]
 
 
 # name -> argtypes  (restype is int unless noted); mirrors include/leopard_amd.h one to one

@@ -167,9 +167,16 @@ int launch_gemm(const GemmArgs& a, void* stream) {
 }
 
 // ---- low-bit correction phase (lmi_gemm_lo4): the production geometries only, mapped like the fp8 family -------------------------------------
+// host-side row ranges of the row selection for the launch in flight on this thread (lmi_lo4.sel_ranges): the launcher that knows the tile
+// height turns them into ranges of row tiles (gemm.h gemm_fill_sel)
+thread_local const int* t_sel_ranges = nullptr;
+thread_local int t_sel_n = 0;
+
 template <typename T, int EPI, int ACT, typename C>
-int launch_gemm_lo4_ring(const GemmArgs& a, void* stream) {
-    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+int launch_gemm_lo4_ring(const GemmArgs& a0, void* stream) {
+    GemmArgs a = a0;
+    gemm_fill_sel(a, t_sel_ranges, t_sel_n, C::BM);
+    const int tiles = gemm_grid_size(a, C::BM, C::BN);
     static std::atomic<uint64_t> attr_done{0};
     allow_big_lds(gemm_kernel<T, EPI, ACT, AMODE_PLAIN, C, T, true>, C::SMEM_LO4, attr_done);
     LMI_LAUNCH((gemm_kernel<T, EPI, ACT, AMODE_PLAIN, C, T, true>), dim3(tiles), dim3(C::NT), C::SMEM_LO4, stream, a);
@@ -180,10 +187,12 @@ int launch_gemm_lo4(const GemmArgs& a, void* stream) {
     switch (choose_gemm_cfg(a)) {
         case 2: case 3: case 4: return launch_gemm_lo4_ring<T, EPI, ACT, Cfg2>(a, stream);
         case 5: case 6: case 7: case 1: {
-            const int tiles = ((a.M + Cfg1::BM - 1) / Cfg1::BM) * ((a.N + Cfg1::BN - 1) / Cfg1::BN);
+            GemmArgs b = a;
+            gemm_fill_sel(b, t_sel_ranges, t_sel_n, Cfg1::BM);
+            const int tiles = gemm_grid_size(b, Cfg1::BM, Cfg1::BN);
             static std::atomic<uint64_t> attr_done{0};
             allow_big_lds(gemm_stagger_kernel<T, EPI, ACT, AMODE_PLAIN, Cfg1, 0, T, true>, Cfg1::SMEM_LO4, attr_done);
-            LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE_PLAIN, Cfg1, 0, T, true>), dim3(tiles), dim3(Cfg1::NT), Cfg1::SMEM_LO4, stream, a);
+            LMI_LAUNCH((gemm_stagger_kernel<T, EPI, ACT, AMODE_PLAIN, Cfg1, 0, T, true>), dim3(tiles), dim3(Cfg1::NT), Cfg1::SMEM_LO4, stream, b);
             return check_launch("lmi_gemm_lo4");
         }
         case 8: case 9: return launch_gemm_lo4_ring<T, EPI, ACT, CfgS>(a, stream);
@@ -618,6 +627,7 @@ int lmi_set_option(const char* key, int value) {
         return LMI_OK;
     }
     if (!strcmp(key, "gemm.order")) { g_gemm_order = value ? 1 : 0; return LMI_OK; }
+    if (!strcmp(key, "gemm.sel_ragged_last")) { g_sel_keep_ragged_last = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "gemm.auto_small")) { g_gemm_auto_small = value ? 1 : 0; return LMI_OK; }
     if (!strcmp(key, "gemm.mid_m")) { g_gemm_mid_m = value ? 1 : 0; return LMI_OK; }
     {
@@ -811,7 +821,7 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
     a.A4 = nullptr; a.W4 = nullptr; a.a4_scale = nullptr; a.w4_scale = nullptr; a.lda4 = a.ldw4 = a.lds4 = a.K4 = 0;
     a.a4_bytes = a.w4_bytes = a.a4s_bytes = 0;
     a.out4 = nullptr; a.out4_scale = nullptr; a.ld_out4 = a.ld_out4s = 0;
-    a.row_sel = nullptr; a.unit_sel = nullptr;
+    a.row_sel = nullptr; a.unit_sel = nullptr; a.sel_n = a.sel_total = 0;
     if (lo) {                                                       // low-bit correction phase (lmi_gemm_lo4 / lmi_rmsnorm_rope_lo4)
         const int k4 = lo->k4;          // K rounded up to 256, or wider: the images may carry their own (padded) k order — see lmi_attn_varlen_fwd_lo4
         if (!lo->a4 || !lo->a4_scale || !lo->w4 || !lo->w4_scale || k4 < K || (k4 & 255) || K < 128 || a_mode != LMI_A_PLAIN || (lo->lda4 & 15) ||
@@ -839,6 +849,12 @@ static int gemm_entry(const char* who, const void* A, const void* W, void* out, 
             return fail(LMI_EINVAL, "%s: lo4 row selection needs row_sel [M] and unit_sel [ceil(M / 64)] together (or neither: every row)", who);
         if (lo->row_sel && row_map) return fail(LMI_EINVAL, "%s: lo4 row selection does not combine with row_map", who);
         a.row_sel = (const uint8_t*)lo->row_sel; a.unit_sel = (const uint8_t*)lo->unit_sel;
+        if (lo->n_sel_ranges < 0 || (lo->n_sel_ranges > 0 && (!lo->sel_ranges || !lo->row_sel)))
+            return fail(LMI_EINVAL, "%s: lo4 sel_ranges needs n_sel_ranges >= 0, a host array of [begin, end) row pairs and row_sel / unit_sel", who);
+        struct SelScope {                                          // visible to the launcher of THIS call only
+            SelScope(const int* r, int n) { t_sel_ranges = r; t_sel_n = n; }
+            ~SelScope() { t_sel_ranges = nullptr; t_sel_n = 0; }
+        } scope(lo->sel_ranges, lo->n_sel_ranges);
         LMI_DISPATCH_T(dtype, dispatch_gemm_lo4<f16_t>(a, epilogue, act, stream), dispatch_gemm_lo4<bf16_t>(a, epilogue, act, stream));
     }
     // (Measured and dropped, profiles/r03_ab_tail_split_and_prologue.txt: computing the last 256-column tile of SigLIP q|k|v / fc1 with a

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
                     for (int e = 0; e < 4; ++e) {
                         const float y = ww[e] * (v[i][h][e] * rstd);
                         yv[4 * h + e] = y;
-                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);       // fp8 operand: static power-of-two scale
+                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : sep_rn(y));       // fp8 operand: static power-of-two scale
                     }
                 } else {
                     const f32x4 bb = *(const f32x4*)(b + c * 8 + 4 * h);
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) norm_kernel(const float* x, const float* 
                     for (int e = 0; e < 4; ++e) {
                         const float y = (v[i][h][e] - mean) * rstd * ww[e] + bb[e];
                         yv[4 * h + e] = y;
-                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);
+                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : sep_rn(y));
                     }
                 }
             }
@@ -292,14 +292,14 @@ __global__ void __launch_bounds__(256) norm_rows_kernel(const float* x, const fl
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float y = ww[e] * (v[i][h][e] * rstd);
-                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);
+                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : sep_rn(y));
                     }
                 } else {
                     const f32x4 bb = *(const f32x4*)(b + c * 8 + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float y = (v[i][h][e] - mean) * rstd * ww[e] + bb[e];
-                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : y);
+                        o[4 * h + e] = OutCvt<T>::cvt(sizeof(T) == 1 ? y * out_scale : sep_rn(y));
                     }
                 }
             }

@@ -106,6 +106,13 @@ struct GemmArgs {
     // row_sel over rows [64 u, 64 u + 64) (what a tile tests: a handful of scalar loads).  Both null = every row selected (round 5's schedule).
     const uint8_t* row_sel;
     const uint8_t* unit_sel;
+    // Tile order under a row selection.  Workgroups are dispatched in id order, id b to XCD b % 8, and the dispatcher stalls on the first id
+    // whose XCD has no free CU: the eight XCDs advance through their slabs in lock-step, so a few 1.25 x longer (corrected) tiles inside ONE XCD's
+    // slab slow the whole launch to their pace (measured: gate/up 1.38 -> 1.73 ms with 2 of 29 row tiles corrected, profiles/r06_lo4_rows_launch.txt).
+    // The row tiles that hold selected rows (sel_n ranges of row-tile indices for THIS launch's BM, filled by the launcher from the caller's host-side
+    // row ranges) are therefore taken FIRST, round-robin over the XCDs in 32-tile patches, ahead of the other row tiles in the usual order.
+    int sel_n, sel_total;                 // ranges (0 = plain order), row tiles in them
+    int sel_tm_first[8], sel_tm_count[8];
 };
 
 // does any row of the tile [m0, m0 + bm) carry a residual image?  (m0 % 64 == 0 for every geometry; workgroup-uniform scalar loads)
@@ -297,6 +304,68 @@ LMI_DEV bool gemm_tile_coords(int bid, int tiles_m, int tiles_n, int group_m, in
     return true;
 }
 
+// tile order with the selected row tiles first (GemmArgs::sel_*); grid = gemm_grid_size(...) workgroups
+LMI_DEV bool gemm_tile_coords_sel(const GemmArgs& p, int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    if (p.sel_n == 0) return gemm_tile_coords(bid, tiles_m, tiles_n, p.group_m, p.order, tm, tn);
+    // prefix: XCD x (= bid % 8) takes the columns x, x + 8, ... of the selected row tiles, the selected row tiles of one column back to back (they
+    // share the column's W / W4 k-tiles in that XCD's L2); evenly spread whatever the count (round-robin 32-tile patches put 112 tiles on 4 XCDs)
+    const int pad = ((tiles_n + 7) >> 3) * 8 * p.sel_total;
+    if (bid < pad) {
+        const int xcd = bid & 7, q = bid >> 3;
+        tn = (q / p.sel_total) * 8 + xcd;
+        if (tn >= tiles_n) return false;
+        int j = q % p.sel_total;
+        tm = 0;
+        for (int r = 0; r < p.sel_n; ++r) {
+            if (j < p.sel_tm_count[r]) { tm = p.sel_tm_first[r] + j; break; }
+            j -= p.sel_tm_count[r];
+        }
+        return true;
+    }
+    int tmu;
+    gemm_tile_coords(bid - pad, tiles_m - p.sel_total, tiles_n, p.group_m, 0, tmu, tn);   // the other row tiles, XCD slabs of the grouped order
+    for (int r = 0; r < p.sel_n; ++r)
+        if (tmu >= p.sel_tm_first[r]) tmu += p.sel_tm_count[r];                            // ranges ascending: step over every selected range at or below
+    tm = tmu;
+    return true;
+}
+inline int g_sel_keep_ragged_last = 0;
+inline int gemm_grid_size(const GemmArgs& p, int bm, int bn) {
+    const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + bn - 1) / bn;
+    if (p.sel_n > 0) return ((tiles_n + 7) >> 3) * 8 * p.sel_total + (tiles_m - p.sel_total) * tiles_n;
+    const int tiles = tiles_m * tiles_n;
+    return p.order == 1 ? (tiles + 255) / 256 * 256 : tiles;
+}
+// row ranges [begin, end) (host memory, ascending, disjoint) -> ranges of row tiles of height bm; more than 8 after merging: plain order
+inline void gemm_fill_sel(GemmArgs& a, const int* ranges, int n, int bm) {
+    a.sel_n = a.sel_total = 0;
+    if (!ranges || n <= 0 || !a.unit_sel) return;
+    const int tiles_m = (a.M + bm - 1) / bm;
+    const int full_tiles = g_sel_keep_ragged_last ? a.M / bm : tiles_m;     // A/B knob (lmi_set_option "gemm.sel_ragged_last"): a ragged last row tile stays last
+    int cnt = 0, first[8], count[8], prev_end = -1;
+    for (int i = 0; i < n; ++i) {
+        int b = ranges[2 * i], e = ranges[2 * i + 1];
+        if (b < 0) b = 0;
+        if (e > a.M) e = a.M;
+        if (e <= b) continue;
+        int t0 = b / bm, t1 = (e - 1) / bm + 1;
+        if (t1 > full_tiles) t1 = full_tiles;
+        if (t0 < prev_end) t0 = prev_end;                               // shares a tile with the previous range
+        if (t1 <= t0) continue;
+        if (cnt > 0 && t0 == prev_end) count[cnt - 1] += t1 - t0;
+        else {
+            if (cnt == 8) return;                                       // too many pieces: keep the plain order
+            first[cnt] = t0; count[cnt] = t1 - t0; ++cnt;
+        }
+        prev_end = t1;
+    }
+    int total = 0;
+    for (int i = 0; i < cnt; ++i) total += count[i];
+    if (total == 0 || total >= tiles_m) return;                         // nothing / everything selected: the plain order
+    a.sel_n = cnt; a.sel_total = total;
+    for (int i = 0; i < cnt; ++i) { a.sel_tm_first[i] = first[i]; a.sel_tm_count[i] = count[i]; }
+}
+
 // ---- epilogue shared by every geometry -------------------------------------------------------------------------
 // The accumulator layout gives a lane ONE output row and 4-column quads, so storing straight from it writes 8/16-byte
 // pieces into 32 different rows per instruction (measured: 1.8-2.8 TB/s on the output stream, a quarter of the SigLIP
@@ -451,10 +520,10 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     // kernel instantiation contracts `a*c - b*s` its own way and a row's bits would depend on the tile geometry
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o1[e] = OutCvt<T>::cvt(__builtin_fmaf(a0[e], cs0[e], -mul_rn(b0[e], sn0[e])));
-                        o1[4 + e] = OutCvt<T>::cvt(__builtin_fmaf(a1[e], cs1[e], -mul_rn(b1[e], sn1[e])));
-                        o2[e] = OutCvt<T>::cvt(__builtin_fmaf(b0[e], cs0[e], mul_rn(a0[e], sn0[e])));
-                        o2[4 + e] = OutCvt<T>::cvt(__builtin_fmaf(b1[e], cs1[e], mul_rn(a1[e], sn1[e])));
+                        o1[e] = OutCvt<T>::cvt(sep_rn(__builtin_fmaf(a0[e], cs0[e], -mul_rn(b0[e], sn0[e]))));
+                        o1[4 + e] = OutCvt<T>::cvt(sep_rn(__builtin_fmaf(a1[e], cs1[e], -mul_rn(b1[e], sn1[e]))));
+                        o2[e] = OutCvt<T>::cvt(sep_rn(__builtin_fmaf(b0[e], cs0[e], mul_rn(a0[e], sn0[e]))));
+                        o2[4 + e] = OutCvt<T>::cvt(sep_rn(__builtin_fmaf(b1[e], cs1[e], mul_rn(a1[e], sn1[e]))));
                     }
                 }
                 if (m < p.M) {
@@ -486,8 +555,8 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 const float os = (sizeof(T) == 1) ? p.out_scale : 1.0f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = OutCvt<T>::cvt(fast_silu(g0[e]) * u0[e] * os);
-                    o[4 + e] = OutCvt<T>::cvt(fast_silu(g1[e]) * u1[e] * os);
+                    o[e] = OutCvt<T>::cvt(sep_rn(fast_silu(g0[e]) * u0[e] * os));
+                    o[4 + e] = OutCvt<T>::cvt(sep_rn(fast_silu(g1[e]) * u1[e] * os));
                 }
                 if constexpr (OUT4 && sizeof(T) == 2) {
                     const bool sel = !p.row_sel || p.row_sel[m < p.M ? m : p.M - 1];
@@ -591,7 +660,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                 T8 o;
                 const float os = (sizeof(T) == 1) ? p.out_scale : 1.0f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = OutCvt<T>::cvt(v0[it][e] * os); o[4 + e] = OutCvt<T>::cvt(v1[it][e] * os); }
+                for (int e = 0; e < 4; ++e) { o[e] = OutCvt<T>::cvt(sep_rn(v0[it][e] * os)); o[4 + e] = OutCvt<T>::cvt(sep_rn(v1[it][e] * os)); }
                 st_epi<2>((T8*)((T*)p.out + orow[it] * p.ldo + nw0 + oc), o);
             } else {
                 float* drow = (float*)p.out + orow[it] * p.ldo + nw0 + oc;
@@ -601,7 +670,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     // the next RMSNorm, started here: gain applied and rounded; its row scale is finished by the consumer GEMM
                     T8 hn;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { hn[e] = OutCvt<T>::cvt(v0[it][e] * gam0[e]); hn[4 + e] = OutCvt<T>::cvt(v1[it][e] * gam1[e]); }
+                    for (int e = 0; e < 4; ++e) { hn[e] = OutCvt<T>::cvt(sep_rn(v0[it][e] * gam0[e])); hn[4 + e] = OutCvt<T>::cvt(sep_rn(v1[it][e] * gam1[e])); }
                     *(T8*)((T*)p.norm_out + orow[it] * p.ld_norm + nw0 + oc) = hn;
                     if ((lane & 7) == 0) p.rowsq_out[orow[it] * (long)(p.N >> 6) + (nw0 >> 6)] = sq;
                 }
@@ -733,7 +802,8 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = (p.N + C::BN - 1) / C::BN;
     int tm, tn;
-    if (!gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn)) return;
+    if (!(LO4 ? gemm_tile_coords_sel(p, (int)blockIdx.x, tiles_m, tiles_n, tm, tn)
+              : gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn))) return;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
     GemmStager<AMODE, C, ES> stager;
@@ -870,7 +940,8 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = (p.N + C::BN - 1) / C::BN;
     int tm, tn;
-    if (!gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn)) return;
+    if (!(LO4 ? gemm_tile_coords_sel(p, (int)blockIdx.x, tiles_m, tiles_n, tm, tn)
+              : gemm_tile_coords((int)blockIdx.x, tiles_m, tiles_n, p.group_m, p.order, tm, tn))) return;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
 
     GemmStager<AMODE, C, ES> stager;

@@ -238,6 +238,11 @@ LMI_DEV float fexp(float x) { return __expf(x); }
 // it into an FMA with a neighbouring operation (HIP's __fmul_rn is a plain `*` and does get contracted)
 LMI_DEV float mul_rn(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }
 LMI_DEV float sub_rn(float a, float b) { float r = a - b; asm volatile("" : "+v"(r)); return r; }
+// an fp32 result about to be rounded to a 16-bit type, made opaque first: hipcc otherwise fuses the producing multiply / fma with the conversion
+// into v_fma_mixlo_f16 (ONE rounding) in some instantiations of an epilogue and not in others (fp32 rounding, then the conversion: two) — a
+// row's 16-bit result then depends on WHICH kernel variant computed it, in one element out of ~3e5 (round 6: the unselected rows of a
+// row-selective lo4 launch against the fast kernel, RoPE outputs).  Not volatile: free to move, only not to fuse.
+LMI_DEV float sep_rn(float v) { asm("" : "+v"(v)); return v; }
 
 #define LMI_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
@@ -452,6 +457,7 @@ inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fexp(float x) { return expf(x); }
 inline float mul_rn(float a, float b) { return a * b; }
 inline float sub_rn(float a, float b) { return a - b; }
+inline float sep_rn(float v) { return v; }
 
 #define LMI_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipemu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
@@ -530,8 +536,9 @@ LMI_DEV unsigned lo4_encode8(const float (&y)[8], typename vec_of<T>::x8& hi, un
     float lo[8], amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        hi[e] = (T)y[e];
-        lo[e] = y[e] - (float)hi[e];
+        const float ye = sep_rn(y[e]);                               // the value is rounded on its own (see sep_rn), whatever produced it
+        hi[e] = (T)ye;
+        lo[e] = ye - (float)hi[e];
         amax = fmaxf(amax, __builtin_fabsf(lo[e]));
     }
     amax = quad_max(amax);

@@ -563,7 +563,8 @@ class LeopardEngine:
         return max(1, min(int(r), seq_len))
 
     def _lo4_selection(self, seq_lens: Sequence[int]):
-        """(row_sel uint8 [S], unit_sel uint8 [ceil(S / 64)]) device tensors for the packed rows of ``seq_lens``, or None when every row is selected."""
+        """(row_sel uint8 [S], unit_sel uint8 [ceil(S / 64)]) device tensors + the host [n, 2] int32 array of the selected row ranges (the
+        tile-order hint of lmi_lo4.sel_ranges) for the packed rows of ``seq_lens``, or None when every row is selected."""
         tails = [self.lo4_tail_rows(int(l)) for l in seq_lens]
         if all(t == int(l) for t, l in zip(tails, seq_lens)):
             return None
@@ -572,16 +573,21 @@ class LeopardEngine:
         if hit is None:
             S = int(sum(key[0]))
             row = np.zeros(S, dtype=np.uint8)
-            end = 0
+            end, ranges = 0, []
             for l, t in zip(*key):
                 end += l
                 row[end - t:end] = 1
+                if ranges and ranges[-1][1] == end - t:
+                    ranges[-1][1] = end
+                else:
+                    ranges.append([end - t, end])
             unit = np.zeros((S + 63) // 64 * 64, dtype=np.uint8)
             unit[:S] = row
             unit = unit.reshape(-1, 64).max(axis=1)
             if len(self._lo4_sel_cache) >= 64:
                 self._lo4_sel_cache.pop(next(iter(self._lo4_sel_cache)))
-            hit = self._lo4_sel_cache[key] = (self._pinned_to_device(torch.from_numpy(row)), self._pinned_to_device(torch.from_numpy(unit)))
+            hit = self._lo4_sel_cache[key] = (self._pinned_to_device(torch.from_numpy(row)), self._pinned_to_device(torch.from_numpy(unit)),
+                                              np.ascontiguousarray(np.array(ranges, dtype=np.int32).reshape(-1, 2)))
         return hit
 
     def _lo4_act(self, rows: int, width: int, heads: Optional[tuple] = None, sel: Optional[tuple] = None):

@@ -43,13 +43,14 @@ class Lo4Act:
     """One A operand of a GEMM with the low-bit correction phase (include/leopard_amd.h ``lmi_lo4``): ``hi`` = T(x) [M, K], ``img`` = the
     fp4 (e2m1) image of x - T(x) [M, K4 / 2] bytes, ``sc`` = its E8M0 block scales [M, K4 / 32].  The three are views into caller-owned
     scratch; the producers (lmi_norm_lo4, lmi_split_lo4, the GEMM epilogues) write all of them, padding included."""
-    __slots__ = ("hi", "img", "sc", "K", "K4", "buf", "row_sel", "unit_sel")
+    __slots__ = ("hi", "img", "sc", "K", "K4", "buf", "row_sel", "unit_sel", "sel_ranges")
 
     def __init__(self, hi: torch.Tensor, img: torch.Tensor, sc: torch.Tensor):
         self.hi, self.img, self.sc, self.buf = hi, img, sc, None
         # row selection of the correction phase (lmi_lo4.row_sel / unit_sel; LeopardEngine.lo4_rows): uint8 [M] / [ceil(M / 64)] device tensors, or
         # None = every row.  With a selection the image and scales MUST start out zero (Lo4Act.empty(..., zero=True)): producers skip unselected rows
-        self.row_sel = self.unit_sel = None
+        # sel_ranges: optional HOST int32 numpy array [n, 2] of the selected [begin, end) row ranges (lmi_lo4.sel_ranges: a tile-order hint)
+        self.row_sel = self.unit_sel = self.sel_ranges = None
         self.K = hi.shape[1]
         self.K4 = img.shape[1] * 2          # lo4_k4(K), or wider when the image carries a padded k order (attention outputs, head_dim 72 / 96)
         assert img.dtype == torch.uint8 and sc.dtype == torch.uint8 and self.K4 % 256 == 0 and self.K4 >= self.K and sc.shape[0] == hi.shape[0] == img.shape[0]
@@ -64,7 +65,8 @@ class Lo4Act:
         act = Lo4Act(torch.empty(M, K, dtype=dtype, device=device), alloc(M, k4 // 2, dtype=torch.uint8, device=device),
                      alloc(M, k4 // 32, dtype=torch.uint8, device=device))
         if sel is not None:
-            act.row_sel, act.unit_sel = sel
+            act.row_sel, act.unit_sel = sel[0], sel[1]
+            act.sel_ranges = sel[2] if len(sel) > 2 else None
             assert act.row_sel.dtype == torch.uint8 and act.row_sel.numel() == M and act.unit_sel.numel() == (M + 63) // 64
         return act
 
@@ -428,6 +430,9 @@ class Ops:
         if sel is not None and sel.row_sel is not None:
             assert out4 is None or a is None or out4.row_sel is None or out4.row_sel.data_ptr() == a.row_sel.data_ptr()
             d.row_sel, d.unit_sel = sel.row_sel.data_ptr(), sel.unit_sel.data_ptr()
+            if sel.sel_ranges is not None and len(sel.sel_ranges):
+                d._keep = sel.sel_ranges                              # host array, read during the call
+                d.sel_ranges, d.n_sel_ranges = sel.sel_ranges.ctypes.data, len(sel.sel_ranges)
         return d
 
     def quantize_w4(self, w: torch.Tensor, head_pad: Optional[tuple] = None) -> Lo4Weight:

@@ -371,17 +371,24 @@ def test_attention_lo4_image_is_the_oracle_rule_in_the_padded_head_order(ops, hd
 
 
 # ---- row selection of the correction phase (round 6: GemmArgs::row_sel / unit_sel, LeopardEngine.lo4_rows) ----------------------------------
+def _ranges(row):
+    """[begin, end) runs of the selected rows: the host-side tile-order hint (lmi_lo4.sel_ranges)."""
+    import numpy as np
+    r = np.flatnonzero(np.diff(np.concatenate([[0], row.numpy().astype(np.int8), [0]])))
+    return np.ascontiguousarray(r.reshape(-1, 2).astype(np.int32))
+
+
 def _selection(M, rows):
     row = torch.zeros(M, dtype=torch.uint8)
     row[list(rows)] = 1
     unit = torch.zeros((M + 63) // 64 * 64, dtype=torch.uint8)
     unit[:M] = row
-    return row, unit.view(-1, 64).max(dim=1).values.contiguous()
+    return row, unit.view(-1, 64).max(dim=1).values.contiguous(), _ranges(row)
 
 
 def _select(act: Lo4Act, sel):
     """The contract of a selected pass: unselected rows carry all-zero images."""
-    act.row_sel, act.unit_sel = sel
+    act.row_sel, act.unit_sel, act.sel_ranges = sel
     keep = sel[0].bool()
     act.img[~keep] = 0
     act.sc[~keep] = 0
@@ -516,8 +523,8 @@ def test_engine_lo4_rows_policy_and_packed_equals_separate():
     assert eng.lo4_rows == "auto" and eng.lo4_tail_rows(228) == 228 and eng.lo4_tail_rows(7187) == eng.LO4_TAIL_ROWS
     assert eng._lo4_selection([228, 100]) is None                     # every row of every (short) sequence: no tables
     eng.lo4_rows = 3
-    row, unit = eng._lo4_selection([70, 9])
-    assert row.tolist() == [0] * 67 + [1] * 3 + [0] * 6 + [1] * 3 and unit.tolist() == [0, 1]
+    row, unit, ranges = eng._lo4_selection([70, 9])
+    assert row.tolist() == [0] * 67 + [1] * 3 + [0] * 6 + [1] * 3 and unit.tolist() == [0, 1] and ranges.tolist() == [[67, 70], [76, 79]]
     tiles = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8))
     ids_a = torch.tensor([[5, 250, 9, 250, 17, 33, 101, 7, 3, 11, 200, 90]])
     ids_b = torch.tensor([[5, 250, 9, 17, 33]])

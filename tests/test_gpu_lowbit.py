@@ -339,16 +339,23 @@ def test_attention_lo4_at_the_production_shapes(ops, name, lens, H, KV, hd, caus
 
 
 # ---- row selection of the correction phase (round 6: GemmArgs::row_sel / unit_sel, LeopardEngine.lo4_rows) ----------------------------------
+def _ranges(row):
+    """[begin, end) runs of the selected rows: the host-side tile-order hint (lmi_lo4.sel_ranges)."""
+    import numpy as np
+    r = np.flatnonzero(np.diff(np.concatenate([[0], row.numpy().astype(np.int8), [0]])))
+    return np.ascontiguousarray(r.reshape(-1, 2).astype(np.int32))
+
+
 def _selection(M, rows):
     row = torch.zeros(M, dtype=torch.uint8)
     row[list(rows)] = 1
     unit = torch.zeros((M + 63) // 64 * 64, dtype=torch.uint8)
     unit[:M] = row
-    return row.to(DEV), unit.view(-1, 64).max(dim=1).values.contiguous().to(DEV)
+    return row.to(DEV), unit.view(-1, 64).max(dim=1).values.contiguous().to(DEV), _ranges(row)
 
 
 def _select(act, sel):
-    act.row_sel, act.unit_sel = sel
+    act.row_sel, act.unit_sel, act.sel_ranges = sel
     keep = sel[0].bool()
     act.img[~keep] = 0
     act.sc[~keep] = 0
