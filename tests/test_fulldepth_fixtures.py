@@ -43,3 +43,23 @@ def test_fixture_integrity_and_first_trace_point(case):
     x = O.siglip_embeddings(torch.from_numpy(siglip_normalize(fx.u8[tiles])), W, cfg)
     want = torch.stack([x[tiles.index(t), r] for t, r in probe_rows("vit.embed", (n_vit, 676, 1152))])
     assert torch.allclose(want, fx.probe["vit.embed"], rtol=0, atol=2e-6)
+
+
+def test_idefics2_c4_fixture_integrity():
+    """tests/golden/c4_idefics2_full_depth.npz (tools/gen_idefics2_fixture.py; round 6): the inputs regenerate from their seeds to the fixture's ids /
+    SHA-256, the stored logits are complete and finite and the emulated 16-bit budget sits where DESIGN.md 2.1 says (1.3 - 1.5e-3 of the logit scale)."""
+    import hashlib
+    from leopard_amd.config import idefics2_full_config
+    from leopard_amd.idefics2 import preprocess_image_u8
+    from tools.parity_report import idefics2_c4_sample
+    cfg = idefics2_full_config()
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c4_idefics2_full_depth.npz"))
+    ims, ids = idefics2_c4_sample(cfg)
+    u8 = [preprocess_image_u8(im, cfg.longest_edge) for im in ims]
+    assert list(z["meta"]) == [4, 1344, 896, 312] and np.array_equal(z["ids"], ids.numpy())
+    assert hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in u8)).digest() == z["images_sha256"].tobytes()
+    ref, emu = torch.from_numpy(z["logits_fp32"]), torch.from_numpy(z["logits_emu_fp16"])
+    assert ref.shape == emu.shape == (cfg.text_config.vocab_size,) and torch.isfinite(ref).all() and torch.isfinite(emu).all()
+    d = float((emu - ref).abs().max() / ref.abs().max())
+    assert 8e-4 < d < 2.5e-3 and int(emu.argmax()) == int(ref.argmax())
+    assert z["feature_probe"].shape == (len(z["feature_probe_rows"]), cfg.text_config.hidden_size) and float(z["feature_max_abs"][0]) > 0

@@ -2,6 +2,8 @@
 layers at reduced depth, two images of different sizes (one is the BASELINE C4 image shape 1344x896 -> 980x653 ->
 3220 patches); plus new-kernel-feature checks at production shapes (sliding window, head_dim 96 cross attention)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -106,17 +108,23 @@ def test_idefics2_full_depth_c4_vs_oracle(ops):
         assert torch.equal(eng.prefill(ids, u8).logits_last, first4), f"lo4 prefill repetition {rep} differs"
     del eng, W
     torch.cuda.empty_cache()
-    Wt = {name: src.get(name).float().cpu() for name in src.specs}
-    pix = [IO.image_processor(im, cfg.longest_edge) for im in ims]
-    ref, parts = IO.prefill_logits(ids, pix, Wt, cfg, last_only=True, return_parts=True)
-    ref = ref[0, 0]
-    with O.emulate_rounding(dtype):
-        emu = IO.prefill_logits(ids, pix, Wt, cfg, last_only=True)[0, 0]
+    # the fp32 oracle's logits and the rounding-emulating oracle's come from the COMMITTED fixture (tools/gen_idefics2_fixture.py, round 6: 2 x 23 TFLOP
+    # of host arithmetic no longer recomputed on the GPU box at every run); the inputs are regenerated from their seeds and hash-checked against it
+    import hashlib
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c4_idefics2_full_depth.npz"))
+    assert np.array_equal(z["ids"], ids.numpy()), "C4 prompt synthesiser drifted from the fixture"
+    assert hashlib.sha256(b"".join(np.ascontiguousarray(a.numpy()).tobytes() for a in u8)).digest() == z["images_sha256"].tobytes(), "C4 images drifted from the fixture"
+    ref, emu = torch.from_numpy(z["logits_fp32"]), torch.from_numpy(z["logits_emu_fp16"])
+    rows = z["feature_probe_rows"].tolist()
+    feats = feats.reshape(-1, feats.shape[-1])[rows]
+    parts = {"image_features": torch.from_numpy(z["feature_probe"])}
+    feat_scale = float(z["feature_max_abs"][0])
     scale = ref.abs().max().item()
     err = (got - ref).abs().max().item() / scale
     pred = (emu - ref).abs().max().item() / scale
-    ferr = (feats - parts["image_features"]).abs().max().item() / parts["image_features"].abs().max().item()
-    print(f"[idefics2 C4 full depth fp16] logits {err:.3e} (predicted {pred:.3e}), image features {ferr:.3e}")
+    ferr = (feats - parts["image_features"]).abs().max().item() / feat_scale
+    print(f"[idefics2 C4 full depth fp16] logits {err:.3e} (predicted {pred:.3e}), image features (probe rows) {ferr:.3e}")
     assert err <= C4_FULL_TOL["logits"] and ferr <= C4_FULL_TOL["features"]
     assert 0.7 * pred <= err <= 1.4 * pred
     assert int(got.argmax()) == int(ref.argmax())
