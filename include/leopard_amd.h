@@ -415,6 +415,29 @@ int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, 
                         int ldo, int packed, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_all, const float* sin_all,
                         void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream);
 
+/* Decode precision mode (round 6; LeopardEngine.precision = "lo4" / "split" also covers the decode branch, EVAL:291-320): every operand of a
+ * decode-step projection is handed over as a PAIR of 16-bit rows — T(x) and T(x - T(x)), rows m and m + M of a [2 M, K] buffer (2 M <= 16) —
+ * and both products land in the same fp32 sums: the operand is seen to ~22 bits at no extra weight traffic (the step is bound by the weight
+ * stream; the lo rows are two of the <= 16 batch rows).  The _hl entry points take X with 2 M rows and write every 16-bit output that is itself a
+ * projection operand (STORE / SWIGLU results, the producer's norm_out) as such a pair again (out / norm_out need 2 M rows); q | k | v rows and the
+ * fp32 stream are single.  lmi_split_rows_hl: fp32 [M, K] -> T [2 M, K] (hi rows, then lo rows); lmi_attn_decode_*_hl: the attention output rows
+ * as pairs (out [2 q_rows, ldo]). */
+int lmi_gemm_skinny_hl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed,
+                       const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, int ld_norm, const float* norm_gamma,
+                       float* rowsq_out, int dtype, void* stream);
+int lmi_rope_qkv_skinny_hl(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
+                           int ldo, int packed, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_all, const float* sin_all,
+                           void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream);
+int lmi_split_rows_hl(const float* x, void* out, int M, int K, int ldx, int ldo, int dtype, void* stream);
+int lmi_attn_decode_fwd_hl(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
+                           int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                           int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                           int dtype, void* stream);
+int lmi_attn_decode_pool_hl(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* k_begin, const int* k_len,
+                            int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                            int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                            int dtype, void* stream);
+
 /* Same with the RMSNorm of the decode step folded in: x is the fp32 residual row [K], norm_weight fp32 [K], and the row
  * fed to the product is T(norm_weight * (x * rsqrt(mean(x^2) + eps))) — the arithmetic of lmi_rmsnorm, without its launch.
  * K = 4096 (the hidden size of Llama-3.1-8B / Mistral-7B). */

@@ -75,6 +75,11 @@ SIGNATURES = {
     "lmi_attn_varlen_fwd_f32": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "lmi_rope_qkv_skinny": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P, _P, _P, _I, C.c_int64, _P, _I, _P],
     "lmi_gemm_skinny_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _I, _P, _P, _I, _P],
+    "lmi_gemm_skinny_hl": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _I, _P, _P, _I, _P],
+    "lmi_rope_qkv_skinny_hl": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P, _P, _P, _I, C.c_int64, _P, _I, _P],
+    "lmi_split_rows_hl": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "lmi_attn_decode_fwd_hl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, C.c_int64, _I, _P],
+    "lmi_attn_decode_pool_hl": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, C.c_int64, _I, _P],
     "lmi_debug_copy": [_P, _P, C.c_int64, _I, _P],
     "lmi_gemm_skinny": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lmi_decode_advance": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],

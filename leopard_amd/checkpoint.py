@@ -27,6 +27,11 @@ from .synth import param_specs
 class CheckpointSource:
     def __init__(self, path: str, device, dtype):
         self.path, self.device, self.dtype = path, device, dtype
+        # what the cast of the matrices to the 16-bit compute type cost (round 6): the released Leopard checkpoints are
+        # bf16-trained (train_multiimg_llava_siglip.sh:64), and a bf16 value is exact in fp16 down to |w| = 2^-17 (fp16 subnormals keep 8
+        # significant bits that far) — below that it loses bits, below 2^-25 it flushes to zero.  An fp32-VALUED checkpoint is rounded
+        # (relative 2^-12 per weight), which no precision mode corrects: the loader counts both cases so that the caller can say so.
+        self.cast_stats = {"matrices": 0, "inexact_matrices": 0, "inexact_elements": 0, "flushed_to_zero": 0, "max_abs_error": 0.0, "elements": 0}
         self._where: Dict[str, str] = {}
         self._bin_cache: Dict[str, dict] = {}
         st = sorted(glob.glob(os.path.join(path, "*.safetensors")))
@@ -59,10 +64,31 @@ class CheckpointSource:
             from safetensors import safe_open
             with safe_open(f, framework="pt") as h:
                 t = h.get_tensor(name)
+        src = t
         t = t.to(device=self.device, dtype=self.dtype if t.dim() >= 2 else torch.float32)
+        if src.dim() >= 2 and src.dtype != t.dtype:
+            back = src.to(self.device, torch.float32) - t.to(torch.float32)
+            bad = back != 0
+            st = self.cast_stats
+            st["matrices"] += 1
+            st["elements"] += src.numel()
+            n_bad = int(bad.sum())
+            if n_bad:
+                st["inexact_matrices"] += 1
+                st["inexact_elements"] += n_bad
+                st["flushed_to_zero"] += int(((t == 0) & bad).sum())
+                st["max_abs_error"] = max(st["max_abs_error"], float(back.abs().max()))
         if t.data_ptr() % 16:                      # views into a memory-mapped file can sit at any 4-byte offset
             t = t.clone()
         return t
+
+    def cast_report(self) -> str:
+        st = self.cast_stats
+        if not st["inexact_elements"]:
+            return f"{st['matrices']} matrices cast to {str(self.dtype).replace('torch.', '')} exactly"
+        return (f"{st['inexact_elements']} of {st['elements']} matrix elements ({st['inexact_matrices']} of {st['matrices']} matrices) are NOT exactly "
+                f"representable in {str(self.dtype).replace('torch.', '')}: max |error| {st['max_abs_error']:.3e}, {st['flushed_to_zero']} flushed to zero — "
+                "the weight cast is a rounding that no precision mode corrects")
 
 
 def load_config(path: str) -> LeopardConfig:

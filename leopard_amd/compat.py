@@ -85,8 +85,13 @@ class LeopardForConditionalGeneration:
         device = torch.device(device)
         if self._engine is None or device != self.device:
             ops = self._ops if self._ops is not None else Ops()
-            W = EngineWeights.build(self.config, self._source_factory(device, self.compute_dtype), self.compute_dtype, tp_rank=self.tp_rank,
-                                    tp_size=self.tp_size)
+            source = self._source_factory(device, self.compute_dtype)
+            W = EngineWeights.build(self.config, source, self.compute_dtype, tp_rank=self.tp_rank, tp_size=self.tp_size)
+            stats = getattr(source, "cast_stats", None)              # checkpoint.CheckpointSource: what the cast to the compute type cost
+            self.weight_cast_stats = dict(stats) if stats else None
+            if stats and stats["inexact_elements"] > 0.05 * max(stats["elements"], 1):     # (a bf16-trained checkpoint: only its few values below 2^-17)
+                import warnings
+                warnings.warn("leopard_amd: " + source.cast_report(), UserWarning, stacklevel=2)
             self._engine = LeopardEngine(self.config, W, ops=ops, device=device)
             if self.precision == "lo4" and not self._engine.lo4_supported():
                 # a model shape the lo4 schedule does not cover: the 2 K mode meets the same figure on one rank; tensor-parallel engines only

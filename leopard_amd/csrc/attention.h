@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_dma_kernel(AttnArgs p
 // result does not depend on timing.
 template <typename T, int D>
 __global__ void __launch_bounds__(256) attn_combine_kernel(const float* part_o, const float* part_ml, T* out, const int* cu_q,
-                                                           int n_seq, int n_heads, int n_splits, int part_rows, int ldo, float scale) {
+                                                           int n_seq, int n_heads, int n_splits, int part_rows, int ldo, float scale, int lo_rows) {
     static_assert(D == 128, "attn_combine_kernel: one float2 per lane");
     __shared__ float wl[64], red[4][D + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -726,7 +726,11 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* part_o, 
     if (threadIdx.x < D) {
         const int d = threadIdx.x;
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-        out[(long)row * ldo + head * D + d] = (T)(((red[0][d] + red[1][d]) + (red[2][d] + red[3][d])) * inv);
+        const float y = sep_rn(((red[0][d] + red[1][d]) + (red[2][d] + red[3][d])) * inv);
+        const T hi = (T)y;
+        out[(long)row * ldo + head * D + d] = hi;
+        // decode precision mode (skinny.h "hl"): the residual of the rounding as a 16-bit row of its own, lo_rows rows further down
+        if (lo_rows > 0) out[(long)(row + lo_rows) * ldo + head * D + d] = (T)(y - (float)hi);
     }
 }
 

@@ -524,7 +524,7 @@ static int decode_grid_heads(int n_heads, int n_kv_heads, int max_q) {
 }
 
 template <typename T>
-int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, int ldo, void* stream) {
+int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, int ldo, void* stream, int lo_rows = 0) {
     static std::atomic<uint64_t> attr_done{0};
     static std::atomic<uint64_t> attr_done_s{0};
     allow_big_lds(attn_fwd_dma_kernel<T, 128, true>, 160 * 1024, attr_done);
@@ -538,7 +538,7 @@ int attn_decode_impl(AttnArgs a, int n_seq, int max_q, int q_rows, void* out, in
     else LMI_LAUNCH((attn_fwd_dma_kernel<T, 128, true>), grid, dim3(ATT_THREADS), AttnDmaGeom<128>::SMEM, stream, a);
     const long items = (long)q_rows * a.n_heads;
     LMI_LAUNCH((attn_combine_kernel<T, 128>), dim3((unsigned)items), dim3(256), 0, stream, (const float*)a.part_o,
-               (const float*)a.part_ml, (T*)out, a.cu_q, n_seq, a.n_heads, a.n_splits, a.part_rows, ldo, a.scale);
+               (const float*)a.part_ml, (T*)out, a.cu_q, n_seq, a.n_heads, a.n_splits, a.part_rows, ldo, a.scale, lo_rows);
     return check_launch("lmi_attn_decode_fwd");
 }
 
@@ -1226,10 +1226,21 @@ int lmi_split_hi_lo(const float* x, void* out, int M, int K, int ldx, int ldo, i
         return fail(LMI_EINVAL, "lmi_split_hi_lo: bad argument (M=%d K=%d ldx=%d ldo=%d; K %% 8 == 0, ldo >= 2K)", M, K, ldx, ldo);
     if (M == 0) return LMI_OK;
     const int grid = grid_for((long)M * (K >> 3), 256);
-    if (dtype == LMI_F16) LMI_LAUNCH((split_hi_lo_kernel<f16_t>), dim3(grid), dim3(256), 0, stream, x, (f16_t*)out, M, K, ldx, ldo);
-    else if (dtype == LMI_BF16) LMI_LAUNCH((split_hi_lo_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, x, (bf16_t*)out, M, K, ldx, ldo);
+    if (dtype == LMI_F16) LMI_LAUNCH((split_hi_lo_kernel<f16_t>), dim3(grid), dim3(256), 0, stream, x, (f16_t*)out, M, K, ldx, ldo, (long)K);
+    else if (dtype == LMI_BF16) LMI_LAUNCH((split_hi_lo_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, x, (bf16_t*)out, M, K, ldx, ldo, (long)K);
     else return fail(LMI_EINVAL, "lmi_split_hi_lo: dtype must be LMI_F16 or LMI_BF16");
     return check_launch("lmi_split_hi_lo");
+}
+
+int lmi_split_rows_hl(const float* x, void* out, int M, int K, int ldx, int ldo, int dtype, void* stream) {
+    if (!x || !out || M < 0 || K <= 0 || (K & 7) || (ldx & 3) || (ldo & 7) || ldo < K || !aligned16(x) || !aligned16(out))
+        return fail(LMI_EINVAL, "lmi_split_rows_hl: bad argument (M=%d K=%d ldx=%d ldo=%d; K %% 8 == 0, ldo >= K)", M, K, ldx, ldo);
+    if (M == 0) return LMI_OK;
+    const int grid = grid_for((long)M * (K >> 3), 256);
+    if (dtype == LMI_F16) LMI_LAUNCH((split_hi_lo_kernel<f16_t>), dim3(grid), dim3(256), 0, stream, x, (f16_t*)out, M, K, ldx, ldo, (long)M * ldo);
+    else if (dtype == LMI_BF16) LMI_LAUNCH((split_hi_lo_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, x, (bf16_t*)out, M, K, ldx, ldo, (long)M * ldo);
+    else return fail(LMI_EINVAL, "lmi_split_rows_hl: dtype must be LMI_F16 or LMI_BF16");
+    return check_launch("lmi_split_rows_hl");
 }
 
 // ---- caller-owned scratch of a prefill pass ("workspace: size from lmi_*_workspace_bytes"; the library allocates nothing) ----------
@@ -1281,7 +1292,7 @@ int64_t lmi_attn_decode_workspace_bytes(int q_rows, int n_heads, int head_dim, i
 static int attn_decode_entry(const char* who, const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
                              const int* k_len, int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
                              int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
-                             int dtype, void* stream) {
+                             int dtype, void* stream, int hl = 0) {
     if (!q || !k || !v || !out || !cu_seqlens_q || !cu_seqlens_k || !workspace) return fail(LMI_EINVAL, "%s: null pointer", who);
     if (n_seq < 0 || max_seqlen_q < 0 || max_seqlen_k < 0 || q_rows < 0 || n_heads <= 0 || n_kv_heads <= 0 || (n_heads % n_kv_heads))
         return fail(LMI_EINVAL, "%s: bad sizes", who);
@@ -1305,8 +1316,8 @@ static int attn_decode_entry(const char* who, const void* q, const void* k, cons
     a.part_rows = q_rows;
     a.part_o = (float*)workspace;
     a.part_ml = a.part_o + (size_t)a.n_splits * q_rows * n_heads * head_dim;
-    LMI_DISPATCH_T(dtype, (attn_decode_impl<f16_t>(a, n_seq, max_seqlen_q, q_rows, out, ldo, stream)),
-                   (attn_decode_impl<bf16_t>(a, n_seq, max_seqlen_q, q_rows, out, ldo, stream)));
+    LMI_DISPATCH_T(dtype, (attn_decode_impl<f16_t>(a, n_seq, max_seqlen_q, q_rows, out, ldo, stream, hl ? q_rows : 0)),
+                   (attn_decode_impl<bf16_t>(a, n_seq, max_seqlen_q, q_rows, out, ldo, stream, hl ? q_rows : 0)));
 }
 
 int lmi_attn_decode_fwd(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
@@ -1326,10 +1337,11 @@ int lmi_attn_decode_pool(const void* q, const void* k, const void* v, void* out,
                              n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, window, workspace, workspace_bytes, dtype, stream);
 }
 
-int lmi_gemm_skinny_ex(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed,
-                       const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, int ld_norm, const float* norm_gamma,
-                       float* rowsq_out, int dtype, void* stream) {
+static int gemm_skinny_entry(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed,
+                             const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, int ld_norm, const float* norm_gamma,
+                             float* rowsq_out, int dtype, void* stream, int hl) {
     if (!W || !X || !out) return fail(LMI_EINVAL, "lmi_gemm_skinny: null pointer");
+    if (hl && 2 * M > 16) return fail(LMI_EINVAL, "lmi_gemm_skinny_hl: the hi + lo row pairs need 2 M <= 16 (M = %d)", M);
     if (M < 0 || M > 16 || N <= 0 || K <= 0 || (K % 128) || epilogue < LMI_SKINNY_STORE || epilogue > LMI_SKINNY_STORE_F32 ||
         (N % (epilogue == LMI_SKINNY_SWIGLU ? 64 : 16)))
         return fail(LMI_EINVAL, "lmi_gemm_skinny: need M <= 16, K %% 128 == 0, N %% 16 == 0 (SwiGLU: N %% 64 == 0) (M=%d N=%d K=%d)", M, N, K);
@@ -1342,6 +1354,7 @@ int lmi_gemm_skinny_ex(const void* W, const void* X, void* out, int M, int N, in
     SkinnyNorm nm;
     if (int rc = skinny_norm_args("lmi_gemm_skinny_ex", nm, M, N, epilogue, rowsq_in, rowsq_parts, norm_dim, norm_eps, norm_out, ld_norm, norm_gamma, rowsq_out))
         return rc;
+    nm.hl = hl ? 1 : 0;
     if (M == 0) return LMI_OK;
     if (packed)
         LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, 1>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)),
@@ -1353,14 +1366,46 @@ int lmi_gemm_skinny_ex(const void* W, const void* X, void* out, int M, int N, in
                    (skinny_impl<bf16_t, 0>(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, stream, RopeEpi(), nm)));
 }
 
+int lmi_attn_decode_fwd_hl(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* cu_seqlens_k,
+                           int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                           int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                           int dtype, void* stream) {
+    return attn_decode_entry("lmi_attn_decode_fwd_hl", q, k, v, out, cu_seqlens_q, cu_seqlens_k, nullptr, n_seq, max_seqlen_q, max_seqlen_k, q_rows,
+                             n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, window, workspace, workspace_bytes, dtype, stream, 1);
+}
+
+int lmi_attn_decode_pool_hl(const void* q, const void* k, const void* v, void* out, const int* cu_seqlens_q, const int* k_begin, const int* k_len,
+                            int n_seq, int max_seqlen_q, int max_seqlen_k, int q_rows, int n_heads, int n_kv_heads, int head_dim,
+                            int ldq, int ldk, int ldv, int ldo, float scale, int window, void* workspace, int64_t workspace_bytes,
+                            int dtype, void* stream) {
+    if (!k_len) return fail(LMI_EINVAL, "lmi_attn_decode_pool_hl: null k_len");
+    return attn_decode_entry("lmi_attn_decode_pool_hl", q, k, v, out, cu_seqlens_q, k_begin, k_len, n_seq, max_seqlen_q, max_seqlen_k, q_rows,
+                             n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, window, workspace, workspace_bytes, dtype, stream, 1);
+}
+
+int lmi_gemm_skinny_ex(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed,
+                       const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, int ld_norm, const float* norm_gamma,
+                       float* rowsq_out, int dtype, void* stream) {
+    return gemm_skinny_entry(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, packed, rowsq_in, rowsq_parts, norm_dim, norm_eps, norm_out, ld_norm, norm_gamma,
+                             rowsq_out, dtype, stream, 0);
+}
+
+int lmi_gemm_skinny_hl(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed,
+                       const float* rowsq_in, int rowsq_parts, int norm_dim, float norm_eps, void* norm_out, int ld_norm, const float* norm_gamma,
+                       float* rowsq_out, int dtype, void* stream) {
+    return gemm_skinny_entry(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, packed, rowsq_in, rowsq_parts, norm_dim, norm_eps, norm_out, ld_norm, norm_gamma,
+                             rowsq_out, dtype, stream, 1);
+}
+
 int lmi_gemm_skinny(const void* W, const void* X, void* out, int M, int N, int K, int ldw, int ldx, int ldo, int epilogue, int packed, int dtype,
                     void* stream) {
     return lmi_gemm_skinny_ex(W, X, out, M, N, K, ldw, ldx, ldo, epilogue, packed, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, nullptr, dtype, stream);
 }
 
-int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
-                        int ldo, int packed, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_all, const float* sin_all,
-                        void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream) {
+static int rope_qkv_skinny_entry(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
+                                 int ldo, int packed, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_all, const float* sin_all,
+                                 void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream, int hl) {
+    if (hl && 2 * M > 16) return fail(LMI_EINVAL, "lmi_rope_qkv_skinny_hl: the hi + lo row pairs need 2 M <= 16 (M = %d)", M);
     if (!Wqkv_rope || !X || !qkv || !cos_all || !sin_all || !k_cache || !v_cache || !pos_rows_dev) return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: null pointer");
     if (head_dim != 128) return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: head_dim %d (only 128)", head_dim);
     const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
@@ -1369,6 +1414,7 @@ int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, 
         return fail(LMI_EINVAL, "lmi_rope_qkv_skinny: bad argument (M <= 16, K %% 128 == 0, 16-byte aligned rows)");
     SkinnyNorm nm;
     if (int rc = skinny_norm_args("lmi_rope_qkv_skinny", nm, M, N, 4, rowsq_in, rowsq_parts, K, norm_eps, nullptr, 0, nullptr, nullptr)) return rc;
+    nm.hl = hl ? 1 : 0;
     if (M == 0) return LMI_OK;
     RopeEpi rp;
     rp.cos_all = cos_all; rp.sin_all = sin_all; rp.pos = pos_rows_dev; rp.k_cache = k_cache; rp.v_cache = v_cache; rp.ld_cache = ld_cache;
@@ -1381,6 +1427,20 @@ int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, 
                        (skinny_impl<bf16_t, 2>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
     LMI_DISPATCH_T(dtype, (skinny_impl<f16_t, 0>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)),
                    (skinny_impl<bf16_t, 0>(Wqkv_rope, X, qkv, M, N, K, ldw, ldx, ldo, 4, stream, rp, nm)));
+}
+
+int lmi_rope_qkv_skinny(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
+                        int ldo, int packed, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_all, const float* sin_all,
+                        void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream) {
+    return rope_qkv_skinny_entry(Wqkv_rope, X, qkv, M, n_q_heads, n_kv_heads, head_dim, K, ldw, ldx, ldo, packed, rowsq_in, rowsq_parts, norm_eps, cos_all,
+                                 sin_all, k_cache, v_cache, ld_cache, cache_stride, pos_rows_dev, dtype, stream, 0);
+}
+
+int lmi_rope_qkv_skinny_hl(const void* Wqkv_rope, const void* X, void* qkv, int M, int n_q_heads, int n_kv_heads, int head_dim, int K, int ldw, int ldx,
+                           int ldo, int packed, const float* rowsq_in, int rowsq_parts, float norm_eps, const float* cos_all, const float* sin_all,
+                           void* k_cache, void* v_cache, int ld_cache, int64_t cache_stride, const int* pos_rows_dev, int dtype, void* stream) {
+    return rope_qkv_skinny_entry(Wqkv_rope, X, qkv, M, n_q_heads, n_kv_heads, head_dim, K, ldw, ldx, ldo, packed, rowsq_in, rowsq_parts, norm_eps, cos_all,
+                                 sin_all, k_cache, v_cache, ld_cache, cache_stride, pos_rows_dev, dtype, stream, 1);
 }
 
 int lmi_rope_qk_rows(void* qkv, int S, int ld, int n_q_heads, int n_kv_heads, int head_dim, const float* cos_all, const float* sin_all,

@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(256) gemv_split_kernel(const T* W, const void*
 // HBM-bound: 4 B in, 4 B out per element.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) split_hi_lo_kernel(const float* x, T* out, int M, int K, int ldx, int ldo) {
+__global__ void __launch_bounds__(256) split_hi_lo_kernel(const float* x, T* out, int M, int K, int ldx, int ldo, long lo_off) {
     typedef typename vec_of<T>::x8 T8;
     const int cpr = K >> 3;
     const long total = (long)M * cpr;
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(256) split_hi_lo_kernel(const float* x, T* out
         }
         T* o = out + (long)m * ldo + c * 8;
         *(T8*)o = hi;
-        *(T8*)(o + K) = lo;
+        *(T8*)(o + lo_off) = lo;                                      // K: [hi | lo] columns (lmi_split_hi_lo); M * ldo: lo rows below the hi rows (lmi_split_rows_hl)
     }
 }
 

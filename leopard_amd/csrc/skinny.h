@@ -40,7 +40,13 @@ enum { SK_STORE_T = 0, SK_RESID_F32 = 1, SK_SWIGLU_T = 2, SK_STORE_F32 = 3, SK_Q
 //       partial per workgroup and row, written once: no atomics, bit-reproducible);
 //   consumer (any epilogue, rowsq_in != null): accumulator row m is multiplied by rstd[m] = rsqrt(sum_j rowsq_in[m, j] / norm_dim + eps)
 //       before RoPE / SwiGLU / store; the partials are summed in a fixed order (32 lanes per row: strided partial sums, then a butterfly).
+// hl (round 6: the decode step's precision mode, engine.precision = "lo4" / "split"): X holds 2 M rows — rows [0, M) = T(x), rows [M, 2 M) =
+// T(x - T(x)), the 16-bit image of the hand-over rounding's residual (2 M <= 16) — and both products land in the same sums, so the
+// projection sees the operand to ~22 bits at NO extra weight traffic (the kernel is bound by the weight stream; the lo rows are two of
+// its <= 16 batch rows).  Every 16-bit output that is itself a projection operand (SwiGLU / STORE results, the producer's T(x gamma)) is
+// written as such a pair again: row m and row m + M.
 struct SkinnyNorm {
+    int hl;                   // 0 = plain; 1 = X is [hi rows | lo rows] (2 M rows) and 16-bit operand outputs are written as pairs
     const float* rowsq_in;    // [M, parts_in] or null
     int parts_in;
     float inv_dim, eps;
@@ -80,7 +86,8 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
                          : W + (long)(row0 + 32 * b + i) * ldw + 8 * g;
     const int src_lane = 4 * i + g;                                // COAL: MFMA lane (i, g) = 16 g + i takes what lane 4 i + g loaded
     const T* xrow = X + (long)i * ldx + 8 * g;
-    const bool has_x = i < M;
+    const int MX = nm.hl ? 2 * M : M;                              // batch rows in X
+    const bool has_x = i < MX;
     const int nsteps = K >> 7;
     const int my_steps = (nsteps - wave + 7) >> 3;                 // steps wave, wave + 8, ...
     T8 wv[DEPTH][NW][4], xv[DEPTH][4];
@@ -146,6 +153,12 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
             float s = part[0][b][l][r];
 #pragma unroll
             for (int w = 1; w < 8; ++w) s += part[w][b][l][r];     // fixed order: results do not depend on timing
+            if (nm.hl && m < M) {                                   // + the lo row's product (lane l + M holds (n, m + M)): hi sum, lo sum, then their sum
+                float s2 = part[0][b][l + M][r];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) s2 += part[w][b][l + M][r];
+                s += s2;
+            }
             v[b] = nm.rowsq_in ? s * rstd_s[m] : s;
         }
         if (m < M) {
@@ -177,9 +190,14 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
                 }
             } else if (EPI == SK_SWIGLU_T) {
                 const float gt = v[0], up = v[NW - 1];
-                ((T*)out)[(long)m * ldo + (unit >> 1) * 32 + (unit & 1) * 16 + n] = (T)(gt / (1.0f + fexp(-gt)) * up);
+                const float y = sep_rn(gt / (1.0f + fexp(-gt)) * up);
+                const T hi = (T)y;
+                ((T*)out)[(long)m * ldo + (unit >> 1) * 32 + (unit & 1) * 16 + n] = hi;
+                if (nm.hl) ((T*)out)[(long)(m + M) * ldo + (unit >> 1) * 32 + (unit & 1) * 16 + n] = (T)(y - (float)hi);
             } else if (EPI == SK_STORE_T) {
-                ((T*)out)[(long)m * ldo + row0 + n] = (T)v[0];
+                const T hi = (T)v[0];
+                ((T*)out)[(long)m * ldo + row0 + n] = hi;
+                if (nm.hl) ((T*)out)[(long)(m + M) * ldo + row0 + n] = (T)(v[0] - (float)hi);
             } else if (EPI == SK_STORE_F32) {
                 ((float*)out)[(long)m * ldo + row0 + n] = v[0];
             } else {
@@ -187,7 +205,10 @@ __global__ void __launch_bounds__(512) skinny_gemm_kernel(const T* W, const T* X
                 const float xn = *xo + v[0];
                 *xo = xn;
                 if (nm.norm_out) {
-                    ((T*)nm.norm_out)[(long)m * nm.ld_norm + row0 + n] = (T)(xn * nm.gamma[row0 + n]);
+                    const float y = sep_rn(xn * nm.gamma[row0 + n]);
+                    const T hi = (T)y;
+                    ((T*)nm.norm_out)[(long)m * nm.ld_norm + row0 + n] = hi;
+                    if (nm.hl) ((T*)nm.norm_out)[(long)(m + M) * nm.ld_norm + row0 + n] = (T)(y - (float)hi);
                     sq_s[n][m] = xn * xn;
                 }
             }

@@ -151,6 +151,7 @@ class LeopardEngine:
         # lands in a tile: packed == separate stays bit for bit.  LMI_LO4_ROWS overrides.
         env_rows = os.environ.get("LMI_LO4_ROWS", "auto")
         self.lo4_rows = env_rows if env_rows in ("auto", "all") else int(env_rows)
+        self.decode_precision = os.environ.get("LMI_DECODE_PRECISION", "1") == "1"   # lo4 / split also cover the decode steps (decode_hl); 0 = fast decode (A/B)
         self._lo4_sel_cache: Dict[tuple, tuple] = {}
         self.skinny_fold_norm = True   # batched decode: RMSNorms folded into the projections (lmi_gemm_skinny_ex producer / consumer); False: norm launches
         self.skinny_packed = True      # batched decode over nn.Linear-layout weights (TP, pack_llm_weights=False): stream a packed second copy
@@ -210,6 +211,16 @@ class LeopardEngine:
         self._encode_graphs.clear()                           # captured encodes replay the launches of the old schedule
         if self.lo4 and self.device.type == "cuda":
             self._lo4_weights("llm")                          # the multi-GB quantisation happens HERE, not inside the first (timed) prefill
+
+    def decode_hl(self, B: int = 1) -> bool:
+        """Decode precision mode (round 6): with ``precision`` = "lo4" / "split" the captured decode step hands every projection operand over as a
+        pair of 16-bit rows — T(x) and T(x - T(x)) — through the M <= 16 kernels (lmi_gemm_skinny_hl ...): the hand-over roundings of the token's
+        own path through the layers, which are what its logits' error is made of, are gone, at no extra weight traffic.  Needs the packed one-copy
+        weight layout (the default on one rank), the folded norms and 2 B <= 16; otherwise the step is the fast one."""
+        D = self.cfg.text_config.hidden_size
+        return bool((self.lo4 or self.split_operands) and self.decode_precision and self.tp_size == 1 and self.llm_packed and 2 * B <= 16
+                    and self.skinny_fold_norm and D % 16 == 0 and self.cfg.text_config.head_dim == 128
+                    and all(L.qkv_w_rope is not None for L in self.W.llm_layers))
 
     def _llm_heads(self) -> Tuple[int, int]:
         """(query heads, kv heads) this rank computes."""
@@ -1160,8 +1171,8 @@ class LeopardEngine:
     # ------------------------------------------------------------------------------------------------
     def _decode_state(self, cache: KVCache):
         st = getattr(cache, "_decode_state", None)
-        if st is not None:
-            return st
+        if st is not None and getattr(st, "mode", None) == (self.precision, self.decode_precision):
+            return st                                                 # (a state built under another precision mode is rebuilt: other buffers, other launches)
         W, tc = self.W, self.cfg.text_config
         (H, KV), hd, D = self._llm_heads(), tc.head_dim, tc.hidden_size
         dev = self.device
@@ -1175,8 +1186,11 @@ class LeopardEngine:
         st.cu_q = torch.tensor([0, 1], dtype=torch.int32, device=dev)
         st.cu_k = torch.tensor([0, 1], dtype=torch.int32, device=dev)
         st.x = self._empty(1, D, dtype=torch.float32)
-        st.h, st.qkv, st.att = self._empty(1, D), self._empty(1, (H + 2 * KV) * hd), self._empty(1, H * hd)
-        st.gu = self._empty(1, W.llm_ff)
+        st.hl = self.decode_hl(1)                                     # operand buffers hold [hi row; lo row] pairs (decode precision mode)
+        R = 2 if st.hl else 1
+        st.h, st.qkv, st.att = self._empty(R, D), self._empty(1, (H + 2 * KV) * hd), self._empty(R, H * hd)
+        st.gu = self._empty(R, W.llm_ff)
+        st.hf32 = self._empty(1, D, dtype=torch.float32) if st.hl else None
         st.part = torch.zeros(D, dtype=torch.float32, device=dev)     # tensor parallel: partial o_proj / down_proj row
         st.sq_a, st.sq_b = self._empty(1, max(D // 16, 1), dtype=torch.float32), self._empty(1, max(D // 16, 1), dtype=torch.float32)
         st.k_begin = torch.zeros(1, dtype=torch.int32, device=dev)    # packed weights: the step runs on the batched-decode kernels with one row
@@ -1185,6 +1199,7 @@ class LeopardEngine:
         st.ws = torch.empty(self.ops.decode_workspace_elems(1, H, hd, cache.capacity), dtype=torch.float32, device=dev)
         st.graph = None
         st.layout = self.llm_packed                                   # a captured step replays the launches of the weight layout it was captured on
+        st.mode = (self.precision, self.decode_precision)             # ... and of the precision mode
         cache._decode_state = st
         return st
 
@@ -1208,7 +1223,7 @@ class LeopardEngine:
             # 3.10 ms per step at B = 2 against 3.12 ms for the GEMV step), its KV rows go to this cache, the head keeps the fp32 row
             self._skinny_layers(st, cache.k, cache.v, cache.capacity,
                                 lambda i: ops.attention_decode(st.qkv[:, :qw], cache.k[i], cache.v[i], st.att, st.cu_q, st.cu_k, 1, cache.capacity, H, KV,
-                                                               hd, hd ** -0.5, st.ws, window=tc.sliding_window or 0))
+                                                               hd, hd ** -0.5, st.ws, window=tc.sliding_window or 0, hl=st.hl))
             ops.lm_head_last(W.lm_head, st.x, None, W.final_norm, tc.rms_norm_eps, st.logits.view(1, -1))
             ops.decode_advance(st.logits.view(1, -1), tc.vocab_size, st.tok, st.pos, k_len=st.cu_k[1:], suppress=self.suppress_tokens)
             return
@@ -1366,7 +1381,7 @@ class LeopardEngine:
         if states is None:
             states = self._batch_states = {}
         st = states.get(B)
-        if st is not None and st.capacity >= need:
+        if st is not None and st.capacity >= need and getattr(st, "mode", None) == (self.precision, self.decode_precision):
             return st
         W, tc, dev = self.W, self.cfg.text_config, self.device
         (H, KV), hd, D = self._llm_heads(), tc.head_dim, tc.hidden_size
@@ -1386,8 +1401,12 @@ class LeopardEngine:
         st.k_begin = (torch.arange(B, dtype=torch.int32) * cap).to(dev)
         st.cu_q = torch.arange(B + 1, dtype=torch.int32, device=dev)
         st.x = self._empty(B, D, dtype=torch.float32)
-        st.h, st.qkv, st.att = self._empty(B, D), self._empty(B, (H + 2 * KV) * hd), self._empty(B, H * hd)
-        st.gu = self._empty(B, W.llm_ff)
+        st.hl = self.decode_hl(B)                                     # [hi rows; lo rows] operand pairs (decode precision mode; 2 B <= 16)
+        R = 2 * B if st.hl else B
+        st.h, st.qkv, st.att = self._empty(R, D), self._empty(B, (H + 2 * KV) * hd), self._empty(R, H * hd)
+        st.gu = self._empty(R, W.llm_ff)
+        st.hf32 = self._empty(B, D, dtype=torch.float32) if st.hl else None
+        st.mode = (self.precision, self.decode_precision)
         st.sq_a, st.sq_b = self._empty(B, D // 16, dtype=torch.float32), self._empty(B, D // 16, dtype=torch.float32)   # folded-norm partials
         st.logits = self._empty(B, W.lm_head.shape[0], dtype=torch.float32)
         st.cos, st.sin = self.rope_tables(torch.arange(cap))
@@ -1433,26 +1452,31 @@ class LeopardEngine:
         # per-row partial sums of squares, the projection that consumes them scales its accumulator rows by rstd — only the first
         # layer's norm and the final one stay launches of their own
         fold = self.skinny_fold_norm and D % 16 == 0 and all(L.qkv_w_rope is not None for L in W.llm_layers) and hd == 128
+        hl = bool(getattr(st, "hl", False))                           # decode precision mode: operands are [hi rows; lo rows] pairs (decode_hl)
+        assert not hl or fold
         for i, L in enumerate(W.llm_layers):
             rope_fused = L.qkv_w_rope is not None and hd == 128
             qkv_w, o_w, gu_w, down_w = pk["layers"][i] if pk else (L.qkv_w_rope if rope_fused else L.qkv_w, L.o_w, L.gu_w, L.down_w)
             packed = None if pk is None else True            # None: as the weight is marked (weights.is_packed)
-            if not fold or i == 0:
+            if hl and i == 0:
+                ops.rmsnorm(st.x, L.in_norm, st.hf32, eps)            # the first norm in fp32, handed over as a pair
+                ops.split_rows_hl(st.hf32, st.h)
+            elif not fold or i == 0:
                 ops.rmsnorm(st.x, L.in_norm, st.h, eps)
             if rope_fused:
                 ops.rope_qkv_skinny(qkv_w, st.h, st.qkv, H, KV, hd, st.cos, st.sin, k_list[i], v_list[i], capacity, st.pos, packed,
-                                    rowsq_in=st.sq_b if fold and i > 0 else None, norm_eps=eps)
+                                    rowsq_in=st.sq_b if fold and i > 0 else None, norm_eps=eps, hl=hl)
             else:
                 ops.gemm_skinny(qkv_w, st.h, st.qkv, 0, packed)
                 ops.rope_qk_rows(st.qkv, H, KV, hd, st.cos, st.sin, k_list[i], v_list[i], capacity, st.pos)
             attend(i)
             if fold:
-                ops.gemm_skinny(o_w, st.att, st.x, 1, packed, norm_out=st.h, norm_gamma=L.post_norm, rowsq_out=st.sq_a)
-                ops.gemm_skinny(gu_w, st.h, st.gu, 2, packed, rowsq_in=st.sq_a, norm_dim=D, norm_eps=eps)
+                ops.gemm_skinny(o_w, st.att, st.x, 1, packed, norm_out=st.h, norm_gamma=L.post_norm, rowsq_out=st.sq_a, hl=hl)
+                ops.gemm_skinny(gu_w, st.h, st.gu, 2, packed, rowsq_in=st.sq_a, norm_dim=D, norm_eps=eps, hl=hl)
                 if i + 1 < n_layers:
-                    ops.gemm_skinny(down_w, st.gu, st.x, 1, packed, norm_out=st.h, norm_gamma=W.llm_layers[i + 1].in_norm, rowsq_out=st.sq_b)
+                    ops.gemm_skinny(down_w, st.gu, st.x, 1, packed, norm_out=st.h, norm_gamma=W.llm_layers[i + 1].in_norm, rowsq_out=st.sq_b, hl=hl)
                 else:
-                    ops.gemm_skinny(down_w, st.gu, st.x, 1, packed)
+                    ops.gemm_skinny(down_w, st.gu, st.x, 1, packed, hl=hl)
             else:
                 ops.gemm_skinny(o_w, st.att, st.x, 1, packed)
                 ops.rmsnorm(st.x, L.post_norm, st.h, eps)
@@ -1476,12 +1500,17 @@ class LeopardEngine:
         ops.embed_merge(st.tok, st.src, W.embed, None, st.x)
         self._skinny_layers(st, st.k, st.v, st.capacity,
                             lambda i: ops.attention_decode_pool(st.qkv[:, :qw], st.k[i], st.v[i], st.att, st.cu_q, st.k_begin, st.k_len, st.capacity,
-                                                                H, KV, hd, hd ** -0.5, st.ws, window=tc.sliding_window or 0))
+                                                                H, KV, hd, hd ** -0.5, st.ws, window=tc.sliding_window or 0, hl=st.hl))
         # head: one pass over lm_head for all B rows (lmi_lm_head_last streams the 1 GB head once PER row), from a packed copy of the head
         # (1 GB, built on the first batched step: the prefill's and the batch-1 step's head kernels read the nn.Linear layout; B = 8 step
         # 3.29 ms against 3.37 ms from the row-major head in the coalescing lane order)
-        ops.rmsnorm(st.x, W.final_norm, st.h, eps)
-        ops.gemm_skinny(self._skinny_head() if self.skinny_packed else W.lm_head, st.h, st.logits, 3)
+        if st.hl:                                                     # decode precision mode: the head's operand as a pair too (the batch-1 step's head reads the fp32 row)
+            ops.rmsnorm(st.x, W.final_norm, st.hf32, eps)
+            ops.split_rows_hl(st.hf32, st.h)
+            ops.gemm_skinny(self._skinny_head() if self.skinny_packed else W.lm_head, st.h, st.logits, 3, hl=True)
+        else:
+            ops.rmsnorm(st.x, W.final_norm, st.h, eps)
+            ops.gemm_skinny(self._skinny_head() if self.skinny_packed else W.lm_head, st.h, st.logits, 3)
         # greedy choice, history ring, stop rule (eos ids / token budget) and position advance of all B slots: ONE launch, device memory only —
         # a slot that stopped freezes (live = 0) and what it produces afterwards is ignored (lmi_decode_advance)
         ops.decode_advance(st.logits, tc.vocab_size, st.tok, st.pos, k_len=st.k_len, live=st.live, budget=st.budget, eos=st.eos, hist=st.hist,

@@ -215,21 +215,24 @@ class Ops:
         return out
 
     def attention_decode(self, q, k, v, out, cu_q, cu_k, max_seqlen_q, max_seqlen_k, n_heads, n_kv_heads, head_dim, scale,
-                         workspace: torch.Tensor, window=0):
-        """Split-KV attention for a few query rows against a long cache (decode).  workspace: fp32, decode_workspace_elems()."""
+                         workspace: torch.Tensor, window=0, hl=False):
+        """Split-KV attention for a few query rows against a long cache (decode).  workspace: fp32, decode_workspace_elems().
+        ``hl``: out has 2 x q rows — the output rows and, below them, the 16-bit residuals of their rounding (lmi_attn_decode_fwd_hl)."""
         n_seq = cu_q.numel() - 1
-        self._check(self.lib.lmi_attn_decode_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(cu_q), _ptr(cu_k), n_seq, int(max_seqlen_q),
+        assert not hl or out.shape[0] == 2 * q.shape[0]
+        self._check((self.lib.lmi_attn_decode_fwd_hl if hl else self.lib.lmi_attn_decode_fwd)(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(cu_q), _ptr(cu_k), n_seq, int(max_seqlen_q),
                                                  int(max_seqlen_k), q.shape[0], n_heads, n_kv_heads, head_dim, q.stride(0), k.stride(0),
                                                  v.stride(0), out.stride(0), float(scale), int(window), _ptr(workspace),
                                                  workspace.numel() * workspace.element_size(), _DT[q.dtype], self._stream(out)))
         return out
 
     def attention_decode_pool(self, q, k, v, out, cu_q, k_begin, k_len, max_seqlen_k, n_heads, n_kv_heads, head_dim, scale,
-                              workspace: torch.Tensor, window=0):
+                              workspace: torch.Tensor, window=0, hl=False):
         """Split-KV decode attention for a batch whose caches share one pooled buffer: sequence s owns rows
-        [k_begin[s], k_begin[s] + k_len[s]) of k / v (int32 device tensors; k_len advances on the device)."""
+        [k_begin[s], k_begin[s] + k_len[s]) of k / v (int32 device tensors; k_len advances on the device).  ``hl``: as attention_decode."""
         n_seq = cu_q.numel() - 1
-        self._check(self.lib.lmi_attn_decode_pool(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(cu_q), _ptr(k_begin), _ptr(k_len), n_seq, 1,
+        assert not hl or out.shape[0] == 2 * q.shape[0]
+        self._check((self.lib.lmi_attn_decode_pool_hl if hl else self.lib.lmi_attn_decode_pool)(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(cu_q), _ptr(k_begin), _ptr(k_len), n_seq, 1,
                                                   int(max_seqlen_k), q.shape[0], n_heads, n_kv_heads, head_dim, q.stride(0), k.stride(0),
                                                   v.stride(0), out.stride(0), float(scale), int(window), _ptr(workspace),
                                                   workspace.numel() * workspace.element_size(), _DT[q.dtype], self._stream(out)))
@@ -242,14 +245,23 @@ class Ops:
                                               _ptr(pos_rows), _DT[qkv.dtype], self._stream(qkv)))
         return qkv
 
-    def gemm_skinny(self, w, x, out, epilogue=0, packed=None, rowsq_in=None, norm_dim=0, norm_eps=0.0, norm_out=None, norm_gamma=None, rowsq_out=None):
+    def gemm_skinny(self, w, x, out, epilogue=0, packed=None, rowsq_in=None, norm_dim=0, norm_eps=0.0, norm_out=None, norm_gamma=None, rowsq_out=None,
+                    hl=False):
         """out[M <= 16, .] = epilogue(x @ w.T): the projections of a batched decode step.  epilogue: 0 store T, 1 fp32 +=,
         2 SwiGLU (w rows interleaved [32 gate | 32 up], out [M, N/2]), 3 store fp32.  packed: w is weights.skinny_pack(w) (same shape).
-        rowsq_in / norm_out + norm_gamma + rowsq_out: the folded RMSNorm of lmi_gemm_skinny_ex (consumer / producer side)."""
+        rowsq_in / norm_out + norm_gamma + rowsq_out: the folded RMSNorm of lmi_gemm_skinny_ex (consumer / producer side).
+        ``hl`` (lmi_gemm_skinny_hl, the decode precision mode): x holds 2 M rows [T(x); T(x - T(x))], 16-bit operand outputs are pairs again."""
         N, K = w.shape
-        M = x.shape[0]
+        M = x.shape[0] // 2 if hl else x.shape[0]
         if packed is None:
             packed = getattr(w, "_lmi_packed", False)
+        if hl:
+            assert x.shape[0] == 2 * M and (epilogue in (1, 3) or out.shape[0] == 2 * M) and (norm_out is None or norm_out.shape[0] == 2 * M)
+            self._check(self.lib.lmi_gemm_skinny_hl(_ptr(w), _ptr(x), _ptr(out), M, N, K, w.stride(0), x.stride(0), out.stride(0), int(epilogue),
+                                                    int(bool(packed)), _ptr(rowsq_in), 0 if rowsq_in is None else rowsq_in.shape[1], int(norm_dim),
+                                                    float(norm_eps), _ptr(norm_out), 0 if norm_out is None else norm_out.stride(0), _ptr(norm_gamma),
+                                                    _ptr(rowsq_out), _DT[w.dtype], self._stream(out)))
+            return out
         if rowsq_in is None and norm_out is None:
             self._check(self.lib.lmi_gemm_skinny(_ptr(w), _ptr(x), _ptr(out), M, N, K, w.stride(0), x.stride(0), out.stride(0), int(epilogue),
                                                  int(bool(packed)), _DT[w.dtype], self._stream(out)))
@@ -261,13 +273,13 @@ class Ops:
         return out
 
     def rope_qkv_skinny(self, w_rope, x, qkv, n_q_heads, n_kv_heads, head_dim, cos_all, sin_all, k_cache, v_cache, cache_stride, pos_rows, packed=None,
-                        rowsq_in=None, norm_eps=0.0):
+                        rowsq_in=None, norm_eps=0.0, hl=False):
         """lmi_rope_qkv_skinny: batched-decode q|k|v projection with RoPE + KV append in the epilogue (w_rope in rope_permute_rows order);
-        rowsq_in: consumer side of the folded RMSNorm."""
-        M, K = x.shape[0], w_rope.shape[1]
+        rowsq_in: consumer side of the folded RMSNorm.  ``hl``: x holds 2 M rows [T(x); T(x - T(x))] (lmi_rope_qkv_skinny_hl); qkv has M rows."""
+        M, K = (x.shape[0] // 2 if hl else x.shape[0]), w_rope.shape[1]
         if packed is None:
             packed = getattr(w_rope, "_lmi_packed", False)
-        self._check(self.lib.lmi_rope_qkv_skinny(_ptr(w_rope), _ptr(x), _ptr(qkv), M, n_q_heads, n_kv_heads, head_dim, K, w_rope.stride(0), x.stride(0),
+        self._check((self.lib.lmi_rope_qkv_skinny_hl if hl else self.lib.lmi_rope_qkv_skinny)(_ptr(w_rope), _ptr(x), _ptr(qkv), M, n_q_heads, n_kv_heads, head_dim, K, w_rope.stride(0), x.stride(0),
                                                  qkv.stride(0), int(bool(packed)), _ptr(rowsq_in), 0 if rowsq_in is None else rowsq_in.shape[1],
                                                  float(norm_eps), _ptr(cos_all), _ptr(sin_all), _ptr(k_cache), _ptr(v_cache),
                                                  k_cache.stride(0), int(cache_stride), _ptr(pos_rows), _DT[w_rope.dtype], self._stream(qkv)))
@@ -515,6 +527,13 @@ class Ops:
                                                   a.hi.stride(0), self._ldw(w_qkv_rope), qkv.stride(0), C.byref(d), _DT[w_qkv_rope.dtype],
                                                   self._stream(qkv)))
         return qkv
+
+    def split_rows_hl(self, x_f32, out):
+        """out [2 M, K] (16-bit) = rows T(x), then rows T(x - T(x)) of the fp32 x [M, K] (lmi_split_rows_hl; the decode precision mode)."""
+        M, K = x_f32.shape
+        assert x_f32.dtype == torch.float32 and out.shape == (2 * M, K)
+        self._check(self.lib.lmi_split_rows_hl(_ptr(x_f32), _ptr(out), M, K, x_f32.stride(0), out.stride(0), _DT[out.dtype], self._stream(out)))
+        return out
 
     def split_hi_lo(self, x_f32, out):
         """out [M, 2K] (16-bit) = [T(x) | T(x - T(x))] of the fp32 x [M, K] (lmi_split_hi_lo; split-operand precision mode)."""

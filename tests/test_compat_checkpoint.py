@@ -99,3 +99,65 @@ def test_harness_gpu_tiler_path_equals_host_path(ckpt, tmp_path):
     finally:
         harness.generate_kwargs = gen_kw
     assert host == dev and len(host) == 1 and host[0]["raw"] and host[0]["multi_img"]
+
+
+def _save_ckpt(path, cfg, transform):
+    """A checkpoint of the micro model whose matrices are ``transform(name, synthetic fp32 values)`` (safetensors, the converter's key layout)."""
+    import os
+    from safetensors.torch import save_file
+    from leopard_amd.synth import param_specs, synth_array
+    os.makedirs(path, exist_ok=True)
+    cfg.save(os.path.join(path, "config.json"))
+    tensors = {}
+    for n, s, k in param_specs(cfg):
+        t = torch.from_numpy(synth_array(n, s, k))
+        tensors[n] = transform(n, t) if t.dim() >= 2 else t
+    save_file(tensors, os.path.join(path, "model.safetensors"))
+    return tensors
+
+
+def test_weights_that_are_not_fp16_exact(tmp_path):
+    """the synthetic parameters are exact in fp16 by construction, a real checkpoint is not.  (a) bf16-VALUED weights (the
+    released Leopard checkpoints are bf16-trained, train_multiimg_llava_siglip.sh:64) incl. values below fp16's normal range: exact down to 2^-17,
+    below that bits are lost / flushed — counted by the loader, invisible in the logits; (b) fp32-VALUED weights: the cast is one rounding per
+    weight that no precision mode corrects — its cost in the logits is printed beside the activation hand-overs' and the loader warns."""
+    import warnings
+    cfg = micro_config()
+    ops = emu_ops()
+    g = torch.Generator().manual_seed(5)
+
+    def bf16_valued(name, t):
+        w = (torch.randn(t.shape, generator=g) * 0.02).to(torch.bfloat16).float()
+        flat = w.view(-1)
+        flat[::97] = flat[::97] * 2.0 ** -12                                   # ~1 % of the weights far below 6.1e-5 (fp16's smallest normal)
+        flat[::1013] = flat[::1013] * 2.0 ** -26                               # ... and a few that even fp16 subnormals cannot hold
+        return flat.view(t.shape).to(torch.bfloat16).float()
+
+    def fp32_valued(name, t):
+        return torch.randn(t.shape, generator=g) * 0.02
+
+    u8 = np.random.default_rng(4).integers(0, 256, (2, 28, 28, 3), dtype=np.uint8)
+    images = torch.from_numpy(siglip_normalize(u8))
+    input_ids = torch.tensor([[7, 250, 11, 250, 12, 31, 5]])
+    out = {}
+    for kind, tf in (("bf16", bf16_valued), ("fp32", fp32_valued)):
+        tensors = _save_ckpt(str(tmp_path / kind), cfg, tf)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            m = compat.from_pretrained(str(tmp_path / kind), torch_dtype=torch.float32, ops=ops).to("cpu")
+        st = m.weight_cast_stats
+        got = m(input_ids=input_ids, pixel_values=images, return_dict=True).logits[0, -1]
+        W_orig = {k: v.float() for k, v in tensors.items()}
+        W_cast = {k: (v.to(torch.float16).float() if v.dim() >= 2 else v.float()) for k, v in tensors.items()}
+        ref = O.prefill_logits(input_ids, images, W_orig, cfg, last_only=True)[0, 0]
+        ref_cast = O.prefill_logits(input_ids, images, W_cast, cfg, last_only=True)[0, 0]
+        scale = ref.abs().max().item()
+        out[kind] = dict(stats=st, cast_cost=(ref_cast - ref).abs().max().item() / scale, total=(got - ref).abs().max().item() / scale,
+                         vs_cast=(got - ref_cast).abs().max().item() / scale, warned=any("NOT exactly representable" in str(w.message) for w in rec))
+        print(f"[weights {kind}-valued -> fp16] loader: {st['inexact_elements']} / {st['elements']} elements inexact, {st['flushed_to_zero']} flushed; "
+              f"logits vs fp32-weight oracle: cast alone {out[kind]['cast_cost']:.2e}, engine {out[kind]['total']:.2e} (engine vs the cast-weight oracle {out[kind]['vs_cast']:.2e})")
+    b, f = out["bf16"], out["fp32"]
+    assert 0 < b["stats"]["inexact_elements"] < 0.02 * b["stats"]["elements"] and b["stats"]["flushed_to_zero"] > 0 and not b["warned"]
+    assert b["cast_cost"] < 1e-5 and b["total"] < 1.2 * b["vs_cast"] + 1e-5              # the tiny values' lost bits do not show
+    assert f["stats"]["inexact_elements"] > 0.9 * f["stats"]["elements"] and f["warned"]
+    assert f["cast_cost"] > 20 * b["cast_cost"]                                            # a real rounding of every weight
