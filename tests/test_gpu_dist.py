@@ -234,3 +234,62 @@ def test_tensor_parallel_c2_full_depth_vs_oracle_fixture_and_tp_checkpoint_load(
     d = (torch.tensor(tp0) - torch.tensor(one)).abs().max().item() / torch.tensor(one).abs().max().item()
     print(f"[tp2 checkpoint load] TP-sharded from_pretrained vs one rank: {d:.3e} of the logit scale")
     assert d <= 2.5e-3
+
+
+def _worker_c2_tp8(rank, world, port, out):
+    """C2 at FULL depth on EIGHT ranks sharing one device (1/8 of the LLM per rank): the 8-way reduce-scatter order, the 8-way column split of the
+    head, and the tile-sharded vision encode with 7 ViT inputs on 8 ranks — one rank has nothing to encode."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from leopard_amd import dist as D
+    from leopard_amd.config import full_config
+    from leopard_amd.engine import LeopardEngine
+    from leopard_amd.ops import Ops
+    from leopard_amd.weights import EngineWeights, SynthSource
+    from tests.test_gpu_parity import sample_inputs
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    D.init(backend="gloo")
+    ops, cfg, dtype = Ops(), full_config(), torch.float16
+    eng = LeopardEngine(cfg, EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype, tp_rank=rank, tp_size=world), ops=ops, device=dev)
+    u8, ids, _ = sample_inputs(cfg, 1, 1344, 896)
+    tiles = torch.from_numpy(u8).to(dev)
+    assert tiles.shape[0] == 7 and world == 8
+    res = {}
+    eng.tp_chunks, eng.tp_comm_dtype = 2, torch.float32
+    res["fast, fp32 reduce-scatter"] = eng.prefill(ids, tiles).logits_last.float().cpu()
+    eng.precision = "lo4"
+    res["lo4, fp32 reduce-scatter"] = eng.prefill(ids, tiles).logits_last.float().cpu()
+    shard = (eng.W.llm_layers[0].o_w.shape, eng.W.lm_head.shape[0])
+    torch.cuda.synchronize()
+    out.put((rank, {k: v.tolist() for k, v in res.items()}, shard))
+    D.barrier()
+
+
+def test_tensor_parallel_c2_full_depth_eight_ranks_one_gpu():
+    """8-rank readiness without an 8-GPU node — the reduce order of 8 partial products, the 8-way head and the idle vision rank
+    meet the fp32 oracle fixture (tests/golden/c2_full_depth.npz) at full depth, fast and lo4 (host-staged gloo collectives: times mean nothing)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_full_depth.npz"))
+    ref = torch.from_numpy(z["logits_fp32"])
+    mp.set_start_method("spawn", force=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c2_tp8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=2400) for _ in procs)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    v0 = res[0][1]
+    for r in res[1:]:
+        assert r[1] == v0 and r[2] == res[0][2]                  # every rank holds the same logits and an equal shard
+    assert res[0][2][0][1] * 8 == 4096                           # o_proj: 1/8 of the contraction per rank
+    scale = ref.abs().max().item()
+    errs = {k: (torch.tensor(v) - ref).abs().max().item() / scale for k, v in v0.items()}
+    print("[tp8 on one device, C2 full depth fp16] max|logit diff| / max|logit| vs the fp32 oracle fixture:", {k: f"{e:.3e}" for k, e in errs.items()},
+          "(two ranks: 1.20e-3 / 3.9e-4; one rank: 1.38e-3 / 3.8e-4)")
+    for k, v in v0.items():
+        assert int(torch.tensor(v).argmax()) == int(ref.argmax()), k
+    assert errs["fast, fp32 reduce-scatter"] <= 1.7e-3
+    assert errs["lo4, fp32 reduce-scatter"] <= 1.0e-3            # north_star's figure on eight ranks
