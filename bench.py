@@ -619,7 +619,13 @@ def measure_tp(args, cfg, ops, dev, dtype, rank, world, D, gpu_tiler):
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     assert res.seq_len == S and torch.isfinite(res.logits_last).all()
     fl = algorithmic_flops(cfg, u8.shape[0], S)
+
+    class _Ctx:                                                  # the sample is the fixture's (seed 0): the tensor-parallel logits against the fp32 oracle
+        pass
+    pc = _Ctx()
+    pc.ids, pc.tiles = ids, torch.from_numpy(u8)
     return {"value": round(args.images * args.steps / elapsed, 3), "unit": "images/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "parity": fixture_parity(args, pc, res) if rank == 0 else None,
             "scaling": "strong", "n_gpus": world, "precision_mode": PRECISION_NOTE[tp_precision],
             "parallelism": f"one sample on {world} ranks: ViT inputs sharded {u8.shape[0]} -> {world} + 1 all-gather; TP{world} LLM with "
                            f"sequence-parallel norms ({eng.tp_chunks} row chunks, all-gather + reduce-scatter per half layer in "
@@ -764,9 +770,9 @@ def main():
     ap.add_argument("--no-fast-line", action="store_true", help="lo4 headline: skip the additional measurement of the fast schedule on the same sample")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configurations appended to the default line")
     ap.add_argument("--cpu-tflops", type=float, default=0.0, help="(internal) host TFLOP/s measured by the parent run: the cpu_baseline of an other_configs child")
-    ap.add_argument("--lo4-vit", type=int, default=0, choices=[0, 1],
-                    help="--precision lo4: 0 = the correction phase on the LLM layer linears (default: full-depth logits 2.4e-4 / 3.9e-4 / 7.3e-4 of the logit "
-                         "scale on C3 / C2 / C1), 1 = on the SigLIP layer linears too (2.4e-4 / 3.3e-4 / 6.1e-4 for + 6 %% of the step)")
+    ap.add_argument("--lo4-vit", type=int, default=None, choices=[0, 1],
+                    help="--precision lo4: 0 = the correction phase on the LLM layer linears only, 1 = on the SigLIP layer linears too; default = the "
+                         "engine's 'auto' (the tower is corrected for samples whose LLM sequence is short, <= 1024 rows: C1; not for C2 / C3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-tp", action="store_true", help="N > 1: skip the additional one-sample-on-all-ranks (strong scaling) measurement")
@@ -836,7 +842,8 @@ def main():
         if args.precision == "lo4" and not eng.lo4_supported():
             args.precision = "fast"                            # a model shape the lo4 schedule does not cover (advisor r05): only an EXPLICIT request fails
     eng.precision = args.precision
-    eng.lo4_vit = bool(args.lo4_vit)
+    if args.lo4_vit is not None:
+        eng.lo4_vit = bool(args.lo4_vit)
     load_s = time.perf_counter() - t0
 
     class Ctx:
@@ -989,7 +996,9 @@ def main():
         out["lo4_rows"] = {"policy": eng.lo4_rows, "rows_with_residual_images": tail, "rows_in_corrected_tiles": corrected_rows, "of": S,
                            "note": "the correction covers the trailing rows of each sequence — the rows whose logits are read; the other rows' "
                                    "hand-over roundings reach them only through the softmax average (DESIGN.md 2.1, profiles/r06_lo4_policy_study_*.txt)"}
-        lo_fl = fl["llm_linear"] * corrected_rows / S + ((fl["vit"] - n_tiles * vit_attention_flops(cfg)) if args.lo4_vit else 0)
+        vit_corrected = eng.lo4_vit_tiles([n_tiles], [S]) is not None
+        lo_fl = fl["llm_linear"] * corrected_rows / S + ((fl["vit"] - n_tiles * vit_attention_flops(cfg)) if vit_corrected else 0)
+        out["lo4_rows"]["siglip_tower_corrected"] = vit_corrected
         out["matrix_pipe_frac"] = round((args.inflight * (fl["total"] / MFMA_PEAK_TFLOPS + lo_fl / MFMA_PEAK_FP4_TFLOPS) / 1e12) / (elapsed / args.steps), 4)
         out["matrix_pipe_frac_note"] = ("algorithmic FLOPs at the 2.5 PF 16-bit peak + the correction phase's FLOPs (every corrected layer linear once more, "
                                         f"{lo_fl / 1e12:.1f} TFLOP) at the 10 PF fp4 peak, over the step time; prefill_mfma_frac counts the algorithmic FLOPs only")

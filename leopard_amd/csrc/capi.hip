@@ -123,6 +123,9 @@ int choose_gemm_cfg(const GemmArgs& a) {
     // 256 < M <= 384 (Idefics2's text side: S = 312) on a wide N: one M-complete 384x128 tile per 128 weight rows — the weights are streamed
     // once instead of once per 64-row tile (5x at M = 312); narrower N leaves too few tiles for 256 CUs and stays on the 64x128 ring
     if (g_gemm_mid_m.load() && a.M > 256 && a.M <= 384 && a.N >= 128 * 160) return 10;
+    // 128 < M <= 256 on a wide N (C1's gate/up at S = 228): the 256 x 128 ring is M-complete there too — 224 tiles of 8 waves, every weight tile
+    // fetched once — against 896 tiles of the 64 x 128 ring (isolated launches: 61 vs 79 us, profiles/r06_small_m_gemm_sweep.txt)
+    if (g_gemm_mid_m.load() && a.M > 128 && a.M <= 256 && a.N >= 128 * 160) return 2;
     if (a.M < 512) return 8;
     const int cls = a.N >= 2048 ? (a.K <= 1536 ? g_gemm_short.load() : g_gemm_wide.load()) : (a.K >= 2048 ? g_gemm_narrow.load() : g_gemm_small.load());
     if (!g_gemm_auto_small.load()) return cls;

@@ -140,7 +140,11 @@ class LeopardEngine:
         # lo4 corrects the LLM layer linears; ``lo4_vit`` (LMI_LO4_VIT=1) extends it to the SigLIP layer linears.  Off by default: measured at
         # full depth, the tower's correction moves the logits of the benchmarked C3 sample by < 1 % (2.35e-4 vs 2.37e-4 of the logit scale) and
         # those of the hardest case — C1: one ViT input, S = 228 — from 7.3e-4 to 6.1e-4, for + 6 % of the step (1.20 x vs 1.27 x the fast schedule)
-        self.lo4_vit = os.environ.get("LMI_LO4_VIT", "0") == "1"
+        # Round 6: "auto" (default) = the tower is corrected too for the samples whose LLM sequence is short (<= LO4_FULL_BELOW rows: C1-like, where
+        # the rounding noise of ONE realisation lands anywhere between 7e-4 and 1e-3 without it) — a per-SAMPLE decision carried to the tower's rows
+        # by the same row selection as the LLM's (the tiles of a long sample in a packed batch stay on the fast tower: packed == separate).
+        env_vit = os.environ.get("LMI_LO4_VIT", "auto")
+        self.lo4_vit = "auto" if env_vit == "auto" else env_vit == "1"
         self._lo4_w = {}               # tower -> fp4 weight images (built when the mode is selected / on first use; dropped by invalidate_lo4_weights)
         # WHICH ROWS carry the correction (round 6; DESIGN.md 2.1 "row selection", tools/lo4_policy_study.py).  The logits of a row are dominated by
         # the hand-over roundings on that row's OWN path through the 32 layers; the roundings of the other rows reach it only through the softmax
@@ -383,8 +387,19 @@ class LeopardEngine:
     # ------------------------------------------------------------------------------------------------
     # a5 + a7: vision tower
     # ------------------------------------------------------------------------------------------------
-    def vision_tower(self, tiles: torch.Tensor) -> torch.Tensor:
-        """tiles: u8 [N,S,S,3] (HWC) or fp32 pixel_values [N,3,S,S].  Returns post-LN features T [N*T, D]."""
+    def lo4_vit_tiles(self, tiles_per_sample: Sequence[int], seq_lens: Sequence[int]) -> Optional[Tuple[bool, ...]]:
+        """Per ViT input: does the lo4 schedule correct the SigLIP layer linears for it (``lo4_vit``: True / False / "auto" = the inputs of the
+        samples whose LLM sequence has at most LO4_FULL_BELOW rows)?  None = no input is corrected (the fast tower)."""
+        if not self.lo4 or self.lo4_vit is False:
+            return None
+        flags: List[bool] = []
+        for n, S in zip(tiles_per_sample, seq_lens):
+            flags += [bool(self.lo4_vit is True or int(S) <= self.LO4_FULL_BELOW)] * int(n)
+        return tuple(flags) if any(flags) else None
+
+    def vision_tower(self, tiles: torch.Tensor, lo4_tiles: Optional[Sequence[bool]] = None) -> torch.Tensor:
+        """tiles: u8 [N,S,S,3] (HWC) or fp32 pixel_values [N,3,S,S].  Returns post-LN features T [N*T, D].  ``lo4_tiles``: per ViT input, whether
+        the lo4 schedule corrects the tower's linears for it (lo4_vit_tiles; None = none)."""
         ops, W, vc = self.ops, self.W, self.cfg.vision_config
         n = tiles.shape[0]
         T, D, H, hd = vc.num_patches, vc.hidden_size, vc.num_attention_heads, vc.head_dim
@@ -401,8 +416,8 @@ class LeopardEngine:
             return self._vit_layers_fp8(x, n)
         if self.split_operands:
             return self._vit_layers_split(x, n)
-        if self.lo4 and self.lo4_vit:
-            return self._vit_layers_lo4(x, n)
+        if self.lo4 and lo4_tiles is not None and any(lo4_tiles):
+            return self._vit_layers_lo4(x, n, lo4_tiles)
         qkv_w = W.vit_layers[0].qkv_w.shape[0] if W.vit_layers else 3 * D
         total, offs = ops.vit_workspace(M, D, qkv_w, W.vit_ff, self.dtype)
         h, qkv, att, ff = self._carve("vit", total, offs, [(M, D, self.dtype), (M, qkv_w, self.dtype), (M, D, self.dtype), (M, W.vit_ff, self.dtype)])
@@ -607,14 +622,27 @@ class LeopardEngine:
         from .ops import Lo4Act, lo4_head_k4
         return Lo4Act.empty(rows, width, self.dtype, self.device, k4=lo4_head_k4(*heads) if heads else None, sel=sel)
 
-    def _vit_layers_lo4(self, x: torch.Tensor, n: int) -> torch.Tensor:
+    def _vit_layers_lo4(self, x: torch.Tensor, n: int, flags: Optional[Sequence[bool]] = None) -> torch.Tensor:
         """The SigLIP layers with the low-bit correction phase: the LayerNorms and fc1's GELU epilogue hand over T(y) + the fp4 image of
         y - T(y) directly, and so does the attention kernel (lmi_attn_varlen_fwd_lo4: every head padded to 96 slots in the image, out_proj's
         weight image laid out to match).  q / k / v and the attention arithmetic stay 16-bit."""
         ops, W, vc = self.ops, self.W, self.cfg.vision_config
         T, D, H, hd = vc.num_patches, vc.hidden_size, vc.num_attention_heads, vc.head_dim
         M = n * T
-        h, att, ff = self._lo4_act(M, D), self._lo4_act(M, D, heads=(H, hd)), self._lo4_act(M, W.vit_ff)
+        # (a packed batch whose samples differ: the row selection of the correction phase carries the per-input decision — every row of a selected
+        # ViT input, none of the others: _lo4_selection with "sequences" = the inputs)
+        sel = None
+        if flags is not None and not all(flags):
+            key = ("vit", tuple(bool(f) for f in flags))
+            sel = self._lo4_sel_cache.get(key)
+            if sel is None:
+                row = np.repeat(np.array(flags, dtype=np.uint8), T)
+                unit = np.zeros((M + 63) // 64 * 64, dtype=np.uint8)
+                unit[:M] = row
+                r = np.flatnonzero(np.diff(np.concatenate([[0], row.astype(np.int8), [0]])))
+                sel = self._lo4_sel_cache[key] = (self._pinned_to_device(torch.from_numpy(row)), self._pinned_to_device(torch.from_numpy(unit.reshape(-1, 64).max(axis=1))),
+                                                  np.ascontiguousarray(r.reshape(-1, 2).astype(np.int32)))
+        h, att, ff = self._lo4_act(M, D, sel=sel), self._lo4_act(M, D, heads=(H, hd), sel=sel), self._lo4_act(M, W.vit_ff, sel=sel)
         qkv = self._empty(M, W.vit_layers[0].qkv_w.shape[0])
         cu = self._vit_cu_cache[n]
         scale = hd ** -0.5
@@ -691,12 +719,12 @@ class LeopardEngine:
         ops.gemm(h1, W.proj2_w, vis, bias=W.proj2_b, epilogue=_lib.EPI_STORE_F32)
         return vis
 
-    def encode_images(self, tiles: torch.Tensor) -> torch.Tensor:
+    def encode_images(self, tiles: torch.Tensor, lo4_tiles: Optional[Sequence[bool]] = None) -> torch.Tensor:
         if self.graph_encode and self.device.type == "cuda" and not self.ops.emulated and tiles.dtype == torch.uint8:
-            return self._encode_images_graph(tiles)
-        return self.project(self.vision_tower(tiles), tiles.shape[0])
+            return self._encode_images_graph(tiles, lo4_tiles)
+        return self.project(self.vision_tower(tiles, lo4_tiles), tiles.shape[0])
 
-    def _encode_images_graph(self, tiles: torch.Tensor) -> torch.Tensor:
+    def _encode_images_graph(self, tiles: torch.Tensor, lo4_tiles: Optional[Sequence[bool]] = None) -> torch.Tensor:
         """BASELINE config 5 ("hipGraph-captured encode"): the vision tower + projector for N ViT inputs is ~200 launches whose
         shapes depend on N only, so they are captured ONCE per N into a HIP graph over static buffers (u8 tiles in, fp32 visual
         tokens out) and replayed: one graph launch instead of ~200 stream launches, no per-launch host work.  Results are those
@@ -705,7 +733,7 @@ class LeopardEngine:
         n = tiles.shape[0]
         # one graph + static buffers per (N, launch stream): replays of one graph from two streams (bench.py --inflight > 1) would
         # share the static buffers with nothing ordering them
-        key = (n, torch.cuda.current_stream(self.device).cuda_stream)
+        key = (n, torch.cuda.current_stream(self.device).cuda_stream, None if lo4_tiles is None else tuple(bool(f) for f in lo4_tiles))
         ent = self._encode_graphs.get(key)
         if ent is None:
             static_in = torch.empty_like(tiles)
@@ -715,11 +743,11 @@ class LeopardEngine:
             self._private_scratch = True                                       # the graph owns its tower scratch (see _carve)
             try:
                 with torch.cuda.stream(side):
-                    self.project(self.vision_tower(static_in), n)
+                    self.project(self.vision_tower(static_in, lo4_tiles), n)
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    static_out = self.project(self.vision_tower(static_in), n)
+                    static_out = self.project(self.vision_tower(static_in, lo4_tiles), n)
             finally:
                 self._private_scratch = False
             if len(self._encode_graphs) >= 8:                                  # a handful of distinct N per workload; bound the pools
@@ -923,12 +951,13 @@ class LeopardEngine:
         n_tiles = 0
         if visual_tokens is None and tiles is not None and tiles.shape[0] > 0:
             n_tiles = tiles.shape[0]
+            vflags = self.lo4_vit_tiles([n_tiles], [input_ids.numel() + n_tiles * (self.cfg.tokens_per_tile - 1)])
             if keep_parts:
-                vit = self.vision_tower(tiles)
+                vit = self.vision_tower(tiles, vflags)
                 visual_tokens = self.project(vit, n_tiles)
                 parts["vit"] = vit
             else:
-                visual_tokens = self.encode_images(tiles)
+                visual_tokens = self.encode_images(tiles, vflags)
         elif visual_tokens is not None:
             n_tiles = visual_tokens.shape[0] // self.cfg.tokens_per_tile
         if keep_parts and visual_tokens is not None:
@@ -1151,7 +1180,10 @@ class LeopardEngine:
         visual = None
         if tiles:
             all_tiles = torch.cat(tiles, dim=0)
-            visual = self.encode_images(all_tiles)                 # the graph-captured encode when `graph_encode` is set
+            with_tiles = [(ids, t) for ids, t in samples if t is not None and t.shape[0] > 0]
+            vflags = self.lo4_vit_tiles([t.shape[0] for _, t in with_tiles],
+                                        [ids.numel() + t.shape[0] * (self.cfg.tokens_per_tile - 1) for ids, t in with_tiles])
+            visual = self.encode_images(all_tiles, vflags)         # the graph-captured encode when `graph_encode` is set
         xs, seq_lens, row = [], [], 0
         for ids, t in samples:
             n = 0 if t is None else t.shape[0]
@@ -1688,7 +1720,9 @@ class LeopardEngine:
         visual = None
         if tiles:
             all_tiles = torch.cat(tiles, dim=0)
-            visual = self.encode_images(all_tiles)
+            with_tiles = [(ids, t) for ids, t in samples if t is not None and t.shape[0] > 0]
+            visual = self.encode_images(all_tiles, self.lo4_vit_tiles([t.shape[0] for _, t in with_tiles],
+                                                                      [ids.numel() + t.shape[0] * (self.cfg.tokens_per_tile - 1) for ids, t in with_tiles]))
         xs, seq_lens, row = [], [], 0
         for ids, t in samples:
             n = 0 if t is None else t.shape[0]

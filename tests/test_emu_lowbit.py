@@ -303,7 +303,8 @@ def test_engine_lo4_mode_lands_on_the_oracle_prediction():
     with O.emulate_rounding(dtype, exact_sites=sites):
         floor = O.prefill_logits(ids, pix, Wt, cfg)[0]
     base = eng.prefill(ids, tiles, all_logits=True).logits_all.clone()
-    assert eng.precision == "fast" and eng.lo4_vit is False          # default: the LLM layers only
+    assert eng.precision == "fast" and eng.lo4_vit == "auto"         # default: the tower is corrected for short samples only; here: the LLM layers only
+    eng.lo4_vit = False
     eng.precision = "lo4"
     llm_only = eng.prefill(ids, tiles, all_logits=True).logits_all.clone()
     with O.emulate_rounding(dtype, lo_sites=("llm.norm", "llm.attn_out", "llm.mlp_act")):

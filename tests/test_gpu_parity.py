@@ -178,14 +178,15 @@ def rel_rms(a, b):
     return ((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt()).item()
 
 
-def run_full_depth(ops, fx, dtype, split=False, precision=None, lo4_vit=False, lo4_rows=None):
+def run_full_depth(ops, fx, dtype, split=False, precision=None, lo4_vit=None, lo4_rows=None):
     from leopard_amd.engine import LeopardEngine
     from leopard_amd.weights import EngineWeights, SynthSource
     cfg = full_config()
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, torch.device(DEV), dtype), dtype)
     eng = LeopardEngine(cfg, W, ops=ops, device=torch.device(DEV))
     eng.precision = precision or ("split" if split else "fast")
-    eng.lo4_vit = lo4_vit
+    if lo4_vit is not None:
+        eng.lo4_vit = lo4_vit                                             # default "auto": the tower corrected for short samples (C1), not for C2 / C3
     if lo4_rows is not None:
         eng.lo4_rows = lo4_rows
     probes = {}
@@ -515,7 +516,7 @@ def test_prefill_batch_equals_per_sample_prefill(ops, precision):
     cfg = mid_config()
     eng = build_engine(cfg, ops, torch.float16)
     eng.precision = precision.split("+")[0]
-    eng.lo4_vit = precision.endswith("+vit")
+    eng.lo4_vit = True if precision.endswith("+vit") else "auto"          # "auto": the short sample's ViT inputs are corrected, the others' are not — in the pack and alone
     shapes = [(1, 800, 500, 3), (2, 1344, 896, 5), (1, 336, 336, 7)]
     samples = []
     for n, w, h, seed in shapes:

@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--arms", default="all,none")
     ap.add_argument("--vit-lo4", type=int, default=0, help="1 = the SigLIP layer linears corrected too (engine.lo4_vit)")
+    ap.add_argument("--vit-fp8", type=int, default=0, help="1 = the SigLIP layer linears on e4m3 operands (per-tensor scales): what the tower's roundings cost "
+                                                           "the LAST row's logits when they are 128 x larger (they reach it only through the softmax average)")
     ap.add_argument("--weights-cache", default="/tmp/leopard_oracle_weights.pt")
     ap.add_argument("--embeds-cache", default=None, help="torch.save file of the merged embeddings (emulated tower) + fp32 reference logits")
     ap.add_argument("--out", default=None)
@@ -71,7 +73,7 @@ def main():
     n, w, h, n_vit, S = CASES[args.config]
     u8, ids, _ = sample_inputs(cfg, n, w, h, seed=args.seed)
     pix = torch.from_numpy(siglip_normalize(u8))
-    ec = args.embeds_cache or f"/tmp/lo4_policy_{args.config}_s{args.seed}_{args.dtype}_v{args.vit_lo4}.pt"
+    ec = args.embeds_cache or f"/tmp/lo4_policy_{args.config}_s{args.seed}_{args.dtype}_v{args.vit_lo4}_f{args.vit_fp8}.pt"
     if os.path.exists(ec):
         st = torch.load(ec)
         emb, pos, ref = st["emb"], st["pos"], st["ref"]
@@ -86,13 +88,14 @@ def main():
         if ref is None:
             ref = O.prefill_logits(ids, pix, Wt, cfg, last_only=True)[0, 0]
         vit_sites = ("vit.norm", "vit.attn_out", "vit.mlp_act") if args.vit_lo4 else ()
-        with O.emulate_rounding(dt, lo_sites=vit_sites):
+        with O.emulate_rounding(dt, lo_sites=vit_sites, operand_dtype=torch.float8_e4m3fn if args.vit_fp8 else None):
             feats = O.siglip_vision_tower(pix, Wt, cfg)
+        with O.emulate_rounding(dt):
             vis = O.projector(feats, Wt)
             emb, _, pos = O.embed_and_merge(ids, vis, Wt, cfg)
         torch.save({"emb": emb, "pos": pos, "ref": ref}, ec)
     out = open(args.out, "a") if args.out else sys.stdout
-    print(f"# tools/lo4_policy_study.py --config {args.config} --seed {args.seed} --dtype {args.dtype} --vit-lo4 {args.vit_lo4}: S = {emb.shape[1]}, "
+    print(f"# tools/lo4_policy_study.py --config {args.config} --seed {args.seed} --dtype {args.dtype} --vit-lo4 {args.vit_lo4} --vit-fp8 {args.vit_fp8}: S = {emb.shape[1]}, "
           f"max|logit| = {ref.abs().max().item():.3f}; {torch.get_num_threads()} host threads; tower + merge in {time.perf_counter() - t0:.0f} s", file=out)
     print(f"{'corrected Llama sites (lo4 = fp4 e2m1 residual x fp4 weight image)':<72} {'max-abs':>10} {'/ max|logit|':>13} {'rel RMS':>10} {'argmax':>7} {'s':>6}", file=out)
     out.flush()
