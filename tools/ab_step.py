@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--images", type=int, default=6)
     ap.add_argument("--out", default="")
+    ap.add_argument("--precision", default="fast", help="fast | lo4 | split (LeopardEngine.precision)")
     args = ap.parse_args()
     from leopard_amd.engine import KVCache, LeopardEngine
     from leopard_amd.gpu_tiler import GpuTiler
@@ -44,6 +45,7 @@ def main():
     ops = Ops()
     W = EngineWeights.build(cfg, SynthSource(cfg, ops, dev, dtype), dtype)
     eng = LeopardEngine(cfg, W, ops=ops, device=dev)
+    eng.precision = args.precision
     tiler = GpuTiler(ops, dev)
     u8, ids_np, plan, _, raw = bench.make_sample(cfg, args.images, 1344, 896, seed=0)
     raw_dev = [torch.from_numpy(np.array(r)).to(dev) for r in raw]

@@ -6,6 +6,8 @@ from leopard_amd import _lib
 from leopard_amd.ops import Ops
 from leopard_amd.weights import as_packed
 dev = torch.device("cuda:0"); ops = Ops(); dt = torch.float16
+for kv in filter(None, os.environ.get("LMI_OPTS", "").split(",")):      # e.g. LMI_OPTS=gemm.persist=0
+    k, v = kv.split("="); ops.set_option(k, int(v)); print("# option", k, v)
 g = torch.Generator(device=dev).manual_seed(1)
 def t(fn, n=20):
     for _ in range(3): fn()
