@@ -641,7 +641,7 @@ PRECISION_NOTE = {
     "fast": "fast: one rounding of every activation to the 16-bit compute type per MFMA-operand hand-over",
     "lo4": "lo4: fast + the MX fp4 image of the LLM layer-linear operands' rounding residuals multiplied with an fp4 weight image into the same "
            "accumulators (v_mfma_scale_f32_32x32x64_f8f6f4, + 25 % matrix time on the row tiles that run it), on the ROWS WHOSE LOGITS ARE READ: the "
-           "trailing rows of each sequence (engine.lo4_rows = 'auto': every row of a sequence up to 1024 rows, the last 256 rows of a longer one; "
+           "trailing rows of each sequence (engine.lo4_rows = 'auto': every row of a sequence up to 1024 rows, the last 16 rows of a longer one; "
            "LMI_LO4_ROWS=all restores every row) — a row's logits are dominated by the hand-over roundings on its own path through the layers, the "
            "other rows' reach it through the softmax average over ~S keys (see the `lo4_rows` object; algorithmic FLOPs below are the model's, not "
            "the extra MFMA work; --lo4-vit 1 / LMI_LO4_VIT=1 extends the correction to the SigLIP layer linears)",

@@ -556,7 +556,10 @@ class LeopardEngine:
 
     # ---- low-bit correction mode --------------------------------------------------------------------------------------------------------
     LO4_FULL_BELOW = 1024              # "auto": sequences up to this length carry the correction on every row ...
-    LO4_TAIL_ROWS = 256                # ... longer ones on their last LO4_TAIL_ROWS rows (tools/lo4_policy_study.py, profiles/r06_lo4_policy_study_*.txt)
+    LO4_TAIL_ROWS = 16                 # ... longer ones on their last LO4_TAIL_ROWS rows: the row whose logits are read + a margin of 15 (tools/lo4_policy_study.py,
+                                       # profiles/r06_lo4_policy_study_*.txt; on the device the last 1 / 16 / 64 / 256 / 1024 rows and every row all land at 2.4 - 2.8e-4 on
+                                       # C3 and 3.7 - 4.1e-4 on C2).  16 rows sit in ONE 256-row tile 15 times out of 16, so one row tile per sequence runs the fp4 k-tiles;
+                                       # 256 rows always straddled two (C2: 32.7 -> 31.6 ms, C3: 137.4 -> 137.0 ms on one box, profiles/r06_lo4_tail_rows_ab.txt)
 
     def _lo4_weights(self, tower: str = "llm"):
         """fp4 images (+ one E8M0 scale per row) of one tower's layer-linear weights, built from the row-major order of each weight when the

@@ -276,18 +276,18 @@ def test_full_depth_lo4_meets_1e_3(ops, full_depth_oracle, case):
         assert rel_rms(probes[last][-2:], fx.probe[last][-2:]) <= 0.8 * pred16
 
 
-@pytest.mark.parametrize("rows", ["all", 1, 64, 1024])
+@pytest.mark.parametrize("rows", ["all", 1, 64, 256, 1024])
 @pytest.mark.parametrize("case", ["c2", "c3"])
 def test_full_depth_lo4_row_policies(ops, full_depth_oracle, case, rows):
     """WHICH ROWS need the correction (round 6, engine.lo4_rows; predicted by tools/lo4_policy_study.py with the oracle's lo_row_start): the
     last-position logits are dominated by the roundings on the last row's own path; the other rows' roundings are averaged over ~S keys.  'all' is
-    round 5's schedule; the default 'auto' (the last 256 rows of a sequence longer than 1024) is what test_full_depth_lo4_meets_1e_3 runs."""
+    round 5's schedule, 256 the first half of round 6; the default 'auto' (the last 16 rows of a sequence longer than 1024) is what test_full_depth_lo4_meets_1e_3 runs."""
     fx = full_depth_oracle[case]
     got, _ = run_full_depth(ops, fx, torch.float16, precision="lo4", lo4_rows=rows)
     a, n, r = err_stats(got, fx.ref)
     print(f"[{case} full depth fp16, lo4 on the last {rows} rows] vs fp32 oracle: max-abs {a:.3e}  normalised-max {n:.3e}  rel-rms {r:.3e}")
     assert int(got.argmax()) == int(fx.ref.argmax())
-    if rows in ("all", 1024):
+    if rows in ("all", 256, 1024):
         assert n <= 1.0e-3
 
 
