@@ -124,5 +124,10 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built (run `make` or "
                 "`__graft_entry__.build()`); leopard_amd has no CPU fallback")
+        # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 and the library is linked against the system one; whichever is
+        # loaded first serves both (same soname).  Loaded in the order "library, then torch" the process ends up with a runtime torch was not
+        # built for and the first kernel launch reports "no ROCm-capable device" (seen with build() followed by smoke() in ONE process on a GPU
+        # box, round 6).  Device memory, streams and torch.distributed come from torch anyway: import it first, always.
+        import torch  # noqa: F401
         _LIB = bind(LIB_PATH)
     return _LIB

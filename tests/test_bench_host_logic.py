@@ -102,3 +102,26 @@ def test_tp_child_failures_cost_the_tp_object_not_the_line(monkeypatch, tmp_path
             assert "134" in res["error"] and "RCCL abort" in res["stderr_tail"]
         if case == "hang":
             assert "did not finish" in res["error"]
+
+
+def test_library_load_imports_torch_first():
+    """One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, the library is linked against the system one, and whichever is
+    loaded first serves both.  _lib.load() therefore imports torch BEFORE it dlopens the library (round 6: build() followed by smoke() in one
+    process loaded them the other way round and the first launch on the GPU box said "no ROCm-capable device").  Checked in a fresh
+    interpreter, on the order in which the two shared objects appear in the process's memory map."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys\n"
+            "from leopard_amd import _lib\n"
+            "assert 'torch' not in sys.modules\n"
+            "_lib.load()\n"
+            "assert 'torch' in sys.modules\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "hip = [l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l]\n"
+            "assert hip and len(set(hip)) == 1, set(hip)\n"                 # a single HIP runtime in the process ...
+            "assert '/torch/' in hip[0], hip[0]\n"                          # ... and it is the one torch was built with
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

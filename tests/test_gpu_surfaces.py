@@ -218,3 +218,14 @@ def test_idefics2_processor_and_model_on_device():
             break
         cur = torch.cat([cur, torch.tensor([[nxt]])], dim=1)
     assert got.device.type == "cuda" and got[0].tolist() == want
+
+
+@pytest.mark.gpu
+def test_build_then_smoke_in_one_process():
+    """`python __graft_entry__.py smoke` = build() + smoke() in ONE interpreter: the order in which the HIP runtimes get loaded there used to
+    leave the process with the system runtime under PyTorch (leopard_amd._lib.load now imports torch first)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "__graft_entry__.py"), "smoke"], cwd=repo, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "lo4 schedule" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
