@@ -449,8 +449,11 @@ struct GemmRowScale {
 // the epilogues that may finish a folded RMSNorm (the others never carry the row-scale registers)
 template <int EPI> struct GemmCanScale { static constexpr bool value = (EPI == EPI_STORE_T || EPI == EPI_SWIGLU_T || EPI == EPI_QKV_ROPE_T); };
 
+// `tile_sel` (workgroup-uniform; LO4 producers): does any row of this tile carry a residual image (gemm_tile_selected)?  A tile without one
+// must not even LOAD row_sel: 16 dependent byte loads per wave and tile in the exposed epilogue cost gate/up + 3.9 % and o / down + 2.5 % on
+// the C3 step, where 28 of 29 row tiles hold no selected row (round 6, profiles/r06_lo4_epilogue_rowsel_ab.txt).
 template <typename T, int EPI, int ACT, typename C, bool OUT4 = false, typename Put>
-LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, int wn, int lane, char* stage, const float* rstd_lds) {
+LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, int wn, int lane, char* stage, const float* rstd_lds, bool tile_sel = true) {
     typedef typename vec_of<T>::x8 T8;
     constexpr int RS = GemmImage<C::WTN>::RS;
     static_assert(32 * RS <= C::SMEM / (C::NT / 64), "per-wave LDS slice too small for the epilogue image");
@@ -559,7 +562,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
                     o[4 + e] = OutCvt<T>::cvt(sep_rn(fast_silu(g1[e]) * u1[e] * os));
                 }
                 if constexpr (OUT4 && sizeof(T) == 2) {
-                    const bool sel = !p.row_sel || p.row_sel[m < p.M ? m : p.M - 1];
+                    const bool sel = tile_sel && (!p.row_sel || p.row_sel[m < p.M ? m : p.M - 1]);
                     if (p.out4 && wave_any(sel)) {                   // (wave-uniform) residual image of the products: a row's 4 lanes = one 32-column block
                         float y[8];
 #pragma unroll
@@ -638,7 +641,7 @@ LMI_DEV void gemm_epilogue(const GemmArgs& p, Put put, int m0, int n0, int wm, i
             T8 o4;
             bool sel4 = false;
             if constexpr (OUT4 && sizeof(T) == 2 && (EPI == EPI_STORE_T || EPI == EPI_RESID_F32)) {
-                if (p.out4 && (EPI == EPI_STORE_T || p.norm_out)) sel4 = !p.row_sel || p.row_sel[imin(mb + it * RPI + r_in, p.M - 1)];
+                if (tile_sel && p.out4 && (EPI == EPI_STORE_T || p.norm_out)) sel4 = !p.row_sel || p.row_sel[imin(mb + it * RPI + r_in, p.M - 1)];
                 if (wave_any(sel4)) {
                     float y[8];
 #pragma unroll
@@ -901,7 +904,7 @@ __global__ void __launch_bounds__(C::NT) gemm_kernel(GemmArgs p) {
     if (CAN_SCALE && p.rowsq_in) row_scale.finish(p, tid, rstd_lds);   // published by the barrier below
     raw_barrier();                                                 // every wave is done reading k-tiles: LDS is free
     gemm_epilogue<T, EPI, ACT, C, LO4>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
-                                  smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds);
+                                  smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds, !LO4 || sel_tile);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1075,7 +1078,7 @@ __global__ void __launch_bounds__(C::NT) gemm_stagger_kernel(GemmArgs p) {
     }
     // past its last barrier a wave knows that every other wave has finished its last LOAD segment: LDS is free
     gemm_epilogue<T, EPI, ACT, C, LO4>(p, [&](int mi, char* st) { gemm_put32<C>(acc, mi, lane, st); }, m0, n0, wm, wn, lane,
-                                  smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds);
+                                  smem + wave * (C::SMEM / (C::NT / 64)), rstd_lds, !LO4 || sel_tile);
 }
 
 }  // namespace lmi

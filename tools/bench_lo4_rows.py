@@ -29,9 +29,10 @@ def t(fn, n=30):
 H, KV, hd, D, F = 32, 8, 128, 4096, 14336
 pos = torch.arange(M, device=dev).float(); inv = 1.0 / (5e5 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
 cos, sin = (pos[:, None] * inv[None]).cos().contiguous(), (pos[:, None] * inv[None]).sin().contiguous()
-sel = sel_of(range(M - 256, M))
+ROWS = int(os.environ.get("ROWS", "256"))
+sel = sel_of(range(M - ROWS, M))
 shapes = {"q|k|v": ((H + 2 * KV) * hd, D), "o_proj": (D, D), "gate/up": (2 * F, D), "down": (D, F)}
-print(f"{'':10s} {'fast':>9s} {'lo4 all':>9s} {'sel plain':>10s} {'sel first':>10s} {'sel first, ragged last':>22s}   (us per launch, M = {M}, last 256 rows selected)")
+print(f"{'':10s} {'fast':>9s} {'lo4 all':>9s} {'sel plain':>10s} {'sel first':>10s} {'sel first, ragged last':>22s}   (us per launch, M = {M}, last {ROWS} rows selected)")
 for name, (N, K) in shapes.items():
     x = torch.randn(M, K, generator=g, device=dev)
     w = (torch.randn(N, K, generator=g, device=dev) * 0.02).to(dt)
