@@ -125,8 +125,9 @@ LMI_DEV bool gemm_tile_selected(const GemmArgs& p, int m0, int bm) {
 }
 
 constexpr int GEMM_BK = 64;
-constexpr int GEMM_GROUP_M = 5;                 // end-to-end sweeps 2..16 on the C3 prefill: 4-6 best (-0.5 % vs 8), 16 +4 %; round 6, lo4 with the selected row tiles
-                                                // first: 5 is 0.3 - 0.5 % ahead of 4 (fast schedule, C2: +-0; profiles/r06_group_m_ab.txt) — order only, same bits
+constexpr int GEMM_GROUP_M = 4;                 // end-to-end sweep 2..16 on the C3 prefill: 4-6 best (-0.5 % vs 8), 16 +4 %; round 6 (profiles/r06_group_m_ab.txt): 4 x 8
+                                                // tiles per XCD patch is also the HBM-side fetch minimum (1.37 GB per GEMM launch; 3: 1.41, 5: 1.47, 8: 1.67) — 5 is 0.3 - 0.5 %
+                                                // faster on the lo4 step and moves 7.5 % more bytes: not taken
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int STAGES_>
 struct GemmCfg {

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from leopard_amd.config import full_config  # noqa: E402
 
-DEFAULTS = {"gemm.config": -1, "gemm.group_m": 5, "gemm.order": 0, "gemm.wide": 5, "gemm.short_k": 5, "gemm.narrow_n": 2,
+DEFAULTS = {"gemm.config": -1, "gemm.group_m": 4, "gemm.order": 0, "gemm.wide": 5, "gemm.short_k": 5, "gemm.narrow_n": 2,
             "gemm.small": 0, "gemm.auto_small": 1, "gemm.sel_ragged_last": 0, "attn.dma": 1, "attn.lds_pad": 0, "attn.rows64": 0, "attn.rows64_min": 1024}
 
 
